@@ -1,0 +1,945 @@
+/*
+ * sylow_oracle.c -- CPU restatement (plain C, unsigned __int128) of sylow's BN254 hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product path (sylow_amd/, libsylow_hip.so) never links,
+ * loads or calls it.
+ *
+ * The reference (warlock-labs/sylow @ 2024-10-22) is Rust-only and its Fp arithmetic lives in
+ * the un-vendored crate crypto-bigint 0.6.0-rc.3 (Cargo.toml:39), Keccak in sha3 0.11.0-pre.4
+ * (Cargo.toml:41): it can be neither compiled nor imported in the authoring container.  This
+ * file therefore RESTATES the algorithm; every function cites the reference lines it follows
+ * (paths relative to /root/reference).  Results of field/Gt operations are exact residues, so
+ * they are independent of the Montgomery plumbing used here.
+ *
+ * Parity status: pinned by the reference's own known-answer vectors (tests/golden/
+ * reference_kats.json: Fp/Fp2/Fp6 products and quotients, Frobenius tables, psi constants,
+ * SvdW constants, Gt generator, pairing test_cases KAT, EIP-197 pairing vector) and
+ * cross-checked against the independent Python big-int restatement oracle/pyref.py.
+ * The Keccak-256 XMD -> hash_to_field -> SvdW -> sign chain is PARITY UNPINNED by the
+ * reference (no literal in its tests); it is pinned by public Keccak-256 KATs, the RFC 9380
+ * SHA-256 vectors run through the same XMD routine, and sign/verify round trips.
+ *
+ * Boundary format: every Fp is 4 little-endian uint64 limbs holding the canonical value in
+ * [0,p) (what sylow's Fp::value().to_words() yields, fp.rs:232-234).  Array-of-structs.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+typedef struct { u64 l[4]; } fp;          /* Montgomery form internally */
+typedef struct { fp c0, c1; } fp2;
+typedef struct { fp2 c0, c1, c2; } fp6;
+typedef struct { fp6 c0, c1; } fp12;
+
+/* fp.rs:51-56 modulus; R = 2^256 */
+static const u64 PMOD[4] = {0x3C208C16D87CFD47ull, 0x97816A916871CA8Dull, 0xB85045B68181585Dull, 0x30644E72E131A029ull};
+static const u64 PINV = 0x87D20782E4866389ull;   /* -p^-1 mod 2^64 */
+static const fp R2 = {{0xF32CFC5B538AFA89ull, 0xB5E71911D44501FBull, 0x47AB1EFF0A417FF6ull, 0x06D89F71CAB8351Full}};
+static const fp FP_ZERO = {{0, 0, 0, 0}};
+
+/* ---------------------------------------------------------------- Fp ---------------------- */
+static int geq_p(const u64 a[4]) {
+  for (int i = 3; i >= 0; --i) { if (a[i] > PMOD[i]) return 1; if (a[i] < PMOD[i]) return 0; }
+  return 1;
+}
+static void sub_p(u64 a[4]) {
+  u128 b = 0;
+  for (int i = 0; i < 4; ++i) { u128 t = (u128)a[i] - PMOD[i] - (u64)b; a[i] = (u64)t; b = (t >> 64) & 1; }
+}
+/* Montgomery product (CIOS); stands in for crypto-bigint ConstMontyForm mul (fp.rs:387-393) */
+static fp fp_mul(fp a, fp b) {
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+    c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+    u64 m = t[0] * PINV;
+    c = (u128)m * PMOD[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; ++j) { c += (u128)m * PMOD[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+    c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+  }
+  fp r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq_p(r.l)) sub_p(r.l);
+  return r;
+}
+static fp fp_sqr(fp a) { return fp_mul(a, a); }                      /* fp.rs:620-622 */
+static fp fp_add(fp a, fp b) {                                      /* fp.rs:304-310 */
+  fp r; u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (u64)c; c >>= 64; }
+  if (c || geq_p(r.l)) sub_p(r.l);
+  return r;
+}
+static fp fp_neg(fp a) {                                            /* fp.rs:442-449 */
+  if (!(a.l[0] | a.l[1] | a.l[2] | a.l[3])) return a;
+  fp r; u128 b = 0;
+  for (int i = 0; i < 4; ++i) { u128 t = (u128)PMOD[i] - a.l[i] - (u64)b; r.l[i] = (u64)t; b = (t >> 64) & 1; }
+  return r;
+}
+static fp fp_sub(fp a, fp b) { return fp_add(a, fp_neg(b)); }        /* fp.rs:340-347 */
+static int fp_is_zero(fp a) { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
+static int fp_eq(fp a, fp b) { return !memcmp(&a, &b, sizeof(fp)); }
+/* Fp::new: reduce any 256-bit value (fp.rs:199-201); value(): fp.rs:232-234 */
+static fp fp_from_words(const u64 w[4]) {
+  fp r = {{w[0], w[1], w[2], w[3]}};
+  while (geq_p(r.l)) sub_p(r.l);       /* inputs < 2^256 < 6p */
+  return fp_mul(r, R2);
+}
+static void fp_to_words(fp a, u64 w[4]) {
+  fp one = {{1, 0, 0, 0}};
+  fp r = fp_mul(a, one);
+  memcpy(w, r.l, 32);
+}
+static fp fp_from_u64(u64 v) { u64 w[4] = {v, 0, 0, 0}; return fp_from_words(w); }
+/* Fp::pow with a 256-bit exponent, MSB-first square-and-multiply (fp.rs:451-457 -> crypto-bigint pow) */
+static fp fp_pow(fp a, const u64 e[4]) {
+  fp r = fp_from_u64(1);
+  for (int i = 255; i >= 0; --i) {
+    r = fp_sqr(r);
+    if ((e[i >> 6] >> (i & 63)) & 1) r = fp_mul(r, a);
+  }
+  return r;
+}
+static void p_minus(u64 k, u64 out[4]) { memcpy(out, PMOD, 32); out[0] -= k; }   /* k small */
+/* inv via a^(p-2): same value as crypto-bigint's safegcd; inv(0) = 0 (fp.rs:418-433,1126-1132) */
+static fp fp_inv(fp a) { u64 e[4]; p_minus(2, e); return fp_pow(a, e); }
+static void shr_words(u64 w[4], int k) {
+  for (int i = 0; i < 4; ++i) w[i] = (w[i] >> k) | (i < 3 ? w[i + 1] << (64 - k) : 0);
+}
+/* sqrt = a^((p+1)/4) with check (fp.rs:611-616); returns 1 when a is a square */
+static int fp_sqrt(fp a, fp *out) {
+  u64 e[4]; memcpy(e, PMOD, 32); e[0] += 1; shr_words(e, 2);
+  fp s = fp_pow(a, e); *out = s;
+  return fp_eq(fp_sqr(s), a);
+}
+/* is_square: a^((p-1)/2) in {0,1} (fp.rs:625-631) */
+static int fp_is_square(fp a) {
+  u64 e[4]; p_minus(1, e); shr_words(e, 1);
+  fp r = fp_pow(a, e);
+  return fp_is_zero(r) || fp_eq(r, fp_from_u64(1));
+}
+static int fp_sgn0(fp a) { u64 w[4]; fp_to_words(a, w); return (int)(w[0] & 1); }   /* fp.rs:636-644 */
+
+/* ---------------------------------------------------------------- Fp2 (fp2.rs) ------------- */
+static fp NINE, TWO_INV_C, ONE_C, THREE_C;
+static fp2 TWIST_B, EPS0, EPS1, FROB6_C1[6], FROB6_C2[6], FROB12_C1[12], FP2_ZERO_C, FP2_ONE_C;
+static fp6 FP6_ZERO_C, FP6_ONE_C;
+static fp12 FP12_ONE_C;
+
+static fp2 fp2_add(fp2 a, fp2 b) { fp2 r = {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; return r; }
+static fp2 fp2_sub(fp2 a, fp2 b) { fp2 r = {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; return r; }
+static fp2 fp2_neg(fp2 a) { fp2 r = {fp_neg(a.c0), fp_neg(a.c1)}; return r; }
+static int fp2_is_zero(fp2 a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+static int fp2_eq(fp2 a, fp2 b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+/* fp2.rs:285-306 schoolbook */
+static fp2 fp2_mul(fp2 a, fp2 b) {
+  fp2 r = {fp_sub(fp_mul(a.c0, b.c0), fp_mul(a.c1, b.c1)), fp_add(fp_mul(a.c0, b.c1), fp_mul(a.c1, b.c0))};
+  return r;
+}
+/* fp2.rs:164-171 */
+static fp2 fp2_sqr(fp2 a) {
+  fp s = fp_add(a.c0, a.c1), d = fp_sub(a.c0, a.c1), c = fp_add(a.c0, a.c0);
+  fp2 r = {fp_mul(s, d), fp_mul(c, a.c1)};
+  return r;
+}
+/* extensions.rs:86-94 */
+static fp2 fp2_scale(fp2 a, fp k) { fp2 r = {fp_mul(a.c0, k), fp_mul(a.c1, k)}; return r; }
+/* fp2.rs:99-107: x(9+u) */
+static fp2 fp2_mul_xi(fp2 a) {
+  fp2 r = {fp_sub(fp_mul(NINE, a.c0), a.c1), fp_add(a.c0, fp_mul(NINE, a.c1))};
+  return r;
+}
+/* fp2.rs:355-360 (QNR = -1) */
+static fp2 fp2_inv(fp2 a) {
+  fp t = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+  fp2 r = {fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
+  return r;
+}
+/* fp2.rs:119-133 */
+static fp2 fp2_frob(fp2 a, int e) { if (e & 1) a.c1 = fp_neg(a.c1); return a; }
+static fp2 fp2_from_u64(u64 v) { fp2 r = {fp_from_u64(v), FP_ZERO}; return r; }
+
+/* ---------------------------------------------------------------- Fp6 (fp6.rs) ------------- */
+static fp6 fp6_add(fp6 a, fp6 b) { fp6 r = {fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)}; return r; }
+static fp6 fp6_sub(fp6 a, fp6 b) { fp6 r = {fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)}; return r; }
+static fp6 fp6_neg(fp6 a) { fp6 r = {fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)}; return r; }
+/* fp6.rs:283-367: the 36-product schoolbook, regrouped per Fp2 coefficient with v^3 = xi */
+static fp6 fp6_mul(fp6 a, fp6 b) {
+  fp6 r;
+  r.c0 = fp2_add(fp2_mul(a.c0, b.c0), fp2_mul_xi(fp2_add(fp2_mul(a.c1, b.c2), fp2_mul(a.c2, b.c1))));
+  r.c1 = fp2_add(fp2_add(fp2_mul(a.c0, b.c1), fp2_mul(a.c1, b.c0)), fp2_mul_xi(fp2_mul(a.c2, b.c2)));
+  r.c2 = fp2_add(fp2_add(fp2_mul(a.c0, b.c2), fp2_mul(a.c1, b.c1)), fp2_mul(a.c2, b.c0));
+  return r;
+}
+/* fp6.rs:219-236 (CH-SQR2) */
+static fp6 fp6_sqr(fp6 a) {
+  fp2 t0 = fp2_sqr(a.c0);
+  fp2 cross = fp2_mul(a.c0, a.c1);
+  fp2 t1 = fp2_add(cross, cross);
+  fp2 t2 = fp2_sqr(fp2_add(fp2_sub(a.c0, a.c1), a.c2));
+  fp2 bc = fp2_mul(a.c1, a.c2);
+  fp2 s3 = fp2_add(bc, bc);
+  fp2 s4 = fp2_sqr(a.c2);
+  fp6 r = {fp2_add(t0, fp2_mul_xi(s3)), fp2_add(t1, fp2_mul_xi(s4)),
+           fp2_sub(fp2_sub(fp2_add(fp2_add(t1, t2), s3), t0), s4)};
+  return r;
+}
+/* fp6.rs:189-191 */
+static fp6 fp6_mul_v(fp6 a) { fp6 r = {fp2_mul_xi(a.c2), a.c0, a.c1}; return r; }
+static fp6 fp6_scale(fp6 a, fp2 k) { fp6 r = {fp2_mul(a.c0, k), fp2_mul(a.c1, k), fp2_mul(a.c2, k)}; return r; }
+/* fp6.rs:415-423 */
+static fp6 fp6_inv(fp6 a) {
+  fp2 t0 = fp2_sub(fp2_sqr(a.c0), fp2_mul(a.c1, fp2_mul_xi(a.c2)));
+  fp2 t1 = fp2_sub(fp2_mul_xi(fp2_sqr(a.c2)), fp2_mul(a.c0, a.c1));
+  fp2 t2 = fp2_sub(fp2_sqr(a.c1), fp2_mul(a.c0, a.c2));
+  fp2 inv = fp2_inv(fp2_add(fp2_mul_xi(fp2_add(fp2_mul(a.c2, t1), fp2_mul(a.c1, t2))), fp2_mul(a.c0, t0)));
+  fp6 r = {fp2_mul(inv, t0), fp2_mul(inv, t1), fp2_mul(inv, t2)};
+  return r;
+}
+/* fp6.rs:203-209 */
+static fp6 fp6_frob(fp6 a, int e) {
+  fp6 r = {fp2_frob(a.c0, e), fp2_mul(fp2_frob(a.c1, e), FROB6_C1[e % 6]), fp2_mul(fp2_frob(a.c2, e), FROB6_C2[e % 6])};
+  return r;
+}
+
+/* ---------------------------------------------------------------- Fp12 (fp12.rs) ----------- */
+/* fp12.rs:229-238 */
+static fp12 fp12_mul(fp12 a, fp12 b) {
+  fp6 t0 = fp6_mul(a.c0, b.c0), t1 = fp6_mul(a.c1, b.c1);
+  fp12 r = {fp6_add(fp6_mul_v(t1), t0),
+            fp6_sub(fp6_sub(fp6_mul(fp6_add(a.c0, a.c1), fp6_add(b.c0, b.c1)), t0), t1)};
+  return r;
+}
+/* fp12.rs:536-550 */
+static fp12 fp12_sqr(fp12 a) {
+  fp6 c0 = fp6_sub(a.c0, a.c1);
+  fp6 c3 = fp6_sub(a.c0, fp6_mul_v(a.c1));
+  fp6 c2 = fp6_mul(a.c0, a.c1);
+  c0 = fp6_add(fp6_mul(c0, c3), c2);
+  fp6 c1 = fp6_add(c2, c2);
+  c2 = fp6_mul_v(c2);
+  fp12 r = {fp6_add(c0, c2), c1};
+  return r;
+}
+/* fp12.rs:281-286 */
+static fp12 fp12_inv(fp12 a) {
+  fp6 t = fp6_inv(fp6_sub(fp6_sqr(a.c0), fp6_mul_v(fp6_sqr(a.c1))));
+  fp12 r = {fp6_mul(a.c0, t), fp6_neg(fp6_mul(a.c1, t))};
+  return r;
+}
+/* fp12.rs:381-383 */
+static fp12 fp12_conj(fp12 a) { a.c1 = fp6_neg(a.c1); return a; }
+/* fp12.rs:515-522 */
+static fp12 fp12_frob(fp12 a, int e) {
+  fp12 r = {fp6_frob(a.c0, e), fp6_scale(fp6_frob(a.c1, e), FROB12_C1[e % 12])};
+  return r;
+}
+/* fp12.rs:426-503 (zcash/bn mul_by_024 operation sequence) */
+static fp12 fp12_sparse_mul(fp12 f, fp2 ell_0, fp2 ell_vw, fp2 ell_vv) {
+  fp2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
+  fp2 x0 = ell_0, x2 = ell_vv, x4 = ell_vw;
+  fp2 d0 = fp2_mul(z0, x0), d2 = fp2_mul(z2, x2), d4 = fp2_mul(z4, x4);
+  fp2 t2 = fp2_add(z0, z4), t1 = fp2_add(z0, z2), s0 = fp2_add(fp2_add(z1, z3), z5);
+  fp2 s1 = fp2_mul(z1, x2);
+  fp2 t3 = fp2_add(s1, d4);
+  fp2 t4 = fp2_add(fp2_mul_xi(t3), d0);
+  fp2 n0 = t4;
+  t3 = fp2_mul(z5, x4); s1 = fp2_add(s1, t3); t3 = fp2_add(t3, d2); t4 = fp2_mul_xi(t3);
+  t3 = fp2_mul(z1, x0); s1 = fp2_add(s1, t3); t4 = fp2_add(t4, t3);
+  fp2 n1 = t4;
+  fp2 t0 = fp2_add(x0, x2);
+  t3 = fp2_sub(fp2_sub(fp2_mul(t1, t0), d0), d2);
+  t4 = fp2_mul(z3, x4); s1 = fp2_add(s1, t4); t3 = fp2_add(t3, t4);
+  t0 = fp2_add(z2, z4);
+  fp2 n2 = t3;
+  t1 = fp2_add(x2, x4);
+  t3 = fp2_sub(fp2_sub(fp2_mul(t0, t1), d2), d4);
+  t4 = fp2_mul_xi(t3);
+  t3 = fp2_mul(z3, x0); s1 = fp2_add(s1, t3); t4 = fp2_add(t4, t3);
+  fp2 n3 = t4;
+  t3 = fp2_mul(z5, x2); s1 = fp2_add(s1, t3); t4 = fp2_mul_xi(t3);
+  t0 = fp2_add(x0, x4);
+  t3 = fp2_sub(fp2_sub(fp2_mul(t2, t0), d0), d4);
+  t4 = fp2_add(t4, t3);
+  fp2 n4 = t4;
+  t0 = fp2_add(fp2_add(x0, x2), x4);
+  t3 = fp2_sub(fp2_mul(s0, t0), s1);
+  fp2 n5 = t3;
+  fp12 r = {{n0, n1, n2}, {n3, n4, n5}};
+  return r;
+}
+static int fp12_eq(fp12 a, fp12 b) { return !memcmp(&a, &b, sizeof(fp12)); }
+
+/* ---------------------------------------------------------------- constants ---------------- */
+static fp2 fp2_pow_words(fp2 a, const u64 *e, int nbits) {
+  fp2 r = FP2_ONE_C;
+  for (int i = nbits - 1; i >= 0; --i) {
+    r = fp2_sqr(r);
+    if ((e[i >> 6] >> (i & 63)) & 1) r = fp2_mul(r, a);
+  }
+  return r;
+}
+static int g_init_done = 0;
+static void oracle_init(void) {
+  if (g_init_done) return;
+  NINE = fp_from_u64(9); ONE_C = fp_from_u64(1); THREE_C = fp_from_u64(3);
+  TWO_INV_C = fp_inv(fp_from_u64(2));                               /* fp2.rs:18-23 */
+  FP2_ZERO_C.c0 = FP_ZERO; FP2_ZERO_C.c1 = FP_ZERO;
+  FP2_ONE_C.c0 = ONE_C; FP2_ONE_C.c1 = FP_ZERO;
+  FP6_ZERO_C.c0 = FP6_ZERO_C.c1 = FP6_ZERO_C.c2 = FP2_ZERO_C;
+  FP6_ONE_C = FP6_ZERO_C; FP6_ONE_C.c0 = FP2_ONE_C;
+  FP12_ONE_C.c0 = FP6_ONE_C; FP12_ONE_C.c1 = FP6_ZERO_C;
+  fp2 xi = {NINE, ONE_C};
+  TWIST_B = fp2_mul(fp2_from_u64(3), fp2_inv(xi));                  /* fp2.rs:42-55: 3/(9+u) */
+  /* g1 = xi^((p-1)/6); g_i = xi^((p^i-1)/6) = g1 * conj(g_{i-1})  (fp12.rs:29-172 table) */
+  u64 e[4]; p_minus(1, e);
+  { /* divide by 6: (p-1)/6 exact */
+    u128 rem = 0;
+    for (int i = 3; i >= 0; --i) { u128 cur = (rem << 64) | e[i]; e[i] = (u64)(cur / 6); rem = cur % 6; }
+  }
+  fp2 g1 = fp2_pow_words(xi, e, 256);
+  FROB12_C1[0] = FP2_ONE_C;
+  for (int i = 1; i < 12; ++i) FROB12_C1[i] = fp2_mul(g1, fp2_frob(FROB12_C1[i - 1], 1));
+  for (int i = 0; i < 6; ++i) {                                     /* fp6.rs:40-179 */
+    FROB6_C1[i] = fp2_sqr(FROB12_C1[i]);                            /* xi^((p^i-1)/3) */
+    FROB6_C2[i] = fp2_sqr(FROB6_C1[i]);                             /* xi^((2p^i-2)/3) */
+  }
+  EPS0 = FROB6_C1[1];                                               /* g2.rs:80-94  xi^((p-1)/3) */
+  EPS1 = fp2_mul(FROB6_C1[1], FROB12_C1[1]);                        /* g2.rs:95-109 xi^((p-1)/2) */
+  g_init_done = 1;
+}
+
+/* ---------------------------------------------------------------- groups (group.rs) -------- */
+typedef struct { fp x, y, z; } g1p;
+typedef struct { fp2 x, y, z; } g2p;
+typedef struct { fp x, y; int inf; } g1a;
+typedef struct { fp2 x, y; int inf; } g2a;
+
+#define DEFINE_GROUP(T, F, PFX, ADD, SUB, NEG, MUL, ISZ, EQ, B3EXPR, ZERO, ONE)                                  \
+  static T PFX##_zero(void) { T r = {ZERO, ONE, ZERO}; return r; }              /* group.rs:310-316 */          \
+  static int PFX##_is_zero(T p) { return ISZ(p.z); }                                                            \
+  /* group.rs:339-386, RCB'15 algorithm 9 (a = 0) */                                                            \
+  static T PFX##_double(T p) {                                                                                  \
+    F b3 = B3EXPR;                                                                                              \
+    F t0 = MUL(p.y, p.y); F z3 = ADD(t0, t0); z3 = ADD(z3, z3); z3 = ADD(z3, z3);                               \
+    F t1 = MUL(p.y, p.z); F t2 = MUL(p.z, p.z); t2 = MUL(b3, t2);                                               \
+    F x3 = MUL(t2, z3); F y3 = ADD(t0, t2); z3 = MUL(t1, z3); t1 = ADD(t2, t2); t2 = ADD(t1, t2);               \
+    t0 = SUB(t0, t2); y3 = MUL(t0, y3); y3 = ADD(x3, y3); t1 = MUL(p.x, p.y); x3 = MUL(t0, t1);                 \
+    x3 = ADD(x3, x3);                                                                                           \
+    if (PFX##_is_zero(p)) return PFX##_zero();                                                                  \
+    T r = {x3, y3, z3}; return r;                                                                               \
+  }                                                                                                             \
+  /* group.rs:528-599, RCB'15 algorithm 7 (a = 0) */                                                            \
+  static T PFX##_add(T p, T q) {                                                                                \
+    F b3 = B3EXPR;                                                                                              \
+    F t0 = MUL(p.x, q.x), t1 = MUL(p.y, q.y), t2 = MUL(p.z, q.z);                                               \
+    F t3 = MUL(ADD(p.x, p.y), ADD(q.x, q.y)); t3 = SUB(t3, ADD(t0, t1));                                        \
+    F t4 = MUL(ADD(p.y, p.z), ADD(q.y, q.z)); t4 = SUB(t4, ADD(t1, t2));                                        \
+    F y3 = SUB(MUL(ADD(p.x, p.z), ADD(q.x, q.z)), ADD(t0, t2));                                                 \
+    F x3 = ADD(t0, t0); t0 = ADD(x3, t0); t2 = MUL(b3, t2);                                                     \
+    F z3 = ADD(t1, t2); t1 = SUB(t1, t2); y3 = MUL(b3, y3);                                                     \
+    x3 = MUL(t4, y3); t2 = MUL(t3, t1); x3 = SUB(t2, x3);                                                       \
+    y3 = MUL(y3, t0); t1 = MUL(t1, z3); y3 = ADD(t1, y3);                                                       \
+    t0 = MUL(t0, t3); z3 = MUL(z3, t4); z3 = ADD(z3, t0);                                                       \
+    T r = {x3, y3, z3}; return r;                                                                               \
+  }                                                                                                             \
+  static T PFX##_neg(T p) { p.y = NEG(p.y); return p; }                                                         \
+  /* group.rs:639-667: 256-step MSB-first NAF; scalar is an Fp value (NOT reduced mod r) */                     \
+  static T PFX##_scalar_mul(T p, const u64 k[4]) {                                                              \
+    u64 xh[4], x3[4], np[4], nm[4];                                      /* fp.rs:653-662 compute_naf */        \
+    for (int i = 0; i < 4; ++i) xh[i] = (k[i] >> 1) | (i < 3 ? k[i + 1] << 63 : 0);                             \
+    u128 c = 0;                                                                                                 \
+    for (int i = 0; i < 4; ++i) { c += (u128)k[i] + xh[i]; x3[i] = (u64)c; c >>= 64; }                          \
+    for (int i = 0; i < 4; ++i) { u64 cc = xh[i] ^ x3[i]; np[i] = x3[i] & cc; nm[i] = xh[i] & cc; }             \
+    T res = PFX##_zero(); T neg = PFX##_neg(p);                                                                 \
+    for (int i = 255; i >= 0; --i) {                                                                            \
+      res = PFX##_double(res);                                                                                  \
+      if ((np[i >> 6] >> (i & 63)) & 1) res = PFX##_add(res, p);                                                \
+      else if ((nm[i >> 6] >> (i & 63)) & 1) res = PFX##_add(res, neg);                                         \
+    }                                                                                                           \
+    return res;                                                                                                 \
+  }
+
+DEFINE_GROUP(g1p, fp, g1, fp_add, fp_sub, fp_neg, fp_mul, fp_is_zero, fp_eq, fp_mul(THREE_C, THREE_C), FP_ZERO, ONE_C)
+DEFINE_GROUP(g2p, fp2, g2, fp2_add, fp2_sub, fp2_neg, fp2_mul, fp2_is_zero, fp2_eq, fp2_mul(fp2_from_u64(3), TWIST_B), FP2_ZERO_C, FP2_ONE_C)
+
+/* group.rs:475-495: infinity iff Z^-1 == 0 -> (0, 1, inf) */
+static g1a g1_to_affine(g1p p) {
+  fp inv = fp_inv(p.z);
+  if (fp_is_zero(inv)) { g1a r = {FP_ZERO, ONE_C, 1}; return r; }
+  g1a r = {fp_mul(p.x, inv), fp_mul(p.y, inv), 0}; return r;
+}
+static g2a g2_to_affine(g2p p) {
+  fp2 inv = fp2_inv(p.z);
+  if (fp2_is_zero(inv)) { g2a r = {FP2_ZERO_C, FP2_ONE_C, 1}; return r; }
+  g2a r = {fp2_mul(p.x, inv), fp2_mul(p.y, inv), 0}; return r;
+}
+/* group.rs:506-517 */
+static g1p g1_from_affine(g1a a) { g1p r = {a.x, a.y, a.inf ? FP_ZERO : ONE_C}; return r; }
+static g2p g2_from_affine(g2a a) { g2p r = {a.x, a.y, a.inf ? FP2_ZERO_C : FP2_ONE_C}; return r; }
+static g1a g1_gen(void) { g1a r = {ONE_C, fp_from_u64(2), 0}; return r; }          /* g1.rs:54-60 */
+static g2a g2_gen(void) {                                                         /* g2.rs:47-77 */
+  static const u64 xc0[4] = {0x46DEBD5CD992F6EDull, 0x674322D4F75EDADDull, 0x426A00665E5C4479ull, 0x1800DEEF121F1E76ull};
+  static const u64 xc1[4] = {0x97E485B7AEF312C2ull, 0xF1AA493335A9E712ull, 0x7260BFB731FB5D25ull, 0x198E9393920D483Aull};
+  static const u64 yc0[4] = {0x4CE6CC0166FA7DAAull, 0xE3D1E7690C43D37Bull, 0x4AAB71808DCB408Full, 0x12C85EA5DB8C6DEBull};
+  static const u64 yc1[4] = {0x55ACDADCD122975Bull, 0xBC4B313370B38EF3ull, 0xEC9E99AD690C3395ull, 0x090689D0585FF075ull};
+  g2a r = {{fp_from_words(xc0), fp_from_words(xc1)}, {fp_from_words(yc0), fp_from_words(yc1)}, 0};
+  return r;
+}
+/* g1.rs:111-132 */
+static int g1_on_curve_affine(fp x, fp y) { return fp_eq(fp_sub(fp_sqr(y), fp_mul(fp_sqr(x), x)), THREE_C); }
+/* g2.rs:279-297 */
+static int g2_on_curve_affine(fp2 x, fp2 y) { return fp2_eq(fp2_sub(fp2_sqr(y), fp2_mul(fp2_sqr(x), x)), TWIST_B); }
+/* g2.rs:140-152 psi; *ok = 0 where the reference would panic ("Endomorphism failed") */
+static g2a g2_psi_affine(g2a a, int *ok) {
+  if (a.inf) return a;
+  g2a r = {fp2_mul(EPS0, fp2_frob(a.x, 1)), fp2_mul(EPS1, fp2_frob(a.y, 1)), 0};
+  if (!g2_on_curve_affine(r.x, r.y)) *ok = 0;
+  return r;
+}
+static g2p g2_psi_proj(g2p p, int *ok) { return g2_from_affine(g2_psi_affine(g2_to_affine(p), ok)); }   /* g2.rs:208-210 */
+/* g2.rs:460-525: 0 ok, 1 NotOnCurve, 2 NotInSubgroup, 3 = reference panics (off-curve psi) */
+static int g2_projective_new(g2p v) {
+  fp2 lhs = fp2_mul(fp2_sqr(v.y), v.z);
+  fp2 rhs = fp2_add(fp2_mul(fp2_sqr(v.x), v.x), fp2_mul(fp2_mul(fp2_sqr(v.z), v.z), TWIST_B));
+  int on_curve = fp2_eq(lhs, rhs) || fp2_is_zero(v.z);
+  int ok = 1;
+  u64 blsx[4] = {4965661367192848881ull, 0, 0, 0};                  /* g2.rs:112 */
+  g2p a = g2_scalar_mul(v, blsx);
+  g2p b = g2_psi_proj(a, &ok);
+  a = g2_add(a, v);
+  g2p r = g2_psi_proj(b, &ok);
+  g2p l = g2_add(g2_add(r, b), a);
+  r = g2_add(g2_double(g2_psi_proj(r, &ok)), g2_neg(l));
+  if (!ok) return 3;
+  if (!on_curve) return 1;
+  return g2_is_zero(r) ? 0 : 2;
+}
+
+/* ---------------------------------------------------------------- pairing (pairing.rs) ----- */
+static const int8_t ATE_NAF[64] = {   /* pairing.rs:26-30 */
+    1, 0, 1, 0, 0, 0, -1, 0, -1, 0, 0, 0, -1, 0, 1, 0, -1, 0, 0, -1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0,
+    1, 0, 0, -1, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, -1, 0, -1, 0, 0, 1, 0, 0, 0, -1, 0, 0, -1, 0, 1, 0,
+    1, 0, 0, 0};
+typedef struct { fp2 e0, e1, e2; } ell;
+/* pairing.rs:798-818 */
+static ell g2_doubling_step(g2p *r) {
+  fp2 a = fp2_scale(fp2_mul(r->x, r->y), TWO_INV_C);
+  fp2 b = fp2_sqr(r->y), c = fp2_sqr(r->z);
+  fp2 d = fp2_add(fp2_add(c, c), c);
+  fp2 e = fp2_mul(TWIST_B, d);
+  fp2 f = fp2_add(fp2_add(e, e), e);
+  fp2 g = fp2_scale(fp2_add(b, f), TWO_INV_C);
+  fp2 h = fp2_sub(fp2_sqr(fp2_add(r->y, r->z)), fp2_add(b, c));
+  fp2 i = fp2_sub(e, b);
+  fp2 j = fp2_sqr(r->x);
+  fp2 esq = fp2_sqr(e);
+  r->x = fp2_mul(a, fp2_sub(b, f));
+  r->y = fp2_sub(fp2_sqr(g), fp2_add(fp2_add(esq, esq), esq));
+  r->z = fp2_mul(b, h);
+  ell l = {fp2_mul_xi(i), fp2_neg(h), fp2_add(fp2_add(j, j), j)};
+  return l;
+}
+/* pairing.rs:756-772 */
+static ell g2_addition_step(g2p *r, fp2 bx, fp2 by) {
+  fp2 d = fp2_sub(r->x, fp2_mul(r->z, bx));
+  fp2 e = fp2_sub(r->y, fp2_mul(r->z, by));
+  fp2 f = fp2_sqr(d), g = fp2_sqr(e);
+  fp2 h = fp2_mul(d, f), i = fp2_mul(r->x, f);
+  fp2 j = fp2_sub(fp2_add(fp2_mul(r->z, g), h), fp2_add(i, i));
+  fp2 ny = fp2_sub(fp2_mul(e, fp2_sub(i, j)), fp2_mul(h, r->y));
+  r->x = fp2_mul(d, j);
+  r->y = ny;
+  r->z = fp2_mul(r->z, h);
+  ell l = {fp2_mul_xi(fp2_sub(fp2_mul(e, bx), fp2_mul(d, by))), d, fp2_neg(e)};
+  return l;
+}
+/* pairing.rs:676-708; returns 0 if the reference would panic in psi (off-curve Q) */
+static int g2_precompute(g2a q, ell coeffs[87]) {
+  g2p r = g2_from_affine(q);
+  fp2 nqy = fp2_neg(q.y);
+  int idx = 0, ok = 1;
+  for (int i = 0; i < 64; ++i) {
+    coeffs[idx++] = g2_doubling_step(&r);
+    if (ATE_NAF[i] == 1) coeffs[idx++] = g2_addition_step(&r, q.x, q.y);
+    else if (ATE_NAF[i] == -1) coeffs[idx++] = g2_addition_step(&r, q.x, nqy);
+  }
+  g2a q1 = g2_psi_affine(q, &ok);
+  g2a q2 = g2_psi_affine(q1, &ok);
+  q2.y = fp2_neg(q2.y);
+  coeffs[idx++] = g2_addition_step(&r, q1.x, q1.y);
+  coeffs[idx++] = g2_addition_step(&r, q2.x, q2.y);
+  return ok;
+}
+static fp12 line_mul(fp12 f, const ell *c, g1a p) {
+  return fp12_sparse_mul(f, c->e0, fp2_scale(c->e1, p.y), fp2_scale(c->e2, p.x));
+}
+/* pairing.rs:970-1022 (k = 1 is G2PreComputed::miller_loop, pairing.rs:590-619) */
+static fp12 glued_miller_loop(const ell *coeffs /* k x 87 */, const g1a *ps, size_t k) {
+  fp12 f = FP12_ONE_C;
+  int idx = 0;
+  for (int i = 0; i < 64; ++i) {
+    f = fp12_sqr(f);
+    for (size_t j = 0; j < k; ++j) f = line_mul(f, &coeffs[j * 87 + idx], ps[j]);
+    idx++;
+    if (ATE_NAF[i] != 0) {
+      for (size_t j = 0; j < k; ++j) f = line_mul(f, &coeffs[j * 87 + idx], ps[j]);
+      idx++;
+    }
+  }
+  for (size_t j = 0; j < k; ++j) f = line_mul(f, &coeffs[j * 87 + idx], ps[j]);
+  idx++;
+  for (size_t j = 0; j < k; ++j) f = line_mul(f, &coeffs[j * 87 + idx], ps[j]);
+  return f;
+}
+/* pairing.rs:274-284 */
+static void fp4_square(fp2 a, fp2 b, fp2 *c0, fp2 *c1) {
+  fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b);
+  *c0 = fp2_add(fp2_mul_xi(t1), t0);
+  *c1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1);
+}
+/* pairing.rs:309-350 Granger-Scott */
+static fp12 cyclotomic_squared(fp12 f) {
+  fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  fp2 t0, t1, t2, t3;
+  fp4_square(z0, z1, &t0, &t1);
+  z0 = fp2_sub(t0, z0); z0 = fp2_add(fp2_add(z0, z0), t0);
+  z1 = fp2_add(t1, z1); z1 = fp2_add(fp2_add(z1, z1), t1);
+  fp4_square(z2, z3, &t0, &t1);
+  fp4_square(z4, z5, &t2, &t3);
+  z4 = fp2_sub(t0, z4); z4 = fp2_add(fp2_add(z4, z4), t0);
+  z5 = fp2_add(t1, z5); z5 = fp2_add(fp2_add(z5, z5), t1);
+  t0 = fp2_mul_xi(t3);
+  z2 = fp2_add(t0, z2); z2 = fp2_add(fp2_add(z2, z2), t0);
+  z3 = fp2_sub(t2, z3); z3 = fp2_add(fp2_add(z3, z3), t2);
+  fp12 r = {{z0, z4, z3}, {z2, z1, z5}};
+  return r;
+}
+/* pairing.rs:366-378: 256 iterations as written */
+static fp12 cyclotomic_exp(fp12 f, const u64 e[4]) {
+  fp12 res = FP12_ONE_C;
+  for (int i = 255; i >= 0; --i) {
+    res = cyclotomic_squared(res);
+    if ((e[i >> 6] >> (i & 63)) & 1) res = fp12_mul(res, f);
+  }
+  return res;
+}
+static fp12 exp_by_neg_z(fp12 f) {                                   /* pairing.rs:390-392 */
+  u64 blsx[4] = {4965661367192848881ull, 0, 0, 0};
+  return fp12_conj(cyclotomic_exp(f, blsx));
+}
+/* pairing.rs:245-492: easy_part (:410) then hard_part (:437) */
+static fp12 final_exponentiation(fp12 f) {
+  fp12 f1 = fp12_conj(f), f2 = fp12_inv(f);
+  f = fp12_mul(f1, f2);
+  fp12 in = fp12_mul(fp12_frob(f, 2), f);
+  fp12 a = exp_by_neg_z(in);
+  fp12 b = cyclotomic_squared(a);
+  fp12 c = cyclotomic_squared(b);
+  fp12 d = fp12_mul(c, b);
+  fp12 e = exp_by_neg_z(d);
+  fp12 ff = cyclotomic_squared(e);
+  fp12 g = exp_by_neg_z(ff);
+  fp12 h = fp12_conj(d);
+  fp12 i = fp12_conj(g);
+  fp12 j = fp12_mul(i, e);
+  fp12 k = fp12_mul(j, h);
+  fp12 l = fp12_mul(k, b);
+  fp12 m = fp12_mul(k, e);
+  fp12 n = fp12_mul(in, m);
+  fp12 o = fp12_frob(l, 1);
+  fp12 p = fp12_mul(o, n);
+  fp12 q = fp12_frob(k, 2);
+  fp12 r = fp12_mul(q, p);
+  fp12 s = fp12_conj(in);
+  fp12 t = fp12_mul(s, l);
+  fp12 u = fp12_frob(t, 3);
+  return fp12_mul(u, r);
+}
+/* pairing.rs:870-893 */
+static fp12 pairing(g1p pp, g2p qp) {
+  g1a p = g1_to_affine(pp);
+  g2a q = g2_to_affine(qp);
+  int either_zero = p.inf | q.inf;
+  if (either_zero) { p = g1_gen(); q = g2_gen(); }
+  ell coeffs[87];
+  g2_precompute(q, coeffs);
+  fp12 tmp = glued_miller_loop(coeffs, &p, 1);
+  if (either_zero) tmp = FP12_ONE_C;
+  return final_exponentiation(tmp);
+}
+
+/* ---------------------------------------------------------------- SvdW (svdw.rs) ----------- */
+static struct { fp c1, c2, c3, c4, z, a, b; int ready; } SV;
+/* svdw.rs:123-153 with a = 0, b = 3, Z = 1 (find_z_svdw svdw.rs:81-111 returns 1, test :277-283) */
+static void svdw_init(void) {
+  if (SV.ready) return;
+  SV.a = FP_ZERO; SV.b = THREE_C; SV.z = ONE_C;
+  fp z = SV.z;
+  fp gz = fp_add(fp_mul(fp_mul(z, z), z), SV.b);
+  SV.c1 = gz;
+  SV.c2 = fp_mul(fp_neg(z), fp_inv(fp_from_u64(2)));
+  fp t = fp_mul(fp_from_u64(3), fp_sqr(z));                         /* 3 z^2 + 4a, a = 0 */
+  fp c3; fp_sqrt(fp_mul(fp_neg(gz), t), &c3);
+  if (fp_sgn0(c3) == 1) c3 = fp_neg(c3);
+  SV.c3 = c3;
+  SV.c4 = fp_mul(fp_mul(fp_from_u64(4), fp_neg(gz)), fp_inv(t));
+  SV.ready = 1;
+}
+/* svdw.rs:180-262 */
+static int svdw_map(fp u, fp *xo, fp *yo) {
+  svdw_init();
+  fp tv1 = fp_mul(fp_mul(u, u), SV.c1);
+  fp tv2 = fp_add(ONE_C, tv1);
+  tv1 = fp_sub(ONE_C, tv1);
+  fp tv3 = fp_inv(fp_mul(tv1, tv2));
+  fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), SV.c3);
+  fp x1 = fp_sub(SV.c2, tv4);
+  fp gx1 = fp_add(fp_mul(fp_add(fp_mul(x1, x1), SV.a), x1), SV.b);
+  int e1 = fp_is_square(gx1);
+  fp x2 = fp_add(SV.c2, tv4);
+  fp gx2 = fp_add(fp_mul(fp_add(fp_mul(x2, x2), SV.a), x2), SV.b);
+  int e2 = fp_is_square(gx2) & !e1;
+  fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
+  x3 = fp_mul(fp_mul(x3, x3), SV.c4);
+  x3 = fp_add(x3, SV.z);
+  fp x = e1 ? x1 : x3;
+  x = e2 ? x2 : x;
+  fp gx = fp_add(fp_mul(fp_add(fp_mul(x, x), SV.a), x), SV.b);
+  fp y;
+  if (!fp_sqrt(gx, &y)) return 0;
+  if (fp_sgn0(u) != fp_sgn0(y)) y = fp_neg(y);
+  *xo = x; *yo = y;
+  return 1;
+}
+
+/* ---------------------------------------------------------------- Keccak-256 + XMD --------- */
+/* sha3 0.11.0-pre.4 is un-vendored: Keccak-f[1600] restated from FIPS 202, original Keccak pad 0x01 */
+static const u64 KRC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
+    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
+    0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
+    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+static const int KROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+static u64 rol64(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+static void keccak_f(u64 s[25]) {
+  for (int rnd = 0; rnd < 24; ++rnd) {
+    u64 C[5], D[5], B[25];
+    for (int x = 0; x < 5; ++x) C[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+    for (int x = 0; x < 5; ++x) D[x] = C[(x + 4) % 5] ^ rol64(C[(x + 1) % 5], 1);
+    for (int i = 0; i < 25; ++i) s[i] ^= D[i % 5];
+    for (int x = 0; x < 5; ++x)
+      for (int y = 0; y < 5; ++y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(s[x + 5 * y], KROT[x + 5 * y]);
+    for (int y = 0; y < 5; ++y)
+      for (int x = 0; x < 5; ++x) s[x + 5 * y] = B[x + 5 * y] ^ ((~B[(x + 1) % 5 + 5 * y]) & B[(x + 2) % 5 + 5 * y]);
+    s[0] ^= KRC[rnd];
+  }
+}
+typedef struct { u64 s[25]; uint8_t buf[136]; size_t fill; } keccak_ctx;
+static void keccak_init(keccak_ctx *c) { memset(c, 0, sizeof(*c)); }
+static void keccak_absorb_block(keccak_ctx *c) {
+  for (int i = 0; i < 17; ++i) { u64 w; memcpy(&w, c->buf + 8 * i, 8); c->s[i] ^= w; }
+  keccak_f(c->s); c->fill = 0;
+}
+static void keccak_update(keccak_ctx *c, const uint8_t *d, size_t n) {
+  while (n) {
+    size_t k = 136 - c->fill; if (k > n) k = n;
+    memcpy(c->buf + c->fill, d, k); c->fill += k; d += k; n -= k;
+    if (c->fill == 136) keccak_absorb_block(c);
+  }
+}
+static void keccak_final(keccak_ctx *c, uint8_t out[32]) {
+  memset(c->buf + c->fill, 0, 136 - c->fill);
+  c->buf[c->fill] ^= 0x01; c->buf[135] ^= 0x80;
+  keccak_absorb_block(c);
+  memcpy(out, c->s, 32);
+}
+/* hasher.rs:201-250 expand_message_xmd with H = Keccak-256 (b = 32, r = 136); dst <= 255 bytes
+ * (the > 255 branch, hasher.rs:157-173, is applied by the caller-side helper below) */
+static int xmd_keccak(const uint8_t *msg, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                      uint8_t *out, size_t len_in_bytes) {
+  uint8_t dst_h[32];
+  if (dst_len > 255) {
+    keccak_ctx c; keccak_init(&c);
+    keccak_update(&c, (const uint8_t *)"H2C-OVERSIZE-DST-", 17);
+    keccak_update(&c, dst, dst_len); keccak_final(&c, dst_h);
+    dst = dst_h; dst_len = 32;
+  }
+  size_t ell = (len_in_bytes + 31) / 32;
+  if (ell > 255) return 0;
+  uint8_t dlen = (uint8_t)dst_len, zpad[136] = {0}, b0[32], bi[32];
+  uint8_t lib[3] = {(uint8_t)(len_in_bytes >> 8), (uint8_t)len_in_bytes, 0};
+  keccak_ctx c; keccak_init(&c);
+  keccak_update(&c, zpad, 136); keccak_update(&c, msg, msg_len); keccak_update(&c, lib, 3);
+  keccak_update(&c, dst, dst_len); keccak_update(&c, &dlen, 1); keccak_final(&c, b0);
+  uint8_t ctr = 1;
+  keccak_init(&c); keccak_update(&c, b0, 32); keccak_update(&c, &ctr, 1);
+  keccak_update(&c, dst, dst_len); keccak_update(&c, &dlen, 1); keccak_final(&c, bi);
+  size_t off = 0;
+  for (size_t i = 0;; ++i) {
+    size_t k = len_in_bytes - off < 32 ? len_in_bytes - off : 32;
+    memcpy(out + off, bi, k); off += k;
+    if (off >= len_in_bytes) break;
+    uint8_t x[32];
+    for (int j = 0; j < 32; ++j) x[j] = b0[j] ^ bi[j];
+    ctr = (uint8_t)(i + 2);
+    keccak_init(&c); keccak_update(&c, x, 32); keccak_update(&c, &ctr, 1);
+    keccak_update(&c, dst, dst_len); keccak_update(&c, &dlen, 1); keccak_final(&c, bi);
+  }
+  return 1;
+}
+/* hasher.rs:84-128: 48-byte big-endian chunk mod p */
+static fp fp_from_be48(const uint8_t b[48]) {
+  /* value = hi(16 bytes) * 2^256 + lo(32 bytes); computed as hi * R_plain + lo in Fp */
+  u64 lo[4], hi[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) { u64 w = 0; for (int j = 0; j < 8; ++j) w = (w << 8) | b[16 + 8 * (3 - i) + j]; lo[i] = w; }
+  for (int i = 0; i < 2; ++i) { u64 w = 0; for (int j = 0; j < 8; ++j) w = (w << 8) | b[8 * (1 - i) + j]; hi[i] = w; }
+  /* fp_from_words(hi) is hi*R (Montgomery form of hi); mont-mul by R2 gives hi*R^2 = mont form of hi*R = hi*2^256 */
+  fp h = fp_mul(fp_from_words(hi), R2);
+  return fp_add(h, fp_from_words(lo));
+}
+static const uint8_t SYLOW_DST[30] = "WARLOCK-CHAOS-V01-CS01-SHA-256";          /* lib.rs:90 */
+/* g1.rs:307-331 */
+static int hash_to_curve(const uint8_t *msg, size_t len, const uint8_t *dst, size_t dst_len, g1p *out) {
+  uint8_t em[96];
+  if (!xmd_keccak(msg, len, dst, dst_len, em, 96)) return 0;
+  fp u0 = fp_from_be48(em), u1 = fp_from_be48(em + 48);
+  fp x0, y0, x1, y1;
+  if (!svdw_map(u0, &x0, &y0) || !svdw_map(u1, &x1, &y1)) return 0;
+  if (!g1_on_curve_affine(x0, y0) || !g1_on_curve_affine(x1, y1)) return 0;
+  g1p a = {x0, y0, ONE_C}, b = {x1, y1, ONE_C};
+  *out = g1_add(a, b);
+  return 1;
+}
+
+/* ================================================================ exported C API =========== */
+#define API __attribute__((visibility("default")))
+static fp ld(const u64 *p) { return fp_from_words(p); }
+static void st(u64 *p, fp a) { fp_to_words(a, p); }
+static fp2 ld2(const u64 *p) { fp2 r = {ld(p), ld(p + 4)}; return r; }
+static void st2(u64 *p, fp2 a) { st(p, a.c0); st(p + 4, a.c1); }
+static fp6 ld6(const u64 *p) { fp6 r = {ld2(p), ld2(p + 8), ld2(p + 16)}; return r; }
+static void st6(u64 *p, fp6 a) { st2(p, a.c0); st2(p + 8, a.c1); st2(p + 16, a.c2); }
+static fp12 ld12(const u64 *p) { fp12 r = {ld6(p), ld6(p + 24)}; return r; }
+static void st12(u64 *p, fp12 a) { st6(p, a.c0); st6(p + 24, a.c1); }
+
+/* op: 0 add, 1 sub, 2 mul, 3 sqr(a), 4 inv(a), 5 neg(a), 6 div */
+API void oracle_fp_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    fp x = ld(a + 4 * i), y = b ? ld(b + 4 * i) : FP_ZERO, r;
+    switch (op) {
+      case 0: r = fp_add(x, y); break;
+      case 1: r = fp_sub(x, y); break;
+      case 2: r = fp_mul(x, y); break;
+      case 3: r = fp_sqr(x); break;
+      case 4: r = fp_inv(x); break;
+      case 5: r = fp_neg(x); break;
+      default: r = fp_mul(x, fp_inv(y)); break;
+    }
+    st(out + 4 * i, r);
+  }
+}
+API void oracle_fp2_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    fp2 x = ld2(a + 8 * i), y = b ? ld2(b + 8 * i) : FP2_ZERO_C, r;
+    switch (op) {
+      case 0: r = fp2_add(x, y); break;
+      case 1: r = fp2_sub(x, y); break;
+      case 2: r = fp2_mul(x, y); break;
+      case 3: r = fp2_sqr(x); break;
+      case 4: r = fp2_inv(x); break;
+      case 5: r = fp2_neg(x); break;
+      case 7: r = fp2_mul_xi(x); break;
+      default: r = fp2_mul(x, fp2_inv(y)); break;
+    }
+    st2(out + 8 * i, r);
+  }
+}
+API void oracle_fp6_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    fp6 x = ld6(a + 24 * i), y = b ? ld6(b + 24 * i) : FP6_ZERO_C, r;
+    switch (op) {
+      case 0: r = fp6_add(x, y); break;
+      case 1: r = fp6_sub(x, y); break;
+      case 2: r = fp6_mul(x, y); break;
+      case 3: r = fp6_sqr(x); break;
+      case 4: r = fp6_inv(x); break;
+      case 5: r = fp6_neg(x); break;
+      default: r = fp6_mul(x, fp6_inv(y)); break;
+    }
+    st6(out + 24 * i, r);
+  }
+}
+/* op: 2 mul, 3 sqr, 4 inv, 8 frobenius(arg), 9 cyclotomic_squared, 10 conj */
+API void oracle_fp12_op(int op, int arg, const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    fp12 x = ld12(a + 48 * i), r;
+    switch (op) {
+      case 2: r = fp12_mul(x, ld12(b + 48 * i)); break;
+      case 3: r = fp12_sqr(x); break;
+      case 4: r = fp12_inv(x); break;
+      case 8: r = fp12_frob(x, arg); break;
+      case 9: r = cyclotomic_squared(x); break;
+      default: r = fp12_conj(x); break;
+    }
+    st12(out + 48 * i, r);
+  }
+}
+/* f(48 words) x ell(3 x Fp2 = 24 words: ell_0, ell_vw, ell_vv) */
+API void oracle_fp12_sparse_mul(const u64 *f, const u64 *l, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i)
+    st12(out + 48 * i, fp12_sparse_mul(ld12(f + 48 * i), ld2(l + 24 * i), ld2(l + 24 * i + 8), ld2(l + 24 * i + 16)));
+}
+/* constants export (for fixture checks): which: 0 FROB6_C1[6], 1 FROB6_C2[6], 2 FROB12_C1[12], 3 TWIST_B, 4 EPS0, 5 EPS1,
+ * 6 svdw {c1,c2,c3,c4,z} as Fp, 7 TWO_INV */
+API size_t oracle_constants(int which, u64 *out) {
+  oracle_init(); svdw_init();
+  switch (which) {
+    case 0: for (int i = 0; i < 6; ++i) st2(out + 8 * i, FROB6_C1[i]); return 6;
+    case 1: for (int i = 0; i < 6; ++i) st2(out + 8 * i, FROB6_C2[i]); return 6;
+    case 2: for (int i = 0; i < 12; ++i) st2(out + 8 * i, FROB12_C1[i]); return 12;
+    case 3: st2(out, TWIST_B); return 1;
+    case 4: st2(out, EPS0); return 1;
+    case 5: st2(out, EPS1); return 1;
+    case 6: st(out, SV.c1); st(out + 4, SV.c2); st(out + 8, SV.c3); st(out + 12, SV.c4); st(out + 16, SV.z); return 5;
+    default: st(out, TWO_INV_C); return 1;
+  }
+}
+/* G1: points as (x, y, z) 12 words projective in/out; scalars 4 words (plain value < p, NOT mod r) */
+static g1p ldg1(const u64 *p) { g1p r = {ld(p), ld(p + 4), ld(p + 8)}; return r; }
+static void stg1(u64 *p, g1p a) { st(p, a.x); st(p + 4, a.y); st(p + 8, a.z); }
+static g2p ldg2(const u64 *p) { g2p r = {ld2(p), ld2(p + 8), ld2(p + 16)}; return r; }
+static void stg2(u64 *p, g2p a) { st2(p, a.x); st2(p + 8, a.y); st2(p + 16, a.z); }
+API void oracle_g1_scalar_mul(const u64 *pts, const u64 *k, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg1(out + 12 * i, g1_scalar_mul(ldg1(pts + 12 * i), k + 4 * i));
+}
+API void oracle_g2_scalar_mul(const u64 *pts, const u64 *k, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg2(out + 24 * i, g2_scalar_mul(ldg2(pts + 24 * i), k + 4 * i));
+}
+API void oracle_g1_add(const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg1(out + 12 * i, g1_add(ldg1(a + 12 * i), ldg1(b + 12 * i)));
+}
+API void oracle_g1_double(const u64 *a, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg1(out + 12 * i, g1_double(ldg1(a + 12 * i)));
+}
+API void oracle_g2_add(const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg2(out + 24 * i, g2_add(ldg2(a + 24 * i), ldg2(b + 24 * i)));
+}
+API void oracle_g2_double(const u64 *a, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg2(out + 24 * i, g2_double(ldg2(a + 24 * i)));
+}
+/* affine out: x, y (8 words) + inf flag byte */
+API void oracle_g1_to_affine(const u64 *a, u64 *xy, uint8_t *inf, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) { g1a r = g1_to_affine(ldg1(a + 12 * i)); st(xy + 8 * i, r.x); st(xy + 8 * i + 4, r.y); inf[i] = (uint8_t)r.inf; }
+}
+API void oracle_g2_to_affine(const u64 *a, u64 *xy, uint8_t *inf, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) { g2a r = g2_to_affine(ldg2(a + 24 * i)); st2(xy + 16 * i, r.x); st2(xy + 16 * i + 8, r.y); inf[i] = (uint8_t)r.inf; }
+}
+/* 0 ok, 1 NotOnCurve, 2 NotInSubgroup, 3 reference panics */
+API void oracle_g2_projective_new(const u64 *a, uint8_t *status, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) status[i] = (uint8_t)g2_projective_new(ldg2(a + 24 * i));
+}
+API void oracle_g2_psi(const u64 *xy, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) { int ok = 1; g2a q = {ld2(xy + 16 * i), ld2(xy + 16 * i + 8), 0}; g2a r = g2_psi_affine(q, &ok); st2(out + 16 * i, r.x); st2(out + 16 * i + 8, r.y); }
+}
+/* G2 affine (16 words) -> 87 x 3 x Fp2 (87*24 words) */
+API void oracle_g2_precompute(const u64 *q, u64 *coeffs, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g2a a = {ld2(q + 16 * i), ld2(q + 16 * i + 8), 0};
+    ell c[87]; g2_precompute(a, c);
+    for (int j = 0; j < 87; ++j) { u64 *o = coeffs + (i * 87 + j) * 24; st2(o, c[j].e0); st2(o + 8, c[j].e1); st2(o + 16, c[j].e2); }
+  }
+}
+/* raw Miller loop (strict replay of pairing.rs:590-619,676-818): P affine (8 words), Q affine (16 words) -> f */
+API void oracle_miller_loop(const u64 *p, const u64 *q, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g1a pa = {ld(p + 8 * i), ld(p + 8 * i + 4), 0};
+    g2a qa = {ld2(q + 16 * i), ld2(q + 16 * i + 8), 0};
+    ell c[87]; g2_precompute(qa, c);
+    st12(out + 48 * i, glued_miller_loop(c, &pa, 1));
+  }
+}
+API void oracle_final_exponentiation(const u64 *f, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st12(out + 48 * i, final_exponentiation(ld12(f + 48 * i)));
+}
+/* pairing(): projective in (12 + 24 words) -> Gt (48 words) */
+API void oracle_pairing(const u64 *p, const u64 *q, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st12(out + 48 * i, pairing(ldg1(p + 12 * i), ldg2(q + 24 * i)));
+}
+/* glued_pairing (pairing.rs:1029-1037): job j covers pairs [off[j], off[j+1]); projective inputs */
+API void oracle_glued_pairing(const u64 *p, const u64 *q, const u64 *off, u64 *out, size_t njobs) {
+  oracle_init();
+  for (size_t j = 0; j < njobs; ++j) {
+    size_t k = (size_t)(off[j + 1] - off[j]);
+    g1a *ps = (g1a *)malloc((k + 1) * sizeof(g1a));
+    ell *cs = (ell *)malloc((k + 1) * 87 * sizeof(ell));
+    for (size_t i = 0; i < k; ++i) {
+      ps[i] = g1_to_affine(ldg1(p + 12 * (off[j] + i)));
+      g2_precompute(g2_to_affine(ldg2(q + 24 * (off[j] + i))), cs + 87 * i);
+    }
+    st12(out + 48 * j, final_exponentiation(glued_miller_loop(cs, ps, k)));
+    free(ps); free(cs);
+  }
+}
+API void oracle_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+  keccak_ctx c; keccak_init(&c); keccak_update(&c, msg, len); keccak_final(&c, out);
+}
+API int oracle_expand_message_xmd_keccak(const uint8_t *msg, size_t len, const uint8_t *dst, size_t dst_len, uint8_t *out, size_t out_len) {
+  return xmd_keccak(msg, len, dst, dst_len, out, out_len);
+}
+API void oracle_svdw_map(const u64 *u, u64 *xy, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) { fp x = FP_ZERO, y = FP_ZERO; svdw_map(ld(u + 4 * i), &x, &y); st(xy + 8 * i, x); st(xy + 8 * i + 4, y); }
+}
+/* messages: concatenated bytes with offsets[n+1]; out projective (12 words); dst NULL -> sylow DST */
+API int oracle_hash_to_curve(const uint8_t *msgs, const u64 *off, const uint8_t *dst, size_t dst_len, u64 *out, size_t n) {
+  oracle_init();
+  if (!dst) { dst = SYLOW_DST; dst_len = 30; }
+  for (size_t i = 0; i < n; ++i) { g1p h; if (!hash_to_curve(msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, &h)) return 0; stg1(out + 12 * i, h); }
+  return 1;
+}
+/* lib.rs:179-187 */
+API int oracle_sign(const u64 *sk, const uint8_t *msgs, const u64 *off, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g1p h; if (!hash_to_curve(msgs + off[i], (size_t)(off[i + 1] - off[i]), SYLOW_DST, 30, &h)) return 0;
+    stg1(out + 12 * i, g1_scalar_mul(h, sk + 4 * i));
+  }
+  return 1;
+}
+/* lib.rs:223-236: two full pairings, Gt equality */
+API int oracle_verify(const u64 *pk, const uint8_t *msgs, const u64 *off, const u64 *sig, uint8_t *ok, size_t n) {
+  oracle_init();
+  g2p gen = g2_from_affine(g2_gen());
+  for (size_t i = 0; i < n; ++i) {
+    g1p h; if (!hash_to_curve(msgs + off[i], (size_t)(off[i + 1] - off[i]), SYLOW_DST, 30, &h)) return 0;
+    fp12 lhs = pairing(ldg1(sig + 12 * i), gen);
+    fp12 rhs = pairing(h, ldg2(pk + 24 * i));
+    ok[i] = (uint8_t)fp12_eq(lhs, rhs);
+  }
+  return 1;
+}
