@@ -1,0 +1,151 @@
+/*
+ * sylow_hip.h -- C ABI of the MI355X-native batched BN254 pairing / BLS-verify engine.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of warlock-labs/sylow
+ * (src/fields -> src/groups -> src/pairing.rs -> src/svdw.rs / src/hasher.rs -> lib.rs
+ * sign/verify).  The reference has no FFI of its own (100 % safe Rust, `deny(unsafe_code)`,
+ * src/lib.rs:63); each entry point below names the reference item whose *batched* form it
+ * computes, i.e. what a `sylow-hip` Rust shim binds with `extern "C"`.
+ *
+ * Conventions
+ *  - Every array argument is a DEVICE pointer (hipMalloc / sylow_hip_malloc / a torch tensor's
+ *    data_ptr()).  Nothing here takes torch types.
+ *  - Field elements cross the boundary as canonical integers in [0, p) (what sylow's
+ *    `Fp::value().to_words()` yields, src/fields/fp.rs:232-234): 4 little-endian uint64 limbs.
+ *    Inputs >= p are reduced mod p exactly like `Fp::new` (fp.rs:199-201).
+ *  - Struct-of-arrays, word-major: a batch of n objects made of W 64-bit words is a uint64
+ *    array of shape [W][n]; word w of element i is at base[w * n + i].  Word order inside an
+ *    object is the reference's nesting order, least-significant limb first:
+ *      Fp   : W =  4  (limb0..limb3)
+ *      Fp2  : W =  8  (c0 limbs, c1 limbs)                      fields/fp2.rs
+ *      Fp6  : W = 24  (c0.c0, c0.c1, c1.c0, c1.c1, c2.c0, c2.c1) fields/fp6.rs
+ *      Fp12 : W = 48  (c0 as Fp6, c1 as Fp6)  == Gt             fields/fp12.rs, groups/gt.rs
+ *      G1 affine    : W =  8 (x, y)      + uint8 infinity flag array (may be NULL = none)
+ *      G2 affine    : W = 16 (x.c0, x.c1, y.c0, y.c1) + uint8 infinity flag array
+ *      G1 projective: W = 12 (x, y, z);  G2 projective: W = 24
+ *    The canonical affine encoding of the identity is (0, 1, inf=1) (groups/group.rs:271-277).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *    asynchronous on that stream; use sylow_hip_stream_sync or your own events.
+ *  - Return value: 0 on success, negative SYLOW_HIP_E_* otherwise.  No call throws or aborts.
+ *    Per-element failures are reported through `status` byte arrays using codes that mirror
+ *    sylow's GroupError (groups/group.rs:38-47).
+ */
+#ifndef SYLOW_HIP_H
+#define SYLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYLOW_HIP_OK 0
+#define SYLOW_HIP_E_HIP (-1)      /* a HIP runtime call failed; see sylow_hip_last_error() */
+#define SYLOW_HIP_E_ARG (-2)      /* bad argument (NULL pointer, n == 0 where not allowed, ...) */
+#define SYLOW_HIP_E_NO_DEVICE (-3)
+
+/* per-element status codes (mirror GroupError, groups/group.rs:38-47) */
+#define SYLOW_HIP_ST_OK 0
+#define SYLOW_HIP_ST_NOT_ON_CURVE 1
+#define SYLOW_HIP_ST_NOT_IN_SUBGROUP 2
+#define SYLOW_HIP_ST_CANNOT_HASH 3
+#define SYLOW_HIP_ST_DECODE_ERROR 4
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+int32_t sylow_hip_init(int32_t device);                 /* hipSetDevice + arch check (gfx950) */
+const char* sylow_hip_last_error(void);
+int32_t sylow_hip_device_count(void);
+int32_t sylow_hip_malloc(void** dptr, size_t bytes);
+int32_t sylow_hip_free(void* dptr);
+int32_t sylow_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int32_t sylow_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int32_t sylow_hip_stream_sync(void* stream);
+/* layout helpers for hosts that hold array-of-structs ([n][W], e.g. a Rust Vec<[u64; 4]>) */
+int32_t sylow_hip_aos_to_soa(const uint64_t* aos, uint64_t* soa, size_t words, size_t n, void* stream);
+int32_t sylow_hip_soa_to_aos(const uint64_t* soa, uint64_t* aos, size_t words, size_t n, void* stream);
+
+/* ---- Fp: src/fields/fp.rs ----------------------------------------------------------------- */
+/* Add / Sub / Mul / Neg / square / Inv for &Fp (fp.rs:304-310, 340-347, 387-393, 442-449,
+ * 620-622, 418-433).  inv(0) = 0, no error (fp.rs:1126-1132). */
+int32_t sylow_hip_fp_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp_neg_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+
+/* ---- extension tower (test hooks): fields/fp2.rs:285-306,164-171,355-360; fp6.rs:283-367,
+ * 415-423; fp12.rs:229-238,536-550,281-286,515-522,426-503 ------------------------------------ */
+int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp2_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp2_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp6_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp6_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp12_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp12_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+/* Fp12::frobenius(exponent), exponent in {1,2,3} (the ones the pairing uses) */
+int32_t sylow_hip_fp12_frobenius_batch(const uint64_t* a, int32_t exponent, uint64_t* out, size_t n, void* stream);
+/* Fp12::sparse_mul(ell_0, ell_vw, ell_vv): ell is [24][n] = (ell_0, ell_vw, ell_vv) as Fp2 each */
+int32_t sylow_hip_fp12_sparse_mul_batch(const uint64_t* f, const uint64_t* ell, uint64_t* out, size_t n, void* stream);
+
+/* ---- groups: src/groups/group.rs, g1.rs, g2.rs ----------------------------------------------- */
+/* Mul<&Fp> for &G1Projective / &G2Projective (group.rs:639-667): out_i = k_i * P_i.
+ * Points affine in (+ optional infinity flags), affine out + infinity flags (comparison is by
+ * affine normalisation).  Scalars are Fp VALUES (k < p, not reduced mod r, N4). */
+int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k,
+                                      uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k,
+                                      uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* Add for &G1Projective (group.rs:528-599) on affine inputs, affine output */
+int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
+                               uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* GroupAffine::from(&GroupProjective) (group.rs:475-495) */
+int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* G2Projective::new on affine input (g2.rs:460-525): status = OK / NOT_ON_CURVE / NOT_IN_SUBGROUP.
+ * (The reference panics for off-curve input, g2.rs:151; this returns NOT_ON_CURVE instead.) */
+int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream);
+
+/* ---- pairing: src/pairing.rs ------------------------------------------------------------------- */
+/* G2Affine::precompute().miller_loop(&G1Affine) (pairing.rs:590-619, 676-708): raw Miller value,
+ * strict replay of the reference's line formulas and digit schedule.  No infinity handling. */
+int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
+/* MillerLoopResult::final_exponentiation (pairing.rs:245-492) */
+int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
+/* pairing(&G1, &G2) (pairing.rs:870-893): n independent Gt values; either input at infinity ->
+ * Gt identity.  p_inf / q_inf may be NULL. */
+int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                uint64_t* gt_out, size_t n, void* stream);
+/* glued_pairing (pairing.rs:970-1037), one product per job: job j multiplies the pairs
+ * [pair_offsets[j], pair_offsets[j+1]) (uint64 device array of n_jobs+1 entries; n_pairs =
+ * pair_offsets[n_jobs] is the SoA stride of p_xy / q_xy) with shared
+ * squarings and ONE final exponentiation.  skip_infinity = 0 replays the reference (infinity flags
+ * ignored: a G2 identity zeroes the product); skip_infinity = 1 drops pairs with an
+ * identity on either side (EIP-197 semantics).  gt_out [48][n_jobs] may be NULL;
+ * is_one [n_jobs] (may be NULL) receives product == Gt::identity(). */
+int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                      const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
+                                      uint64_t* gt_out, uint8_t* is_one, void* stream);
+
+/* ---- hash-to-curve and BLS: src/hasher.rs, src/svdw.rs, src/groups/g1.rs:307-331, src/lib.rs --- */
+/* G1Projective::hash_to_curve with XMDExpander<Keccak256>(dst, 128), COUNT=2, L=48.
+ * msgs: concatenated message bytes; msg_offsets: n+1 uint64 byte offsets.  dst/dst_len: HOST
+ * pointer to the domain separation tag (NULL -> sylow's DST, lib.rs:90). */
+int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                   uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* sign(&Fp, &[u8]) (lib.rs:179-187): sig_i = sk_i * H(msg_i), affine out */
+int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                 uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream);
+/* verify(&G2Projective, &[u8], &G1Projective) (lib.rs:223-236): ok_i = e(sig_i, G2gen) == e(H(msg_i), pk_i) */
+int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* AND of a flag array -> one int32 on the device (1 = all set); the multi-GPU aggregate then
+ * MIN-reduces that word over ranks (RCCL has no bit-AND; min over {0,1} is AND). */
+int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLOW_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libsylow_hip.so (the C ABI in include/sylow_hip.h).
+
+Fails loudly: there is no CPU fallback anywhere in this package.  If the shared library is
+missing or no gfx950 device is present, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsylow_hip.so")
+_lib = None
+
+c_u64p = ctypes.c_void_p
+c_u8p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+c_i32 = ctypes.c_int32
+c_vp = ctypes.c_void_p
+
+# name -> argtypes (restype is int32 unless listed in _RESTYPE)
+SIGNATURES = {
+    "sylow_hip_init": [c_i32],
+    "sylow_hip_last_error": [],
+    "sylow_hip_device_count": [],
+    "sylow_hip_malloc": [ctypes.POINTER(c_vp), c_sz],
+    "sylow_hip_free": [c_vp],
+    "sylow_hip_memcpy_h2d": [c_vp, c_vp, c_sz, c_vp],
+    "sylow_hip_memcpy_d2h": [c_vp, c_vp, c_sz, c_vp],
+    "sylow_hip_stream_sync": [c_vp],
+    "sylow_hip_aos_to_soa": [c_u64p, c_u64p, c_sz, c_sz, c_vp],
+    "sylow_hip_soa_to_aos": [c_u64p, c_u64p, c_sz, c_sz, c_vp],
+    "sylow_hip_fp_add_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_sub_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_neg_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_inv_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp2_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp2_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp2_inv_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp6_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp6_inv_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_inv_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_frobenius_batch": [c_u64p, c_i32, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_sparse_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_g1_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_add_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_normalize_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_normalize_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_subgroup_check_batch": [c_u64p, c_u8p, c_u8p, c_sz, c_vp],
+    "sylow_hip_miller_loop_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_final_exp_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_pairing_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_vp],
+    "sylow_hip_multi_pairing_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz, c_i32, c_u64p, c_u8p, c_vp],
+    "sylow_hip_hash_to_g1_batch": [c_u8p, c_u64p, ctypes.c_char_p, c_sz, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_bls_sign_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_bls_verify_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
+    "sylow_hip_flags_all": [c_u8p, c_sz, c_vp, c_vp],
+}
+_RESTYPE = {"sylow_hip_last_error": ctypes.c_char_p}
+
+
+class SylowHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libsylow_hip.so for gfx950 with hipcc (works without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", csrc]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SylowHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, c_i32)
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().sylow_hip_last_error()
+        raise SylowHipError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,194 @@
+// Hash-to-G1 on the device: Keccak-256, RFC 9380 expand_message_xmd, hash_to_field, and the
+// Shallue-van de Woestijne map for y^2 = x^3 + 3.  Batched replacement for sylow's
+// src/hasher.rs:84-128,157-250 (XMDExpander<Keccak256>), src/svdw.rs:180-262 and
+// src/groups/g1.rs:307-331.  One message per lane.
+//
+// Keccak comes from the un-vendored crate sha3 0.11.0-pre.4 in the reference (Cargo.toml:41);
+// Keccak-f[1600] is restated here from FIPS 202 with the original Keccak padding (0x01 .. 0x80).
+#pragma once
+#include "bn254_pairing.hpp"
+
+namespace bn254 {
+
+struct DstPrime {        // DST || I2OSP(len(DST), 1), already shortened if the tag was > 255 bytes
+  uint8_t bytes[256];
+  uint32_t len;          // length of DST' (<= 256)
+};
+
+__host__ __device__ inline u64 rotl64(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+
+__host__ __device__ inline void keccak_f1600(u64 (&s)[25]) {
+  const u64 RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+#pragma unroll 1
+  for (int rnd = 0; rnd < 24; ++rnd) {
+    u64 c0 = s[0] ^ s[5] ^ s[10] ^ s[15] ^ s[20];
+    u64 c1 = s[1] ^ s[6] ^ s[11] ^ s[16] ^ s[21];
+    u64 c2 = s[2] ^ s[7] ^ s[12] ^ s[17] ^ s[22];
+    u64 c3 = s[3] ^ s[8] ^ s[13] ^ s[18] ^ s[23];
+    u64 c4 = s[4] ^ s[9] ^ s[14] ^ s[19] ^ s[24];
+    u64 d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5) { s[y] ^= d0; s[y + 1] ^= d1; s[y + 2] ^= d2; s[y + 3] ^= d3; s[y + 4] ^= d4; }
+    // rho + pi
+    u64 b[25];
+    b[0] = s[0];
+    b[10] = rotl64(s[1], 1);   b[20] = rotl64(s[2], 62);  b[5] = rotl64(s[3], 28);   b[15] = rotl64(s[4], 27);
+    b[16] = rotl64(s[5], 36);  b[1] = rotl64(s[6], 44);   b[11] = rotl64(s[7], 6);   b[21] = rotl64(s[8], 55);
+    b[6] = rotl64(s[9], 20);   b[7] = rotl64(s[10], 3);   b[17] = rotl64(s[11], 10); b[2] = rotl64(s[12], 43);
+    b[12] = rotl64(s[13], 25); b[22] = rotl64(s[14], 39); b[23] = rotl64(s[15], 41); b[8] = rotl64(s[16], 45);
+    b[18] = rotl64(s[17], 15); b[3] = rotl64(s[18], 21);  b[13] = rotl64(s[19], 8);  b[14] = rotl64(s[20], 18);
+    b[24] = rotl64(s[21], 2);  b[9] = rotl64(s[22], 61);  b[19] = rotl64(s[23], 56); b[4] = rotl64(s[24], 14);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5) {
+      s[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
+      s[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
+      s[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
+      s[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
+      s[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+    }
+    s[0] ^= RC[rnd];
+  }
+}
+
+// Streaming Keccak-256 absorber: rate 136 bytes.  Bytes are XORed straight into the state words.
+struct Keccak256 {
+  u64 s[25];
+  uint32_t fill;
+  __host__ __device__ inline void init() {
+    for (int i = 0; i < 25; ++i) s[i] = 0;
+    fill = 0;
+  }
+  __host__ __device__ inline void put(uint8_t byte) {
+    // dynamic word index: the state lives in scratch on the device; hashing is <1 % of a verify
+    s[fill >> 3] ^= (u64)byte << (8 * (fill & 7));
+    if (++fill == 136) { keccak_f1600(s); fill = 0; }
+  }
+  __host__ __device__ inline void update(const uint8_t* d, size_t n) {
+    for (size_t i = 0; i < n; ++i) put(d[i]);
+  }
+  __host__ __device__ inline void finish(uint8_t out[32]) {
+    s[fill >> 3] ^= (u64)0x01 << (8 * (fill & 7));
+    s[16] ^= 0x8000000000000000ull;   // last byte of the 136-byte rate block
+    keccak_f1600(s);
+    for (int i = 0; i < 32; ++i) out[i] = (uint8_t)(s[i >> 3] >> (8 * (i & 7)));
+  }
+};
+
+// hasher.rs:157-173: DST' from DST (host side, once per call)
+inline void make_dst_prime(DstPrime& dp, const uint8_t* dst, size_t len) {
+  uint8_t h[32];
+  if (len > 255) {
+    Keccak256 k;
+    k.init();
+    k.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17);
+    k.update(dst, len);
+    k.finish(h);
+    dst = h;
+    len = 32;
+  }
+  for (size_t i = 0; i < len; ++i) dp.bytes[i] = dst[i];
+  dp.bytes[len] = (uint8_t)len;
+  dp.len = (uint32_t)len + 1;
+}
+
+// hasher.rs:201-250 with len_in_bytes = 96 (ell = 3): out = b1 || b2 || b3
+__device__ inline void expand_message_xmd96(uint8_t out[96], const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
+  Keccak256 k;
+  uint8_t b0[32];
+  k.init();
+  // Z_pad: one whole rate block of zeros = one permutation of the zero state
+  keccak_f1600(k.s);
+  k.update(msg, msg_len);
+  k.put(0); k.put(96);          // l_i_b_str = I2OSP(96, 2)
+  k.put(0);                     // I2OSP(0, 1)
+  k.update(dp.bytes, dp.len);
+  k.finish(b0);
+  uint8_t prev[32];
+  for (int i = 0; i < 32; ++i) prev[i] = 0;
+#pragma unroll 1
+  for (int blk = 1; blk <= 3; ++blk) {
+    k.init();
+    for (int i = 0; i < 32; ++i) k.put(b0[i] ^ prev[i]);     // b_0 for blk = 1 (prev = 0), else b_0 xor b_(i-1)
+    k.put((uint8_t)blk);
+    k.update(dp.bytes, dp.len);
+    k.finish(prev);
+    for (int i = 0; i < 32; ++i) out[32 * (blk - 1) + i] = prev[i];
+  }
+}
+
+// hasher.rs:84-128: a 48-byte big-endian integer reduced mod p, in Montgomery form
+__device__ inline Fp fp_from_be48(const uint8_t* b) {
+  Fp lo, hi;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint8_t* q = b + 16 + 4 * (7 - i);
+    lo.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint8_t* q = b + 4 * (3 - i);
+    hi.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  hi.v[4] = hi.v[5] = hi.v[6] = hi.v[7] = 0;
+  // value = hi * 2^256 + lo:  mont(hi) * R^2 / R = mont(hi * R)
+  Fp h = fp_mul(fp_to_mont(hi), fp_r2());
+  return fp_add(h, fp_to_mont(lo));
+}
+
+BN_DEV bool fp_is_square(const Fp& a) {                    // fp.rs:625-631
+  Fp r = fp_pow_pm1_half(a);
+  return fp_is_zero(r) || fp_eq(r, fp_one());
+}
+BN_DEV u32 fp_sgn0(const Fp& a) { return fp_from_mont(a).v[0] & 1; }   // fp.rs:636-644
+
+// svdw.rs:180-262 (RFC 9380 6.6.1, straight line) with A = 0, B = 3, Z = 1.  Returns false where
+// the reference would return MapError (cannot happen for this curve).
+BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
+  const Fp c1 = fp_const(C_SVDW[0]), c2 = fp_const(C_SVDW[1]), c3 = fp_const(C_SVDW[2]), c4 = fp_const(C_SVDW[3]), z = fp_const(C_SVDW[4]);
+  const Fp one = fp_one();
+  const Fp b = fp_small(3);
+  Fp tv1 = fp_mul(fp_mul(u, u), c1);
+  Fp tv2 = fp_add(one, tv1);
+  tv1 = fp_sub(one, tv1);
+  Fp tv3 = fp_inv(fp_mul(tv1, tv2));
+  Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
+  Fp x1 = fp_sub(c2, tv4);
+  Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
+  bool e1 = fp_is_square(gx1);
+  Fp x2 = fp_add(c2, tv4);
+  Fp gx2 = fp_add(fp_mul(fp_mul(x2, x2), x2), b);
+  bool e2 = fp_is_square(gx2) && !e1;
+  Fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
+  x3 = fp_mul(fp_mul(x3, x3), c4);
+  x3 = fp_add(x3, z);
+  Fp x = fp_select(x3, x1, e1);
+  x = fp_select(x, x2, e2);
+  Fp gx = fp_add(fp_mul(fp_mul(x, x), x), b);
+  Fp y = fp_pow_pp1_quarter(gx);
+  bool ok = fp_eq(fp_mul(y, y), gx);
+  bool e3 = fp_sgn0(u) == fp_sgn0(y);
+  y = fp_select(fp_neg(y), y, e3);
+  xo = x;
+  yo = y;
+  return ok;
+}
+
+// g1.rs:307-331: map(u0) + map(u1) with the complete projective addition; projective result
+__device__ inline bool hash_to_g1(G1P& out, const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
+  uint8_t em[96];
+  expand_message_xmd96(em, msg, msg_len, dp);
+  Fp u0 = fp_from_be48(em), u1 = fp_from_be48(em + 48);
+  Fp x0, y0, x1, y1;
+  bool ok = svdw_map(x0, y0, u0);
+  ok = svdw_map(x1, y1, u1) && ok;
+  G1P a{x0, y0, fp_one()}, b{x1, y1, fp_one()};
+  out = g1_add(a, b);
+  return ok;
+}
+
+}  // namespace bn254

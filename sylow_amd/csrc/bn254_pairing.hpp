@@ -1,0 +1,347 @@
+// G1 / G2 group law and the optimal-ate pairing for BN254, one element per lane.
+// Batched replacement for sylow's src/groups/group.rs (complete RCB'15 formulas),
+// src/groups/g2.rs (psi, subgroup check) and src/pairing.rs (doubling/addition steps, Miller
+// loop, final exponentiation).
+//
+// Bit-exactness contract:
+//  * Gt after final exponentiation and affine-normalised points are unique -> any correct
+//    algorithm matches the reference bit for bit.
+//  * The RAW Miller value is not unique (lines are scaled by subfield factors), so the line
+//    formulas and the signed-digit schedule below replay pairing.rs:756-818 and :26-30 exactly;
+//    the line coefficients are consumed on the fly instead of being materialised as the
+//    reference's [Ell; 87] table (16.8 KB per point, pairing.rs:556).
+#pragma once
+#include "bn254_tower.hpp"
+
+namespace bn254 {
+
+// ---------------------------------------------------------------- generic projective group ----
+// Homogeneous projective (X:Y:Z), identity (0:1:0)  (group.rs:303-316)
+template <class F> struct Proj { F x, y, z; };
+typedef Proj<Fp> G1P;
+typedef Proj<Fp2> G2P;
+
+// field adaptors so the RCB formulas are written once (group.rs is generic over F the same way)
+struct OpsFp {
+  typedef Fp F;
+  static BN_DEV F add(const F& a, const F& b) { return fp_add(a, b); }
+  static BN_DEV F sub(const F& a, const F& b) { return fp_sub(a, b); }
+  static BN_DEV F neg(const F& a) { return fp_neg(a); }
+  static BN_DEV F mul(const F& a, const F& b) { return fp_mul(a, b); }
+  static BN_DEV F zero() { return fp_zero(); }
+  static BN_DEV F one() { return fp_one(); }
+  static BN_DEV bool is_zero(const F& a) { return fp_is_zero(a); }
+  static BN_DEV F select(const F& a, const F& b, bool c) { return fp_select(a, b, c); }
+  // 3*b = 9: x9 by doublings
+  static BN_DEV F mul_b3(const F& a) { return fp_add(fp_dbl(fp_dbl(fp_dbl(a))), a); }
+  static BN_DEV F inv(const F& a) { return fp_inv(a); }
+};
+struct OpsFp2 {
+  typedef Fp2 F;
+  static BN_DEV F add(const F& a, const F& b) { return fp2_add(a, b); }
+  static BN_DEV F sub(const F& a, const F& b) { return fp2_sub(a, b); }
+  static BN_DEV F neg(const F& a) { return fp2_neg(a); }
+  static BN_DEV F mul(const F& a, const F& b) { return fp2_mul(a, b); }
+  static BN_DEV F zero() { return fp2_zero(); }
+  static BN_DEV F one() { return fp2_one(); }
+  static BN_DEV bool is_zero(const F& a) { return fp2_is_zero(a); }
+  static BN_DEV F select(const F& a, const F& b, bool c) { return fp2_select(a, b, c); }
+  static BN_DEV F mul_b3(const F& a) { return fp2_mul(a, fp2_const(C_TWIST_B3)); }
+  static BN_DEV F inv(const F& a) { return fp2_inv(a); }
+};
+
+template <class O> BN_DEV Proj<typename O::F> proj_zero() { return Proj<typename O::F>{O::zero(), O::one(), O::zero()}; }
+
+// group.rs:339-386, RCB'15 algorithm 9 (a = 0)
+template <class O>
+BN_DEV Proj<typename O::F> proj_double(const Proj<typename O::F>& p) {
+  typedef typename O::F F;
+  F t0 = O::mul(p.y, p.y);
+  F z3 = O::add(t0, t0);
+  z3 = O::add(z3, z3);
+  z3 = O::add(z3, z3);
+  F t1 = O::mul(p.y, p.z);
+  F t2 = O::mul(p.z, p.z);
+  t2 = O::mul_b3(t2);
+  F x3 = O::mul(t2, z3);
+  F y3 = O::add(t0, t2);
+  z3 = O::mul(t1, z3);
+  t1 = O::add(t2, t2);
+  t2 = O::add(t1, t2);
+  t0 = O::sub(t0, t2);
+  y3 = O::mul(t0, y3);
+  y3 = O::add(x3, y3);
+  t1 = O::mul(p.x, p.y);
+  x3 = O::mul(t0, t1);
+  x3 = O::add(x3, x3);
+  // select zero -> zero (group.rs:377-385); the formulas already map (0:1:0) to (0:y:0), the
+  // select pins the canonical (0:1:0)
+  bool z = O::is_zero(p.z);
+  Proj<F> r;
+  r.x = O::select(x3, O::zero(), z);
+  r.y = O::select(y3, O::one(), z);
+  r.z = O::select(z3, O::zero(), z);
+  return r;
+}
+// group.rs:528-599, RCB'15 algorithm 7 (a = 0), complete
+template <class O>
+BN_DEV Proj<typename O::F> proj_add(const Proj<typename O::F>& p, const Proj<typename O::F>& q) {
+  typedef typename O::F F;
+  F t0 = O::mul(p.x, q.x);
+  F t1 = O::mul(p.y, q.y);
+  F t2 = O::mul(p.z, q.z);
+  F t3 = O::mul(O::add(p.x, p.y), O::add(q.x, q.y));
+  t3 = O::sub(t3, O::add(t0, t1));
+  F t4 = O::mul(O::add(p.y, p.z), O::add(q.y, q.z));
+  t4 = O::sub(t4, O::add(t1, t2));
+  F y3 = O::sub(O::mul(O::add(p.x, p.z), O::add(q.x, q.z)), O::add(t0, t2));
+  F x3 = O::add(t0, t0);
+  t0 = O::add(x3, t0);
+  t2 = O::mul_b3(t2);
+  F z3 = O::add(t1, t2);
+  t1 = O::sub(t1, t2);
+  y3 = O::mul_b3(y3);
+  x3 = O::mul(t4, y3);
+  t2 = O::mul(t3, t1);
+  x3 = O::sub(t2, x3);
+  y3 = O::mul(y3, t0);
+  t1 = O::mul(t1, z3);
+  y3 = O::add(t1, y3);
+  t0 = O::mul(t0, t3);
+  z3 = O::mul(z3, t4);
+  z3 = O::add(z3, t0);
+  return Proj<F>{x3, y3, z3};
+}
+template <class O> BN_DEV Proj<typename O::F> proj_neg(const Proj<typename O::F>& p) {
+  return Proj<typename O::F>{p.x, O::neg(p.y), p.z};
+}
+
+BN_NOINLINE G1P g1_double(G1P p) { return proj_double<OpsFp>(p); }
+BN_NOINLINE G1P g1_add(G1P p, G1P q) { return proj_add<OpsFp>(p, q); }
+BN_NOINLINE void g2_double(G2P& r, const G2P& p) { r = proj_double<OpsFp2>(p); }
+BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp2>(p, q); }
+
+// group.rs:639-667 + fp.rs:653-662: k*P by MSB-first signed-digit double-and-add over the
+// digits x3&c / xh&c of the scalar VALUE (an Fp, i.e. k < p; NOT reduced mod r -- SURVEY N4).
+// The leading zero digits only double the identity, so starting at the top set digit gives the
+// same projective value as the reference's 256 iterations.
+struct Naf { u32 np[8], nm[8]; };
+BN_DEV Naf compute_naf(const u32 k[8]) {
+  u32 xh[8], x3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xh[i] = (k[i] >> 1) | (i < 7 ? (k[i + 1] << 31) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c += (u64)k[i] + xh[i]; x3[i] = (u32)c; c >>= 32; }
+  Naf n;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { u32 cc = xh[i] ^ x3[i]; n.np[i] = x3[i] & cc; n.nm[i] = xh[i] & cc; }
+  return n;
+}
+BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
+  Naf n = compute_naf(k);
+  G1P res = proj_zero<OpsFp>();
+  G1P neg = proj_neg<OpsFp>(p);
+#pragma unroll 1
+  for (int i = 255; i >= 0; --i) {
+    res = g1_double(res);
+    u32 bp = (n.np[i >> 5] >> (i & 31)) & 1, bm = (n.nm[i >> 5] >> (i & 31)) & 1;
+    if (bp | bm) {
+      G1P q;
+      q.x = p.x; q.z = p.z;
+      q.y = fp_select(p.y, neg.y, bm != 0);
+      res = g1_add(res, q);
+    }
+  }
+  return res;
+}
+BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
+  Naf n = compute_naf(k);
+  G2P res = proj_zero<OpsFp2>();
+  Fp2 negy = fp2_neg(p.y);
+#pragma unroll 1
+  for (int i = 255; i >= 0; --i) {
+    g2_double(res, res);
+    u32 bp = (n.np[i >> 5] >> (i & 31)) & 1, bm = (n.nm[i >> 5] >> (i & 31)) & 1;
+    if (bp | bm) {
+      G2P q;
+      q.x = p.x; q.z = p.z;
+      q.y = fp2_select(p.y, negy, bm != 0);
+      g2_add(res, res, q);
+    }
+  }
+  out = res;
+}
+
+// group.rs:475-495: affine = (X/Z, Y/Z); infinity iff Z^-1 == 0 -> (0, 1, inf)
+BN_DEV void g1_to_affine(Fp& x, Fp& y, bool& inf, const G1P& p) {
+  Fp zi = fp_inv(p.z);
+  inf = fp_is_zero(zi);
+  x = fp_select(fp_mul(p.x, zi), fp_zero(), inf);
+  y = fp_select(fp_mul(p.y, zi), fp_one(), inf);
+}
+BN_DEV void g2_to_affine(Fp2& x, Fp2& y, bool& inf, const G2P& p) {
+  Fp2 zi = fp2_inv(p.z);
+  inf = fp2_is_zero(zi);
+  x = fp2_select(fp2_mul(p.x, zi), fp2_zero(), inf);
+  y = fp2_select(fp2_mul(p.y, zi), fp2_one(), inf);
+}
+// g1.rs:111-132 / g2.rs:279-297
+BN_DEV bool g1_on_curve_affine(const Fp& x, const Fp& y) {
+  return fp_eq(fp_sub(fp_sqr(y), fp_mul(fp_sqr(x), x)), fp_small(3));
+}
+BN_DEV bool g2_on_curve_affine(const Fp2& x, const Fp2& y) {
+  return fp2_eq(fp2_sub(fp2_sqr(y), fp2_mul(fp2_sqr(x), x)), fp2_const(C_TWIST_B));
+}
+// g2.rs:140-152: psi(x, y) = (eps0 * conj(x), eps1 * conj(y))
+BN_DEV void g2_psi_affine(Fp2& xo, Fp2& yo, const Fp2& x, const Fp2& y) {
+  xo = fp2_mul(fp2_const(C_EPS_EXP0), fp2_conj(x));
+  yo = fp2_mul(fp2_const(C_EPS_EXP1), fp2_conj(y));
+}
+
+// ---------------------------------------------------------------- Miller loop -----------------
+// pairing.rs:798-818: doubling step on the twist; returns the three non-zero line coefficients
+BN_NOINLINE void g2_doubling_step(G2P& r, Fp2& l0, Fp2& l1, Fp2& l2) {
+  const Fp two_inv = fp_const(C_TWO_INV[0]);
+  Fp2 a = fp2_scale(fp2_mul(r.x, r.y), two_inv);
+  Fp2 b = fp2_sqr(r.y);
+  Fp2 c = fp2_sqr(r.z);
+  Fp2 d = fp2_add(fp2_dbl(c), c);
+  Fp2 e = fp2_mul(fp2_const(C_TWIST_B), d);
+  Fp2 f = fp2_add(fp2_dbl(e), e);
+  Fp2 g = fp2_scale(fp2_add(b, f), two_inv);
+  Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));
+  Fp2 i = fp2_sub(e, b);
+  Fp2 j = fp2_sqr(r.x);
+  Fp2 esq = fp2_sqr(e);
+  r.x = fp2_mul(a, fp2_sub(b, f));
+  r.y = fp2_sub(fp2_sqr(g), fp2_add(fp2_dbl(esq), esq));
+  r.z = fp2_mul(b, h);
+  l0 = fp2_mul_xi(i);
+  l1 = fp2_neg(h);
+  l2 = fp2_add(fp2_dbl(j), j);
+}
+// pairing.rs:756-772: mixed addition step R += (bx, by)
+BN_NOINLINE void g2_addition_step(G2P& r, const Fp2& bx, const Fp2& by, Fp2& l0, Fp2& l1, Fp2& l2) {
+  Fp2 d = fp2_sub(r.x, fp2_mul(r.z, bx));
+  Fp2 e = fp2_sub(r.y, fp2_mul(r.z, by));
+  Fp2 f = fp2_sqr(d);
+  Fp2 g = fp2_sqr(e);
+  Fp2 h = fp2_mul(d, f);
+  Fp2 i = fp2_mul(r.x, f);
+  Fp2 j = fp2_sub(fp2_add(fp2_mul(r.z, g), h), fp2_dbl(i));
+  Fp2 ny = fp2_sub(fp2_mul(e, fp2_sub(i, j)), fp2_mul(h, r.y));
+  r.x = fp2_mul(d, j);
+  r.y = ny;
+  r.z = fp2_mul(r.z, h);
+  l0 = fp2_mul_xi(fp2_sub(fp2_mul(e, bx), fp2_mul(d, by)));
+  l1 = d;
+  l2 = fp2_neg(e);
+}
+// f <- f * line(P): sparse_mul(c0, c1 * P.y, c2 * P.x)  (pairing.rs:598)
+BN_DEV void line_mul(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2, const Fp& px, const Fp& py) {
+  fp12_sparse_mul(f, l0, fp2_scale(l1, py), fp2_scale(l2, px));
+}
+// pairing.rs:590-619 fused with :676-708 (coefficients produced and consumed on the fly).
+// P = (px, py), Q = (qx, qy) affine, neither at infinity (callers substitute, pairing.rs:876-878).
+BN_NOINLINE void miller_loop(Fp12& f, const Fp& px, const Fp& py, const Fp2& qx, const Fp2& qy) {
+  fp12_set_one(f);
+  G2P r{qx, qy, fp2_one()};
+  const Fp2 nqy = fp2_neg(qy);
+  Fp2 l0, l1, l2;
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step(r, l0, l1, l2);
+    fp12_sqr(f, f);
+    line_mul(f, l0, l1, l2, px, py);
+    if ((nz >> (63 - i)) & 1) {
+      bool neg = (ng >> (63 - i)) & 1;
+      g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
+      line_mul(f, l0, l1, l2, px, py);
+    }
+  }
+  // Q1 = psi(Q), Q2 = -psi(psi(Q))  (pairing.rs:701-706)
+  Fp2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qx, qy);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  q2y = fp2_neg(q2y);
+  g2_addition_step(r, q1x, q1y, l0, l1, l2);
+  line_mul(f, l0, l1, l2, px, py);
+  g2_addition_step(r, q2x, q2y, l0, l1, l2);
+  line_mul(f, l0, l1, l2, px, py);
+}
+
+// ---------------------------------------------------------------- final exponentiation --------
+// pairing.rs:274-284
+BN_DEV void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
+  Fp2 t0 = fp2_sqr(a);
+  Fp2 t1 = fp2_sqr(b);
+  c0 = fp2_add(fp2_mul_xi(t1), t0);
+  c1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1);
+}
+// pairing.rs:309-350 (Granger-Scott squaring in the cyclotomic subgroup)
+BN_NOINLINE void cyclotomic_sqr(Fp12& r, const Fp12& f) {
+  Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  Fp2 t0, t1, t2, t3;
+  fp4_square(t0, t1, z0, z1);
+  z0 = fp2_sub(t0, z0); z0 = fp2_add(fp2_dbl(z0), t0);
+  z1 = fp2_add(t1, z1); z1 = fp2_add(fp2_dbl(z1), t1);
+  fp4_square(t0, t1, z2, z3);
+  fp4_square(t2, t3, z4, z5);
+  z4 = fp2_sub(t0, z4); z4 = fp2_add(fp2_dbl(z4), t0);
+  z5 = fp2_add(t1, z5); z5 = fp2_add(fp2_dbl(z5), t1);
+  t0 = fp2_mul_xi(t3);
+  z2 = fp2_add(t0, z2); z2 = fp2_add(fp2_dbl(z2), t0);
+  z3 = fp2_sub(t2, z3); z3 = fp2_add(fp2_dbl(z3), t2);
+  r.c0.c0 = z0; r.c0.c1 = z4; r.c0.c2 = z3;
+  r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
+}
+// pairing.rs:366-392: f^x then conjugate.  The reference walks all 256 bits of the 63-bit x
+// starting from one; squaring one in the cyclotomic formulas gives exactly one, so starting at
+// the top set bit is the same value.
+BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
+  Fp12 res = f;
+  const u64 x = BN_BLS_X;
+#pragma unroll 1
+  for (int i = 61; i >= 0; --i) {
+    cyclotomic_sqr(res, res);
+    if ((x >> i) & 1) fp12_mul(res, res, f);
+  }
+  fp12_conj(r, res);
+}
+// pairing.rs:245-492: easy part (:410), hard part (:437, Fuentes-Castaneda chain)
+BN_NOINLINE void final_exponentiation(Fp12& out, const Fp12& fin) {
+  Fp12 in, t, a, b, d, e, g;
+  // easy part: f^(p^6-1) then ^(p^2+1)
+  fp12_conj(a, fin);
+  fp12_inv(b, fin);
+  fp12_mul(t, a, b);
+  fp12_frobenius<2>(a, t);
+  fp12_mul(in, a, t);
+  // hard part
+  exp_by_neg_z(a, in);           // a
+  cyclotomic_sqr(b, a);          // b
+  cyclotomic_sqr(t, b);          // c
+  fp12_mul(d, t, b);             // d = c*b
+  exp_by_neg_z(e, d);            // e
+  cyclotomic_sqr(t, e);          // f
+  exp_by_neg_z(g, t);            // g
+  fp12_conj(d, d);               // h = conj(d)
+  fp12_conj(g, g);               // i = conj(g)
+  fp12_mul(t, g, e);             // j = i*e
+  fp12_mul(a, t, d);             // k = j*h
+  fp12_mul(d, a, b);             // l = k*b
+  fp12_mul(t, a, e);             // m = k*e
+  fp12_mul(e, in, t);            // n = in*m
+  fp12_frobenius<1>(t, d);       // o = frob(l)
+  fp12_mul(b, t, e);             // p = o*n
+  fp12_frobenius<2>(t, a);       // q = frob2(k)
+  fp12_mul(e, t, b);             // r = q*p
+  fp12_conj(t, in);              // s
+  fp12_mul(a, t, d);             // t = s*l
+  fp12_frobenius<3>(t, a);       // u
+  fp12_mul(out, t, e);           // u*r
+}
+
+}  // namespace bn254

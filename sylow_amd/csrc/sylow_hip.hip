@@ -1,0 +1,584 @@
+// libsylow_hip.so: kernels + the C ABI declared in include/sylow_hip.h.
+// gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
+#include "../../include/sylow_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "bn254_hash.hpp"
+
+using namespace bn254;
+
+// ------------------------------------------------------------------ SoA load / store ----------
+// word w of element i lives at base[w * n + i]: a wavefront reads 64 consecutive uint64 (512 B)
+// per word -> fully coalesced, and the 4 words of an Fp are 4 independent loads in flight.
+BN_DEV Fp load_plain(const u64* __restrict__ base, size_t n, size_t i, int w0) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    u64 w = base[(size_t)(w0 + k) * n + i];
+    r.v[2 * k] = (u32)w;
+    r.v[2 * k + 1] = (u32)(w >> 32);
+  }
+  return r;
+}
+BN_DEV void store_plain(u64* __restrict__ base, size_t n, size_t i, int w0, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) base[(size_t)(w0 + k) * n + i] = (u64)a.v[2 * k] | ((u64)a.v[2 * k + 1] << 32);
+}
+BN_DEV Fp load_fp(const u64* base, size_t n, size_t i, int w0) { return fp_to_mont(load_plain(base, n, i, w0)); }
+BN_DEV void store_fp(u64* base, size_t n, size_t i, int w0, const Fp& a) { store_plain(base, n, i, w0, fp_from_mont(a)); }
+BN_DEV Fp2 load_fp2(const u64* base, size_t n, size_t i, int w0) { return Fp2{load_fp(base, n, i, w0), load_fp(base, n, i, w0 + 4)}; }
+BN_DEV void store_fp2(u64* base, size_t n, size_t i, int w0, const Fp2& a) { store_fp(base, n, i, w0, a.c0); store_fp(base, n, i, w0 + 4, a.c1); }
+BN_DEV void load_fp6(Fp6& r, const u64* base, size_t n, size_t i, int w0) {
+  r.c0 = load_fp2(base, n, i, w0); r.c1 = load_fp2(base, n, i, w0 + 8); r.c2 = load_fp2(base, n, i, w0 + 16);
+}
+BN_DEV void store_fp6(u64* base, size_t n, size_t i, int w0, const Fp6& a) {
+  store_fp2(base, n, i, w0, a.c0); store_fp2(base, n, i, w0 + 8, a.c1); store_fp2(base, n, i, w0 + 16, a.c2);
+}
+BN_DEV void load_fp12(Fp12& r, const u64* base, size_t n, size_t i) { load_fp6(r.c0, base, n, i, 0); load_fp6(r.c1, base, n, i, 24); }
+BN_DEV void store_fp12(u64* base, size_t n, size_t i, const Fp12& a) { store_fp6(base, n, i, 0, a.c0); store_fp6(base, n, i, 24, a.c1); }
+
+#define TID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
+constexpr int BLOCK = 256;
+// the heavy kernels keep an Fp12 working set per lane: ask for 2 waves per SIMD (<= 256 VGPRs),
+// the occupancy at which v_mad_u64_u32 already reaches its peak issue rate (profiles/r01_issue_rate_ubench.txt)
+#define HEAVY_BOUNDS __launch_bounds__(BLOCK, 2)
+
+// ------------------------------------------------------------------ Fp kernels ----------------
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
+
+// a*b for canonical inputs without a round trip through Montgomery form for the second operand:
+// mont(mont(a, R^2), b) = a*b.  Two Montgomery products per element; the kernel is HBM-bound
+// (96 B per element) as long as those stay under the memory time.
+template <int OP>
+__global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp x = load_plain(a, n, i, 0), y = load_plain(b, n, i, 0), r;
+  if (OP == OP_MUL) {
+    r = fp_mul(fp_to_mont(x), y);
+  } else {
+    // reduce arbitrary 256-bit inputs like Fp::new, then add/sub on canonical values (no Montgomery needed)
+    x = fp_from_mont(fp_to_mont(x));
+    y = fp_from_mont(fp_to_mont(y));
+    r = (OP == OP_ADD) ? fp_add(x, y) : fp_sub(x, y);
+  }
+  store_plain(out, n, i, 0, r);
+}
+template <int OP>
+__global__ void __launch_bounds__(BLOCK) k_fp_unop(const u64* __restrict__ a, u64* __restrict__ out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp x = load_plain(a, n, i, 0), r;
+  if (OP == OP_SQR) {
+    Fp xm = fp_to_mont(x);
+    r = fp_from_mont(fp_mul(xm, xm));
+  } else if (OP == OP_NEG) {
+    r = fp_neg(fp_from_mont(fp_to_mont(x)));
+  } else {
+    r = fp_from_mont(fp_inv(fp_to_mont(x)));
+  }
+  store_plain(out, n, i, 0, r);
+}
+
+// ------------------------------------------------------------------ tower test hooks ----------
+__global__ void __launch_bounds__(BLOCK) k_fp2_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp2 x = load_fp2(a, n, i, 0), r;
+  if (op == OP_MUL) r = fp2_mul(x, load_fp2(b, n, i, 0));
+  else if (op == OP_SQR) r = fp2_sqr(x);
+  else r = fp2_inv(x);
+  store_fp2(out, n, i, 0, r);
+}
+__global__ void HEAVY_BOUNDS k_fp6_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp6 x, y, r;
+  load_fp6(x, a, n, i, 0);
+  if (op == OP_MUL) { load_fp6(y, b, n, i, 0); fp6_mul(r, x, y); }
+  else fp6_inv(r, x);
+  store_fp6(out, n, i, 0, r);
+}
+enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROB1 = 3, OP12_FROB2 = 4, OP12_FROB3 = 5, OP12_SPARSE = 6, OP12_CYCSQR = 7 };
+__global__ void HEAVY_BOUNDS k_fp12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp12 x, y, r;
+  load_fp12(x, a, n, i);
+  switch (op) {
+    case OP12_MUL: load_fp12(y, b, n, i); fp12_mul(r, x, y); break;
+    case OP12_SQR: fp12_sqr(r, x); break;
+    case OP12_INV: fp12_inv(r, x); break;
+    case OP12_FROB1: fp12_frobenius<1>(r, x); break;
+    case OP12_FROB2: fp12_frobenius<2>(r, x); break;
+    case OP12_FROB3: fp12_frobenius<3>(r, x); break;
+    case OP12_CYCSQR: cyclotomic_sqr(r, x); break;
+    default: {
+      Fp2 l0 = load_fp2(b, n, i, 0), lvw = load_fp2(b, n, i, 8), lvv = load_fp2(b, n, i, 16);
+      r = x;
+      fp12_sparse_mul(r, l0, lvw, lvv);
+    }
+  }
+  store_fp12(out, n, i, r);
+}
+
+// ------------------------------------------------------------------ group kernels --------------
+BN_DEV void load_scalar(u32 (&k)[8], const u64* base, size_t n, size_t i) {
+  // scalars are Fp values: reduce like Fp::new so that k >= p behaves as in the reference
+  Fp s = fp_from_mont(fp_to_mont(load_plain(base, n, i, 0)));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = s.v[j];
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool inf = pinf && pinf[i];
+  G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), inf ? fp_zero() : fp_one()};
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G1P r = g1_scalar_mul(p, k);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool inf = pinf && pinf[i];
+  G2P p{load_fp2(pxy, n, i, 0), load_fp2(pxy, n, i, 8), inf ? fp2_zero() : fp2_one()};
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G2P r;
+  g2_scalar_mul(r, p, k);
+  Fp2 x, y; bool rinf;
+  g2_to_affine(x, y, rinf, r);
+  store_fp2(oxy, n, i, 0, x); store_fp2(oxy, n, i, 8, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P b{load_fp(bxy, n, i, 0), load_fp(bxy, n, i, 4), (binf && binf[i]) ? fp_zero() : fp_one()};
+  G1P r = g1_add(a, b);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P p{load_fp(pxyz, n, i, 0), load_fp(pxyz, n, i, 4), load_fp(pxyz, n, i, 8)};
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, p);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void __launch_bounds__(BLOCK) k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G2P p{load_fp2(pxyz, n, i, 0), load_fp2(pxyz, n, i, 8), load_fp2(pxyz, n, i, 16)};
+  Fp2 x, y; bool rinf;
+  g2_to_affine(x, y, rinf, p);
+  store_fp2(oxy, n, i, 0, x); store_fp2(oxy, n, i, 8, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+// g2.rs:460-525 on an affine input: on-curve, then (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ)
+__global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* qinf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  if (qinf && qinf[i]) { status[i] = SYLOW_HIP_ST_OK; return; }   // Z == 0 passes both tests (g2.rs:469,510)
+  Fp2 x = load_fp2(qxy, n, i, 0), y = load_fp2(qxy, n, i, 8);
+  if (!g2_on_curve_affine(x, y)) { status[i] = SYLOW_HIP_ST_NOT_ON_CURVE; return; }
+  G2P q{x, y, fp2_one()};
+  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
+  G2P a;
+  g2_scalar_mul(a, q, bx);                       // xQ
+  // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
+  auto psi = [](G2P& r, const G2P& p) {
+    r.x = fp2_mul(fp2_const(C_EPS_EXP0), fp2_conj(p.x));
+    r.y = fp2_mul(fp2_const(C_EPS_EXP1), fp2_conj(p.y));
+    r.z = fp2_conj(p.z);
+  };
+  G2P b, c, l, r;
+  psi(b, a);                                      // psi(xQ)
+  g2_add(a, a, q);                                // (x+1)Q
+  psi(c, b);                                      // psi^2(xQ)
+  g2_add(l, c, b);
+  g2_add(l, l, a);                                // lhs
+  psi(r, c);
+  g2_double(r, r);                                // psi^3(2xQ)
+  G2P nl = proj_neg<OpsFp2>(l);
+  g2_add(r, r, nl);
+  status[i] = fp2_is_zero(r.z) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+}
+
+// ------------------------------------------------------------------ pairing kernels -------------
+__global__ void HEAVY_BOUNDS k_miller_loop(const u64* pxy, const u64* qxy, u64* fout, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+  Fp2 qx = load_fp2(qxy, n, i, 0), qy = load_fp2(qxy, n, i, 8);
+  Fp12 f;
+  miller_loop(f, px, py, qx, qy);
+  store_fp12(fout, n, i, f);
+}
+__global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp12 f, g;
+  load_fp12(f, fin, n, i);
+  final_exponentiation(g, f);
+  store_fp12(gout, n, i, g);
+}
+// pairing.rs:870-893
+__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
+  Fp12 f, g;
+  if (either_zero) {
+    fp12_set_one(g);   // Miller value forced to one; final_exponentiation(1) == 1
+  } else {
+    Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+    Fp2 qx = load_fp2(qxy, n, i, 0), qy = load_fp2(qxy, n, i, 8);
+    miller_loop(f, px, py, qx, qy);
+    final_exponentiation(g, f);
+  }
+  store_fp12(gout, n, i, g);
+}
+
+
+// ------------------------------------------------------------------ multi-pairing ---------------
+// glued_miller_loop + final_exponentiation (pairing.rs:970-1037): one job per lane, the job's pairs
+// share each squaring of the accumulator.  Pairs are processed KMAX at a time; the product of the
+// chunk accumulators equals the reference's single accumulator exactly (Fp12 multiplication is
+// exact and commutative, and (prod f_c)^2 * prod lines is the same recurrence).
+constexpr int KMAX = 4;
+struct PairState { G2P r; Fp2 qx, qy; Fp px, py; bool qinf; };
+
+__global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                             const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
+                                             u64* gout, uint8_t* is_one) {
+  size_t job = TID;
+  if (job >= n_jobs) return;
+  size_t lo = offsets[job], hi = offsets[job + 1];
+  Fp12 acc;
+  fp12_set_one(acc);
+  PairState st[KMAX];
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+  size_t next = lo;
+#pragma unroll 1
+  while (next < hi) {
+    int k = 0;
+#pragma unroll 1
+    for (; next < hi && k < KMAX; ++next) {
+      bool pi = pinf && pinf[next], qi = qinf && qinf[next];
+      if (skip_infinity && (pi || qi)) continue;          // EIP-197: a pair with an identity contributes 1
+      PairState& s = st[k++];
+      s.px = load_fp(pxy, n_pairs, next, 0); s.py = load_fp(pxy, n_pairs, next, 4);
+      s.qx = load_fp2(qxy, n_pairs, next, 0); s.qy = load_fp2(qxy, n_pairs, next, 8);
+      s.qinf = qi;
+      // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the reference's
+      // glued loop never looks at the flag again, neither do we in replay mode
+      s.r = G2P{s.qx, s.qy, qi ? fp2_zero() : fp2_one()};
+    }
+    if (k == 0) continue;
+    Fp12 f;
+    fp12_set_one(f);
+    Fp2 l0, l1, l2;
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      fp12_sqr(f, f);
+#pragma unroll 1
+      for (int j = 0; j < k; ++j) { g2_doubling_step(st[j].r, l0, l1, l2); line_mul(f, l0, l1, l2, st[j].px, st[j].py); }
+      if ((nz >> (63 - i)) & 1) {
+        bool neg = (ng >> (63 - i)) & 1;
+#pragma unroll 1
+        for (int j = 0; j < k; ++j) {
+          Fp2 by = neg ? fp2_neg(st[j].qy) : st[j].qy;
+          g2_addition_step(st[j].r, st[j].qx, by, l0, l1, l2);
+          line_mul(f, l0, l1, l2, st[j].px, st[j].py);
+        }
+      }
+    }
+    // the two Frobenius additions; endomorphism() returns self for the identity (g2.rs:141-143)
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+#pragma unroll 1
+      for (int j = 0; j < k; ++j) {
+        Fp2 q1x, q1y, q2x, q2y;
+        if (st[j].qinf) { q1x = st[j].qx; q1y = st[j].qy; q2x = q1x; q2y = q1y; }
+        else { g2_psi_affine(q1x, q1y, st[j].qx, st[j].qy); g2_psi_affine(q2x, q2y, q1x, q1y); }
+        if (step == 0) g2_addition_step(st[j].r, q1x, q1y, l0, l1, l2);
+        else g2_addition_step(st[j].r, q2x, fp2_neg(q2y), l0, l1, l2);
+        line_mul(f, l0, l1, l2, st[j].px, st[j].py);
+      }
+    }
+    fp12_mul(acc, acc, f);
+  }
+  Fp12 g;
+  final_exponentiation(g, acc);
+  if (gout) store_fp12(gout, n_jobs, job, g);
+  if (is_one) {
+    Fp12 one;
+    fp12_set_one(one);
+    is_one[job] = fp12_eq(g, one) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------ hash / BLS kernels ----------
+__global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  bool ok = hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, h);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = inf ? 1 : 0;
+  if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
+}
+// lib.rs:179-187
+__global__ void __launch_bounds__(BLOCK) k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  u32 k[8];
+  load_scalar(k, sk, n, i);
+  G1P s = g1_scalar_mul(h, k);
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, s);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = inf ? 1 : 0;
+}
+// lib.rs:223-236: ok = pairing(sig, G2gen) == pairing(H(msg), pk), two full pairings as written
+__global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                          const u64* sigxy, const uint8_t* siginf, uint8_t* okout, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  Fp hx, hy; bool hinf;
+  g1_to_affine(hx, hy, hinf, h);
+  Fp12 f, lhs, rhs;
+  // lhs = pairing(sig, G2gen)
+  if (siginf && siginf[i]) {
+    fp12_set_one(lhs);
+  } else {
+    Fp sx = load_fp(sigxy, n, i, 0), sy = load_fp(sigxy, n, i, 4);
+    Fp2 gx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, gy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
+    miller_loop(f, sx, sy, gx, gy);
+    final_exponentiation(lhs, f);
+  }
+  // rhs = pairing(H, pk)
+  if (hinf || (pkinf && pkinf[i])) {
+    fp12_set_one(rhs);
+  } else {
+    Fp2 qx = load_fp2(pkxy, n, i, 0), qy = load_fp2(pkxy, n, i, 8);
+    miller_loop(f, hx, hy, qx, qy);
+    final_exponentiation(rhs, f);
+  }
+  okout[i] = fp12_eq(lhs, rhs) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ layout helpers --------------
+__global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
+  size_t t = TID;
+  if (t >= words * n) return;
+  size_t w = t / n, i = t % n;
+  soa[t] = aos[i * words + w];
+}
+__global__ void __launch_bounds__(BLOCK) k_soa_to_aos(const u64* __restrict__ soa, u64* __restrict__ aos, size_t words, size_t n) {
+  size_t t = TID;
+  if (t >= words * n) return;
+  size_t w = t / n, i = t % n;
+  aos[i * words + w] = soa[t];
+}
+__global__ void __launch_bounds__(BLOCK) k_flags_all(const uint8_t* flags, size_t n, int32_t* out) {
+  // out pre-set to 1; any zero flag clears it
+  size_t i = TID;
+  bool bad = (i < n) && (flags[i] == 0);
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicAnd(out, 0);
+}
+
+// ================================================================== C ABI ======================
+static thread_local char g_err[256] = "";
+static int32_t fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return SYLOW_HIP_E_HIP;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(e_, #x); } while (0)
+#define ARGCHK(c) do { if (!(c)) { snprintf(g_err, sizeof(g_err), "bad argument: %s", #c); return SYLOW_HIP_E_ARG; } } while (0)
+#define GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream
+#define LAUNCHED() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "kernel launch"); return SYLOW_HIP_OK; } while (0)
+
+extern "C" {
+
+const char* sylow_hip_last_error(void) { return g_err; }
+int32_t sylow_hip_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+int32_t sylow_hip_init(int32_t device) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess || c == 0) { snprintf(g_err, sizeof(g_err), "no HIP device"); return SYLOW_HIP_E_NO_DEVICE; }
+  ARGCHK(device >= 0 && device < c);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(g_err, sizeof(g_err), "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return SYLOW_HIP_E_NO_DEVICE;
+  }
+  return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_malloc(void** dptr, size_t bytes) { ARGCHK(dptr); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return SYLOW_HIP_OK; }
+int32_t sylow_hip_free(void* dptr) { HIPCHK(hipFree(dptr)); return SYLOW_HIP_OK; }
+int32_t sylow_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_stream_sync(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return SYLOW_HIP_OK; }
+int32_t sylow_hip_aos_to_soa(const uint64_t* aos, uint64_t* soa, size_t words, size_t n, void* stream) {
+  ARGCHK(aos && soa); if (!n || !words) return SYLOW_HIP_OK;
+  k_aos_to_soa<<<GRID(words * n)>>>(aos, soa, words, n); LAUNCHED();
+}
+int32_t sylow_hip_soa_to_aos(const uint64_t* soa, uint64_t* aos, size_t words, size_t n, void* stream) {
+  ARGCHK(aos && soa); if (!n || !words) return SYLOW_HIP_OK;
+  k_soa_to_aos<<<GRID(words * n)>>>(soa, aos, words, n); LAUNCHED();
+}
+
+#define FP_BIN(name, OP)                                                                                         \
+  int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) { \
+    ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;                                                           \
+    k_fp_binop<OP><<<GRID(n)>>>(a, b, out, n); LAUNCHED();                                                        \
+  }
+FP_BIN(add, OP_ADD) FP_BIN(sub, OP_SUB) FP_BIN(mul, OP_MUL)
+#define FP_UN(name, OP)                                                                                  \
+  int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {           \
+    ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;                                                        \
+    k_fp_unop<OP><<<GRID(n)>>>(a, out, n); LAUNCHED();                                                    \
+  }
+FP_UN(sqr, OP_SQR) FP_UN(neg, OP_NEG) FP_UN(inv, OP_INV)
+
+int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OP_MUL, a, b, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp2_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OP_SQR, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp2_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OP_INV, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp6_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OP_MUL, a, b, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp6_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OP_INV, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_MUL, a, b, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp12_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_SQR, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp12_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_INV, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp12_frobenius_batch(const uint64_t* a, int32_t exponent, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out && exponent >= 1 && exponent <= 3); if (!n) return SYLOW_HIP_OK;
+  k_fp12_op<<<GRID(n)>>>(OP12_FROB1 + exponent - 1, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp12_sparse_mul_batch(const uint64_t* f, const uint64_t* ell, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(f && ell && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_SPARSE, f, ell, out, n); LAUNCHED();
+}
+// test hook (not in the public header's stable surface): Granger-Scott cyclotomic square
+int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_CYCSQR, a, nullptr, out, n); LAUNCHED();
+}
+
+int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g2_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g2_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(q_xy && status); if (!n) return SYLOW_HIP_OK;
+  k_g2_subgroup_check<<<GRID(n)>>>(q_xy, q_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
+  ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
+  k_miller_loop<<<GRID(n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
+}
+int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
+  ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
+  k_final_exp<<<GRID(n)>>>(f, gt_out, n); LAUNCHED();
+}
+int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
+  ARGCHK(p_xy && q_xy && gt_out); if (!n) return SYLOW_HIP_OK;
+  k_pairing<<<GRID(n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
+}
+
+int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                      const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
+                                      uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
+  k_multi_pairing<<<GRID(n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED();
+}
+static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
+static void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
+  if (!dst) { dst = SYLOW_DST; len = 30; }
+  make_dst_prime(dp, dst, len);
+}
+int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                   uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; dst_arg(dp, dst_host, dst_len);
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                 uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
+  ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; dst_arg(dp, nullptr, 0);
+  k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; dst_arg(dp, nullptr, 0);
+  k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+}
+int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
+  ARGCHK(out_dev && (flags || !n));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)out_dev, 1, 1, (hipStream_t)stream));
+  if (!n) return SYLOW_HIP_OK;
+  k_flags_all<<<GRID(n)>>>(flags, n, out_dev); LAUNCHED();
+}
+
+}  // extern "C"

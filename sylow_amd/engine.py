@@ -1,0 +1,262 @@
+"""Batch engine: device buffers + one method per C-ABI entry point, numpy in / numpy out.
+
+Host-side arrays are array-of-structs uint64 [n, W] (W as in include/sylow_hip.h); the engine
+transposes to the struct-of-arrays [W, n] device layout.  Device-resident use (bench.py) goes
+through `DeviceArray` handles directly, so the timed region contains no host traffic.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """A hipMalloc'ed buffer holding a numpy-shaped array (row-major)."""
+
+    def __init__(self, engine: "Engine", shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = ctypes.c_void_p()
+        _lib.check(engine.lib.sylow_hip_malloc(ctypes.byref(p), self.nbytes), "malloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.sylow_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes, (arr.shape, self.shape)
+        _lib.check(self.engine.lib.sylow_hip_memcpy_h2d(self.ptr, arr.ctypes.data, self.nbytes, self.engine.stream), "h2d")
+        _lib.check(self.engine.lib.sylow_hip_stream_sync(self.engine.stream), "sync")
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        _lib.check(self.engine.lib.sylow_hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, self.engine.stream), "d2h")
+        _lib.check(self.engine.lib.sylow_hip_stream_sync(self.engine.stream), "sync")
+        return out
+
+
+def _aos(a, width):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, width)
+    assert a.ndim == 2 and a.shape[1] == width, (a.shape, width)
+    return a
+
+
+class Engine:
+    """One engine per process / GPU (one process per GPU, as torch.distributed launches them)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = _lib.load()
+        _lib.check(self.lib.sylow_hip_init(device), "sylow_hip_init")
+        self.device = device
+        self.stream = stream  # raw hipStream_t as int, or None for the default stream
+
+    # ---- buffers ---------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.uint64) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def to_device_soa(self, aos: np.ndarray, width: int) -> DeviceArray:
+        a = _aos(aos, width)
+        return self.empty((width, a.shape[0])).upload(np.ascontiguousarray(a.T))
+
+    def to_device(self, arr: np.ndarray, dtype=None) -> DeviceArray:
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        return self.empty(arr.shape, arr.dtype).upload(arr)
+
+    def from_device_soa(self, d: DeviceArray) -> np.ndarray:
+        return np.ascontiguousarray(d.download().T)
+
+    def sync(self):
+        _lib.check(self.lib.sylow_hip_stream_sync(self.stream), "sync")
+
+    def _flags(self, inf, n):
+        if inf is None:
+            return None
+        f = np.ascontiguousarray(inf, dtype=np.uint8).reshape(n)
+        return self.to_device(f)
+
+    @staticmethod
+    def _ptr(d):
+        return None if d is None else d.ptr
+
+    def _call(self, name, *args):
+        _lib.check(getattr(self.lib, name)(*args, self.stream), name)
+
+    # ---- field ops (numpy AoS in/out) -----------------------------------------------------
+    def _binop(self, name, width, a, b):
+        a, b = _aos(a, width), _aos(b, width)
+        n = a.shape[0]
+        da, db = self.to_device_soa(a, width), self.to_device_soa(b, width)
+        do = self.empty((width, n))
+        self._call(name, da.ptr, db.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
+    def _unop(self, name, width, a, *extra):
+        a = _aos(a, width)
+        n = a.shape[0]
+        da = self.to_device_soa(a, width)
+        do = self.empty((width, n))
+        self._call(name, da.ptr, *extra, do.ptr, n)
+        return self.from_device_soa(do)
+
+    def fp_add(self, a, b): return self._binop("sylow_hip_fp_add_batch", 4, a, b)
+    def fp_sub(self, a, b): return self._binop("sylow_hip_fp_sub_batch", 4, a, b)
+    def fp_mul(self, a, b): return self._binop("sylow_hip_fp_mul_batch", 4, a, b)
+    def fp_sqr(self, a): return self._unop("sylow_hip_fp_sqr_batch", 4, a)
+    def fp_neg(self, a): return self._unop("sylow_hip_fp_neg_batch", 4, a)
+    def fp_inv(self, a): return self._unop("sylow_hip_fp_inv_batch", 4, a)
+    def fp2_mul(self, a, b): return self._binop("sylow_hip_fp2_mul_batch", 8, a, b)
+    def fp2_sqr(self, a): return self._unop("sylow_hip_fp2_sqr_batch", 8, a)
+    def fp2_inv(self, a): return self._unop("sylow_hip_fp2_inv_batch", 8, a)
+    def fp6_mul(self, a, b): return self._binop("sylow_hip_fp6_mul_batch", 24, a, b)
+    def fp6_inv(self, a): return self._unop("sylow_hip_fp6_inv_batch", 24, a)
+    def fp12_mul(self, a, b): return self._binop("sylow_hip_fp12_mul_batch", 48, a, b)
+    def fp12_sqr(self, a): return self._unop("sylow_hip_fp12_sqr_batch", 48, a)
+    def fp12_inv(self, a): return self._unop("sylow_hip_fp12_inv_batch", 48, a)
+    def fp12_frobenius(self, a, e): return self._unop("sylow_hip_fp12_frobenius_batch", 48, a, int(e))
+
+    def fp12_cyclotomic_sqr(self, a):
+        fn = self.lib.sylow_hip_fp12_cyclotomic_sqr_batch
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        fn.restype = ctypes.c_int32
+        return self._unop("sylow_hip_fp12_cyclotomic_sqr_batch", 48, a)
+
+    def fp12_sparse_mul(self, f, ell):
+        f, ell = _aos(f, 48), _aos(ell, 24)
+        n = f.shape[0]
+        df, dl = self.to_device_soa(f, 48), self.to_device_soa(ell, 24)
+        do = self.empty((48, n))
+        self._call("sylow_hip_fp12_sparse_mul_batch", df.ptr, dl.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
+    # ---- groups ----------------------------------------------------------------------------
+    def _scalar_mul(self, name, width, p_xy, p_inf, k):
+        p_xy, k = _aos(p_xy, width), _aos(k, 4)
+        n = p_xy.shape[0]
+        dp, dk, di = self.to_device_soa(p_xy, width), self.to_device_soa(k, 4), self._flags(p_inf, n)
+        do, doi = self.empty((width, n)), self.empty((n,), np.uint8)
+        self._call(name, dp.ptr, self._ptr(di), dk.ptr, do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def g1_scalar_mul(self, p_xy, k, p_inf=None): return self._scalar_mul("sylow_hip_g1_scalar_mul_batch", 8, p_xy, p_inf, k)
+    def g2_scalar_mul(self, p_xy, k, p_inf=None): return self._scalar_mul("sylow_hip_g2_scalar_mul_batch", 16, p_xy, p_inf, k)
+
+    def g1_add(self, a_xy, b_xy, a_inf=None, b_inf=None):
+        a_xy, b_xy = _aos(a_xy, 8), _aos(b_xy, 8)
+        n = a_xy.shape[0]
+        da, db = self.to_device_soa(a_xy, 8), self.to_device_soa(b_xy, 8)
+        dai, dbi = self._flags(a_inf, n), self._flags(b_inf, n)
+        do, doi = self.empty((8, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_g1_add_batch", da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def _normalize(self, name, win, wout, p):
+        p = _aos(p, win)
+        n = p.shape[0]
+        dp = self.to_device_soa(p, win)
+        do, doi = self.empty((wout, n)), self.empty((n,), np.uint8)
+        self._call(name, dp.ptr, do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def g1_normalize(self, p_xyz): return self._normalize("sylow_hip_g1_normalize_batch", 12, 8, p_xyz)
+    def g2_normalize(self, p_xyz): return self._normalize("sylow_hip_g2_normalize_batch", 24, 16, p_xyz)
+
+    def g2_subgroup_check(self, q_xy, q_inf=None):
+        q_xy = _aos(q_xy, 16)
+        n = q_xy.shape[0]
+        dq, di = self.to_device_soa(q_xy, 16), self._flags(q_inf, n)
+        ds = self.empty((n,), np.uint8)
+        self._call("sylow_hip_g2_subgroup_check_batch", dq.ptr, self._ptr(di), ds.ptr, n)
+        return ds.download()
+
+    # ---- pairing ---------------------------------------------------------------------------
+    def miller_loop(self, p_xy, q_xy):
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        dp, dq = self.to_device_soa(p_xy, 8), self.to_device_soa(q_xy, 16)
+        do = self.empty((48, n))
+        self._call("sylow_hip_miller_loop_batch", dp.ptr, dq.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
+    def final_exp(self, f):
+        return self._unop("sylow_hip_final_exp_batch", 48, f)
+
+    def pairing(self, p_xy, q_xy, p_inf=None, q_inf=None):
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        dp, dq = self.to_device_soa(p_xy, 8), self.to_device_soa(q_xy, 16)
+        dpi, dqi = self._flags(p_inf, n), self._flags(q_inf, n)
+        do = self.empty((48, n))
+        self._call("sylow_hip_pairing_batch", dp.ptr, self._ptr(dpi), dq.ptr, self._ptr(dqi), do.ptr, n)
+        return self.from_device_soa(do)
+
+    def multi_pairing(self, p_xy, q_xy, offsets, p_inf=None, q_inf=None, skip_infinity=False, want_gt=True):
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nj = off.shape[0] - 1
+        dp = self.to_device_soa(p_xy, 8) if n else self.empty((8, 1))
+        dq = self.to_device_soa(q_xy, 16) if n else self.empty((16, 1))
+        dpi, dqi = (self._flags(p_inf, n), self._flags(q_inf, n)) if n else (None, None)
+        doff = self.to_device(off)
+        dgt = self.empty((48, max(nj, 1))) if want_gt else None
+        dis = self.empty((max(nj, 1),), np.uint8)
+        self._call("sylow_hip_multi_pairing_batch", dp.ptr, self._ptr(dpi), dq.ptr, self._ptr(dqi), doff.ptr, nj, n,
+                   1 if skip_infinity else 0, self._ptr(dgt), dis.ptr)
+        gt = self.from_device_soa(dgt)[:nj] if want_gt else None
+        return gt, dis.download()[:nj]
+
+    # ---- hashing / BLS ---------------------------------------------------------------------
+    def _msgs(self, msgs):
+        off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+        for i, m in enumerate(msgs):
+            off[i + 1] = off[i] + len(m)
+        blob = np.frombuffer(b"".join(msgs) or b"\x00", dtype=np.uint8)
+        return self.to_device(blob), self.to_device(off)
+
+    def hash_to_g1(self, msgs, dst: bytes | None = None):
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        do, doi = self.empty((8, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_hash_to_g1_batch", dm.ptr, doff.ptr, dst, len(dst) if dst else 0, do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def bls_sign(self, sk, msgs):
+        sk = _aos(sk, 4)
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        dsk = self.to_device_soa(sk, 4)
+        do, doi = self.empty((8, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_bls_sign_batch", dsk.ptr, dm.ptr, doff.ptr, do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def bls_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None):
+        pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        dpk, dsig = self.to_device_soa(pk_xy, 16), self.to_device_soa(sig_xy, 8)
+        dpi, dsi = self._flags(pk_inf, n), self._flags(sig_inf, n)
+        dok = self.empty((n,), np.uint8)
+        self._call("sylow_hip_bls_verify_batch", dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
+        return dok.download()
+
+    def flags_all(self, dflags: DeviceArray) -> int:
+        out = self.empty((1,), np.int32)
+        self._call("sylow_hip_flags_all", dflags.ptr, dflags.shape[0], out.ptr)
+        return int(out.download()[0])
