@@ -99,7 +99,10 @@ BN_DEV Fp fp_cond_sub_p(const u32 r[8], u32 top) {
 }
 
 // Montgomery product a*b/R mod p, inputs and output canonical (fp.rs:387-393).
-BN_DEV Fp fp_mul(const Fp& a, const Fp& b) {
+// Out-of-line leaf: 8 + 8 argument registers is exactly what the AMDGPU C ABI passes in VGPRs
+// (16), the result comes back in 8, and the body touches ~50 VGPRs, so callers keep ~200
+// registers of live tower state across the call without spilling.
+BN_DEV Fp fp_mul_inline(const Fp& a, const Fp& b) {
   const u32 p[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
   u32 m[8];
   u32 r[8];
@@ -129,6 +132,7 @@ BN_DEV Fp fp_mul(const Fp& a, const Fp& b) {
   return fp_cond_sub_p(r, (u32)acc);
 }
 
+BN_NOINLINE Fp fp_mul(Fp a, Fp b) { return fp_mul_inline(a, b); }
 BN_DEV Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }  // fp.rs:620-622
 
 // (a + b) mod p  (fp.rs:304-310)

@@ -35,21 +35,21 @@ BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_
 BN_DEV Fp2 fp2_select(const Fp2& a, const Fp2& b, bool c) { return Fp2{fp_select(a.c0, b.c0, c), fp_select(a.c1, b.c1, c)}; }
 
 // fp2.rs:285-306 (value); Karatsuba: 3 Fp products
-BN_NOINLINE Fp2 fp2_mul(Fp2 a, Fp2 b) {
+BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
   Fp v0 = fp_mul(a.c0, b.c0);
   Fp v1 = fp_mul(a.c1, b.c1);
   Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
   return Fp2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
 // fp2.rs:164-171: (a0+a1)(a0-a1), 2 a0 a1
-BN_NOINLINE Fp2 fp2_sqr(Fp2 a) {
+BN_DEV Fp2 fp2_sqr(const Fp2& a) {
   Fp s = fp_add(a.c0, a.c1);
   Fp d = fp_sub(a.c0, a.c1);
   Fp t = fp_mul(a.c0, a.c1);
   return Fp2{fp_mul(s, d), fp_dbl(t)};
 }
 // extensions.rs:86-94 with F = Fp
-BN_NOINLINE Fp2 fp2_scale(Fp2 a, Fp k) { return Fp2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
+BN_DEV Fp2 fp2_scale(const Fp2& a, const Fp& k) { return Fp2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
 // x (9+u): (9a - b, a + 9b)  (fp2.rs:99-107); 9x = 8x + x by doublings
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {
   Fp a8 = fp_dbl(fp_dbl(fp_dbl(a.c0)));

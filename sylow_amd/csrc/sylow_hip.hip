@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, c
   if (i >= n) return;
   Fp x = load_plain(a, n, i, 0), y = load_plain(b, n, i, 0), r;
   if (OP == OP_MUL) {
-    r = fp_mul(fp_to_mont(x), y);
+    r = fp_mul_inline(fp_mul_inline(x, fp_r2()), y);
   } else {
     // reduce arbitrary 256-bit inputs like Fp::new, then add/sub on canonical values (no Montgomery needed)
     x = fp_from_mont(fp_to_mont(x));

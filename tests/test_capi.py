@@ -1,0 +1,59 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/sylow_hip.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared():
+    with open(os.path.join(ROOT, "include", "sylow_hip.h")) as f:
+        return sorted(set(re.findall(r"\b(sylow_hip_[a-z0-9_]+)\s*\(", f.read())))
+
+
+def test_library_exports_every_declared_symbol():
+    import sylow_amd
+    from sylow_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        sylow_amd.build()
+    lib = sylow_amd.load()
+    names = declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+    # and the Python binding table covers the same set
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_product_package_does_not_import_oracle():
+    """The product path must never route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "sylow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, fn)
+                assert "libsylow_oracle" not in text and "sylow_oracle.c" not in text, os.path.join(dirpath, fn)
+                assert "pyref" not in text and "coracle" not in text, os.path.join(dirpath, fn)
+
+
+def test_no_gpu_fails_loudly():
+    import sylow_amd
+    lib = sylow_amd.load()
+    if lib.sylow_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert lib.sylow_hip_init(0) < 0
+    assert b"no HIP device" in lib.sylow_hip_last_error()
+    with pytest.raises(sylow_amd.SylowHipError):
+        sylow_amd.Engine(0)
+
+
+def test_argument_errors_are_reported_not_thrown():
+    import sylow_amd
+    lib = sylow_amd.load()
+    rc = lib.sylow_hip_fp_mul_batch(None, None, None, 4, None)
+    assert rc == -2 and b"bad argument" in lib.sylow_hip_last_error()
+    assert lib.sylow_hip_fp_mul_batch(None, None, None, 0, None) == -2
