@@ -260,51 +260,82 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
 // share each squaring of the accumulator.  Pairs are processed KMAX at a time; the product of the
 // chunk accumulators equals the reference's single accumulator exactly (Fp12 multiplication is
 // exact and commutative, and (prod f_c)^2 * prod lines is the same recurrence).
+//
+// The schedule is WAVE-UNIFORM: every lane walks the same number of chunks and the same number of
+// pair slots per chunk (the wavefront maximum); a lane whose job has fewer pairs steps a dummy point
+// and multiplies its accumulator by the unit line (1, 0, 0), which leaves it bit-identical.  The
+// shared digit schedule is uniform anyway, so the whole Miller loop runs without divergence.
 constexpr int KMAX = 4;
-struct PairState { G2P r; Fp2 qx, qy; Fp px, py; bool qinf; };
+struct PairState { G2P r; Fp2 qx, qy; Fp px, py; bool qinf; bool live; };
+
+BN_DEV int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(v, off); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
 __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                              const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
                                              u64* gout, uint8_t* is_one) {
   size_t job = TID;
-  if (job >= n_jobs) return;
-  size_t lo = offsets[job], hi = offsets[job + 1];
+  const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
+  size_t next = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
   Fp12 acc;
   fp12_set_one(acc);
   PairState st[KMAX];
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
-  size_t next = lo;
+  const Fp2 gx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, gy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
 #pragma unroll 1
-  while (next < hi) {
+  while (wave_max(next < hi ? 1 : 0)) {
+    // gather up to KMAX pairs of this lane's job; dead slots hold the generator (any curve point does)
     int k = 0;
 #pragma unroll 1
-    for (; next < hi && k < KMAX; ++next) {
-      bool pi = pinf && pinf[next], qi = qinf && qinf[next];
-      if (skip_infinity && (pi || qi)) continue;          // EIP-197: a pair with an identity contributes 1
-      PairState& s = st[k++];
-      s.px = load_fp(pxy, n_pairs, next, 0); s.py = load_fp(pxy, n_pairs, next, 4);
-      s.qx = load_fp2(qxy, n_pairs, next, 0); s.qy = load_fp2(qxy, n_pairs, next, 8);
+    for (int slot = 0; slot < KMAX; ++slot) {
+      bool have = false;
+      size_t idx = 0;
+      // advance to the next pair this lane actually multiplies in (bounded scan: uniform trip count not needed, no calls inside)
+      while (next < hi) {
+        bool pi = pinf && pinf[next], qi = qinf && qinf[next];
+        idx = next++;
+        if (!(skip_infinity && (pi || qi))) { have = true; break; }   // EIP-197: identity pairs contribute 1
+      }
+      PairState& s = st[slot];
+      s.live = have;
+      size_t src = have ? idx : 0;
+      bool qi = have && qinf && qinf[src];
+      bool ld = have && n_pairs != 0;
+      s.px = ld ? load_fp(pxy, n_pairs, src, 0) : fp_one();
+      s.py = ld ? load_fp(pxy, n_pairs, src, 4) : fp_one();
+      s.qx = ld ? load_fp2(qxy, n_pairs, src, 0) : gx;
+      s.qy = ld ? load_fp2(qxy, n_pairs, src, 8) : gy;
       s.qinf = qi;
-      // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the reference's
-      // glued loop never looks at the flag again, neither do we in replay mode
+      // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the reference's glued
+      // loop never looks at the flag again, neither do we in replay mode
       s.r = G2P{s.qx, s.qy, qi ? fp2_zero() : fp2_one()};
+      if (have) k = slot + 1;
     }
-    if (k == 0) continue;
+    const int kw = wave_max(k);
+    if (kw == 0) continue;
     Fp12 f;
     fp12_set_one(f);
     Fp2 l0, l1, l2;
+    const Fp2 u0 = fp2_one(), u1 = fp2_zero();
+    auto apply = [&](PairState& s) {          // f *= line, or *= 1 for a dead slot
+      bool lv = s.live;
+      fp12_sparse_mul(f, fp2_select(u0, l0, lv), fp2_select(u1, fp2_scale(l1, s.py), lv), fp2_select(u1, fp2_scale(l2, s.px), lv));
+    };
 #pragma unroll 1
     for (int i = 0; i < 64; ++i) {
       fp12_sqr(f, f);
 #pragma unroll 1
-      for (int j = 0; j < k; ++j) { g2_doubling_step(st[j].r, l0, l1, l2); line_mul(f, l0, l1, l2, st[j].px, st[j].py); }
+      for (int j = 0; j < kw; ++j) { g2_doubling_step(st[j].r, l0, l1, l2); apply(st[j]); }
       if ((nz >> (63 - i)) & 1) {
         bool neg = (ng >> (63 - i)) & 1;
 #pragma unroll 1
-        for (int j = 0; j < k; ++j) {
+        for (int j = 0; j < kw; ++j) {
           Fp2 by = neg ? fp2_neg(st[j].qy) : st[j].qy;
           g2_addition_step(st[j].r, st[j].qx, by, l0, l1, l2);
-          line_mul(f, l0, l1, l2, st[j].px, st[j].py);
+          apply(st[j]);
         }
       }
     }
@@ -312,24 +343,29 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
 #pragma unroll 1
-      for (int j = 0; j < k; ++j) {
+      for (int j = 0; j < kw; ++j) {
         Fp2 q1x, q1y, q2x, q2y;
-        if (st[j].qinf) { q1x = st[j].qx; q1y = st[j].qy; q2x = q1x; q2y = q1y; }
-        else { g2_psi_affine(q1x, q1y, st[j].qx, st[j].qy); g2_psi_affine(q2x, q2y, q1x, q1y); }
+        g2_psi_affine(q1x, q1y, st[j].qx, st[j].qy);
+        g2_psi_affine(q2x, q2y, q1x, q1y);
+        bool qi = st[j].qinf;
+        q1x = fp2_select(q1x, st[j].qx, qi); q1y = fp2_select(q1y, st[j].qy, qi);
+        q2x = fp2_select(q2x, st[j].qx, qi); q2y = fp2_select(q2y, st[j].qy, qi);
         if (step == 0) g2_addition_step(st[j].r, q1x, q1y, l0, l1, l2);
         else g2_addition_step(st[j].r, q2x, fp2_neg(q2y), l0, l1, l2);
-        line_mul(f, l0, l1, l2, st[j].px, st[j].py);
+        apply(st[j]);
       }
     }
     fp12_mul(acc, acc, f);
   }
   Fp12 g;
   final_exponentiation(g, acc);
-  if (gout) store_fp12(gout, n_jobs, job, g);
-  if (is_one) {
-    Fp12 one;
-    fp12_set_one(one);
-    is_one[job] = fp12_eq(g, one) ? 1 : 0;
+  if (active) {
+    if (gout) store_fp12(gout, n_jobs, job, g);
+    if (is_one) {
+      Fp12 one;
+      fp12_set_one(one);
+      is_one[job] = fp12_eq(g, one) ? 1 : 0;
+    }
   }
 }
 

@@ -1,0 +1,156 @@
+"""GPU parity: G1/G2 scalar multiplication, addition, normalisation, G2 subgroup check vs the oracle.
+Points are compared after affine normalisation, as the reference's own fixtures are."""
+import numpy as np
+import pytest
+
+from helpers import P, SEED, Xoshiro, fast_rand_fp_array, ints, limbs, pack
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+G1 = [1, 2]
+G2 = list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1])
+ONE4 = np.array([[1, 0, 0, 0]], dtype=np.uint64)
+
+
+def g1_proj(xy, inf=None):
+    n = xy.shape[0]
+    z = np.repeat(ONE4, n, 0)
+    if inf is not None:
+        z = z * (1 - np.asarray(inf, dtype=np.uint64))[:, None]
+    return np.concatenate([xy, z], axis=1)
+
+
+def g2_proj(xy, inf=None):
+    n = xy.shape[0]
+    z = np.concatenate([np.repeat(ONE4, n, 0), np.zeros((n, 4), dtype=np.uint64)], axis=1)
+    if inf is not None:
+        z = z * (1 - np.asarray(inf, dtype=np.uint64))[:, None]
+    return np.concatenate([xy, z], axis=1)
+
+
+def scalars(rng, n):
+    # edge scalars: 0, 1, 2, p-1, r, r-1, r+1, 2^253 pattern, then random (Fp values, NOT reduced mod r: N4)
+    edge = [0, 1, 2, 3, P - 1, R.R_ORDER, R.R_ORDER - 1, R.R_ORDER + 1, (1 << 253) - 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % P, P, P + 5]
+    return edge + [rng.fp() for _ in range(n - len(edge))]
+
+
+def test_g1_scalar_mul_vs_oracle(engine, coracle):
+    rng = Xoshiro(SEED + 20)
+    n = 512
+    k = limbs(scalars(rng, n))
+    base, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    got_xy, got_inf = engine.g1_scalar_mul(base, k)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.g1_scalar_mul(g1_proj(base), coracle.fp_op("add", k, np.zeros_like(k))))
+    assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_xy, exp_xy)
+    assert got_inf[0] == 1 and ints(got_xy[0:1]) == [0, 1]              # 0 * P = identity = (0, 1, inf)
+    assert np.array_equal(got_xy[1], base[1])                           # 1 * P = P
+    assert got_inf[5] == 1                                              # r * P = identity
+    # identity input
+    z_xy, z_inf = engine.g1_scalar_mul(pack([0, 1], 8), limbs([12345]), p_inf=[1])
+    assert z_inf[0] == 1
+
+
+def test_g2_scalar_mul_vs_oracle(engine, coracle):
+    rng = Xoshiro(SEED + 21)
+    n = 192
+    k = limbs(scalars(rng, n))
+    base, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    got_xy, got_inf = engine.g2_scalar_mul(base, k)
+    exp_xy, exp_inf = coracle.g2_to_affine(coracle.g2_scalar_mul(g2_proj(base), coracle.fp_op("add", k, np.zeros_like(k))))
+    assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_xy, exp_xy)
+
+
+def test_g1_add_and_normalize(engine, coracle):
+    rng = Xoshiro(SEED + 22)
+    n = 256
+    g = np.repeat(pack(G1, 8), n, 0)
+    a, _ = engine.g1_scalar_mul(g, limbs([rng.fp() for _ in range(n)]))
+    b, _ = engine.g1_scalar_mul(g, limbs([rng.fp() for _ in range(n)]))
+    b[0] = a[0]                                           # doubling through the complete addition
+    b[1] = a[1]; b[1, 4:8] = limbs([(-ints(a[1:2])[1]) % P])[0]   # P + (-P) = identity
+    ainf = np.zeros(n, dtype=np.uint8); binf = np.zeros(n, dtype=np.uint8)
+    ainf[2] = 1; a[2] = pack([0, 1], 8)[0]               # identity + Q = Q
+    binf[3] = 1; b[3] = pack([0, 1], 8)[0]
+    ainf[4] = binf[4] = 1; a[4] = b[4] = pack([0, 1], 8)[0]
+    got_xy, got_inf = engine.g1_add(a, b, ainf, binf)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.g1_add(g1_proj(a, ainf), g1_proj(b, binf)))
+    assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_xy, exp_xy)
+    assert got_inf[1] == 1 and got_inf[4] == 1 and np.array_equal(got_xy[2], b[2]) and np.array_equal(got_xy[3], a[3])
+    # normalisation of non-trivial projective representatives: (X*z, Y*z, z) -> (X, Y)
+    z = limbs([rng.fp() or 1 for _ in range(n)])
+    proj = np.concatenate([engine.fp_mul(a[:, :4], z), engine.fp_mul(a[:, 4:], z), z], axis=1)
+    nx, ninf = engine.g1_normalize(proj)
+    assert np.array_equal(nx, a) and not ninf.any()
+    proj[7, 8:12] = 0
+    nx, ninf = engine.g1_normalize(proj)
+    assert ninf[7] == 1 and ints(nx[7:8]) == [0, 1]                     # Z = 0 -> (0, 1, inf), group.rs:480-492
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 8, 0), limbs([rng.fp() for _ in range(8)]))
+    zq = fast_rand_fp_array(5, 8, 2)
+    projq = np.concatenate([engine.fp2_mul(q[:, :8], zq), engine.fp2_mul(q[:, 8:], zq), zq], axis=1)
+    nq, nqinf = engine.g2_normalize(projq)
+    assert np.array_equal(nq, q) and not nqinf.any()
+    eq, einf = coracle.g2_to_affine(projq)
+    assert np.array_equal(nq, eq)
+
+
+def fp2_sqrt(a):
+    """sqrt in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4 (complex method); None if a is not a square"""
+    a0, a1 = a
+    if a1 == 0:
+        s = R.fp_sqrt(a0)
+        if s is not None:
+            return (s, 0)
+        s = R.fp_sqrt((-a0) % P)
+        return (0, s)
+    n = R.fp_sqrt((a0 * a0 + a1 * a1) % P)
+    if n is None:
+        return None
+    for nn in (n, (-n) % P):
+        h = (a0 + nn) * R.fp_inv(2) % P
+        x0 = R.fp_sqrt(h)
+        if x0 is not None and x0 != 0:
+            x1 = a1 * R.fp_inv(2 * x0 % P) % P
+            if R.fp2_square((x0, x1)) == (a0 % P, a1 % P):
+                return (x0, x1)
+    return None
+
+
+def test_g2_subgroup_check(engine, coracle):
+    """g2.rs:460-525: generator multiples pass; twist points outside the r-torsion and off-curve points fail."""
+    rng = Xoshiro(SEED + 23)
+    good, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 16, 0), limbs([rng.fp() for _ in range(16)]))
+    bad = []
+    while len(bad) < 8:
+        x = (rng.fp(), rng.fp())
+        y = fp2_sqrt(R.fp2_add(R.fp2_mul(R.fp2_square(x), x), R.TWIST_B))
+        if y is not None:
+            assert R.g2_is_on_curve_affine(x, y)
+            bad.append(list(x) + list(y))
+    bad = pack([v for q in bad for v in q], 16)
+    off = good[:4].copy()
+    off[:, 8] ^= np.uint64(1)                                            # perturb y: off the curve
+    pts = np.concatenate([good, bad, off, pack(G2, 16)])
+    inf = np.zeros(pts.shape[0], dtype=np.uint8)
+    st = engine.g2_subgroup_check(pts, inf)
+    assert st[:16].tolist() == [0] * 16 and st[-1] == 0
+    assert st[16:24].tolist() == [2] * 8                                 # NotInSubgroup (cofactor is huge: random twist points are outside G2)
+    assert st[24:28].tolist() == [1] * 4                                 # NotOnCurve
+    exp = coracle.g2_projective_new(g2_proj(np.concatenate([good, bad])))
+    assert np.array_equal(st[:24], exp)
+    inf[0] = 1
+    assert engine.g2_subgroup_check(pts, inf)[0] == 0                     # identity passes (Z == 0 branch)
+
+
+def test_scalar_mul_group_properties_large(engine):
+    """size-independent properties at 2^14: (a+b)P = aP + bP and a(bP) = (ab)P (groups/mod.rs:699-768)."""
+    n = 1 << 14
+    g = np.repeat(pack(G1, 8), n, 0)
+    a, b = fast_rand_fp_array(31, n, 1), fast_rand_fp_array(32, n, 1)
+    a[:, 3] >>= np.uint64(2); b[:, 3] >>= np.uint64(2)                    # keep a+b < p
+    ap, _ = engine.g1_scalar_mul(g, a)
+    bp, _ = engine.g1_scalar_mul(g, b)
+    s = engine.fp_add(a, b)
+    sp, _ = engine.g1_scalar_mul(g, s)
+    sum_xy, sum_inf = engine.g1_add(ap, bp)
+    assert np.array_equal(sum_xy, sp) and not sum_inf.any()

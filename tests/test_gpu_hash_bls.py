@@ -1,0 +1,81 @@
+"""GPU parity: Keccak-256 XMD -> hash_to_field -> SvdW -> hash_to_curve, BLS sign and verify vs the oracle.
+(The reference pins no literal for this chain -- SURVEY.md §8c3; the oracle is pinned by public Keccak
+KATs, RFC 9380 SHA-256 vectors through the same XMD routine and round trips: tests/test_oracle_kats.py.)"""
+import numpy as np
+import pytest
+
+from helpers import P, SEED, Xoshiro, ints, limbs, pack
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+G2 = list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1])
+
+
+def messages():
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 2, 4, 31, 32, 33, 93, 94, 95, 96, 97, 135, 136, 137, 200, 271, 272, 273, 500]
+    return [rng.integers(0, 256, size=l, dtype=np.uint8).tobytes() for l in lens] + [(20).to_bytes(4, "big")]
+
+
+def test_hash_to_g1_vs_oracle(engine, coracle):
+    msgs = messages()
+    xy, inf = engine.hash_to_g1(msgs)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.hash_to_curve(msgs))
+    assert np.array_equal(xy, exp_xy) and np.array_equal(inf, exp_inf)
+    for i in (0, 5, 20):                                        # and against the independent Python restatement
+        a = R.affine_from_proj(R.F1, R.hash_to_curve(msgs[i]))
+        assert ints(xy[i:i + 1]) == [a[0], a[1]]
+        assert R.g1_is_on_curve_affine(a[0], a[1])
+    # custom and oversize (> 255 bytes -> hashed) domain separation tags (hasher.rs:157-173)
+    for dst in (b"QUUX-V01-CS02-with-BN254G1_XMD:KECCAK-256_SVDW_RO_", b"x" * 255, b"y" * 256, b"z" * 400):
+        xy2, _ = engine.hash_to_g1(msgs[:6], dst)
+        e2, _ = coracle.g1_to_affine(coracle.hash_to_curve(msgs[:6], dst))
+        assert np.array_equal(xy2, e2), len(dst)
+
+
+def test_sign_verify_vs_oracle(engine, coracle):
+    rng = Xoshiro(SEED + 30)
+    msgs = messages()
+    n = len(msgs)
+    sk = limbs([rng.fp() for _ in range(n)])
+    sig_xy, sig_inf = engine.bls_sign(sk, msgs)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.sign(sk, msgs))
+    assert np.array_equal(sig_xy, exp_xy) and np.array_equal(sig_inf, exp_inf)
+    pk_xy, pk_inf = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    assert engine.bls_verify(pk_xy, msgs, sig_xy).tolist() == [1] * n              # lib.rs:29-42 round trip
+    # planted corruption pattern: wrong message, sig + G1gen, wrong key
+    bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
+    plant = np.zeros(n, dtype=bool)
+    plant[[1, 7, 13]] = True
+    mixed = np.where(plant[:, None], bad_sig, sig_xy)
+    got = engine.bls_verify(pk_xy, msgs, mixed)
+    assert got.tolist() == (~plant).astype(int).tolist()
+    pk_proj = np.concatenate([pk_xy, np.repeat(pack([1, 0], 8), n, 0)], axis=1)
+    sig_proj = np.concatenate([mixed, np.repeat(limbs([1]), n, 0)], axis=1)
+    assert np.array_equal(got, coracle.verify(pk_proj[:8], msgs[:8], sig_proj[:8]).tolist() + got[8:].tolist())
+    assert engine.bls_verify(pk_xy, msgs[::-1], sig_xy).sum() <= 1                 # only a palindromic position could match
+    assert engine.bls_verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy).tolist() == [0] * n
+    # infinity signature / key: pairing() maps them to the identity (pairing.rs:876-886) -> both sides must be 1 to pass
+    inf = np.ones(n, dtype=np.uint8)
+    assert engine.bls_verify(pk_xy, msgs, sig_xy, sig_inf=inf).tolist() == [0] * n
+    assert engine.bls_verify(pk_xy, msgs, sig_xy, pk_inf=inf, sig_inf=inf).tolist() == [1] * n
+
+
+def test_verify_batch_planted_pattern_large(engine):
+    """2^12 tuples, 1/64 corrupted at PRNG-chosen indices: flags must equal the planted pattern, and
+    the device-side AND (flags_all) must see it."""
+    n = 1 << 12
+    g = np.random.default_rng(77)
+    msgs = [g.integers(0, 256, size=32, dtype=np.uint8).tobytes() for _ in range(n)]
+    sk = g.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sk[:, 3] &= np.uint64((1 << 60) - 1)
+    sig_xy, _ = engine.bls_sign(sk, msgs)
+    pk_xy, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    plant = g.random(n) < 1 / 64
+    bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
+    mixed = np.where(plant[:, None], bad_sig, sig_xy)
+    ok = engine.bls_verify(pk_xy, msgs, mixed)
+    assert np.array_equal(ok.astype(bool), ~plant)
+    d_ok = engine.to_device(ok)
+    assert engine.flags_all(d_ok) == 0
+    assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1

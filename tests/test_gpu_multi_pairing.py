@@ -1,0 +1,113 @@
+"""GPU parity: k-pair multi-Miller product with one final exponentiation (glued_pairing,
+pairing.rs:970-1037; the ecPairing shape of examples/reth_bn128.rs:156-217) vs the oracle."""
+import numpy as np
+import pytest
+
+from helpers import P, SEED, Xoshiro, ints, limbs, pack
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+G1 = [1, 2]
+G2 = list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1])
+ONE4 = np.array([[1, 0, 0, 0]], dtype=np.uint64)
+
+
+def proj1(xy, inf=None):
+    z = np.repeat(ONE4, xy.shape[0], 0)
+    if inf is not None:
+        z = z * (1 - np.asarray(inf, dtype=np.uint64))[:, None]
+    return np.concatenate([xy, z], axis=1)
+
+
+def proj2(xy, inf=None):
+    n = xy.shape[0]
+    z = np.concatenate([np.repeat(ONE4, n, 0), np.zeros((n, 4), dtype=np.uint64)], axis=1)
+    if inf is not None:
+        z = z * (1 - np.asarray(inf, dtype=np.uint64))[:, None]
+    return np.concatenate([xy, z], axis=1)
+
+
+def test_eip197_vector(engine, kats):
+    v = {e["line"]: bytes.fromhex(e["hex"]) for e in kats["eip_vectors_raw"]["hex_literals"]}
+    inp = v[389]
+    p, q = [], []
+    for i in range(0, len(inp), 192):
+        c = inp[i:i + 192]
+        ax, ay = int.from_bytes(c[0:32], "big"), int.from_bytes(c[32:64], "big")
+        bay, bax, bby, bbx = [int.from_bytes(c[64 + 32 * j:96 + 32 * j], "big") for j in range(4)]
+        p += [ax, ay]
+        q += [bax, bay, bbx, bby]
+    p, q = pack(p, 8), pack(q, 16)
+    assert engine.g2_subgroup_check(q).tolist() == [0, 0]
+    gt, is_one = engine.multi_pairing(p, q, [0, 2])
+    assert is_one.tolist() == [1]                                     # reth_bn128.rs:406 expects 1
+    one = np.zeros((1, 48), dtype=np.uint64); one[0, 0] = 1
+    assert np.array_equal(gt, one)
+    # empty job -> identity (pairing.rs:1218-1219; reth_bn128.rs:445-457 "no input" -> true)
+    gt, is_one = engine.multi_pairing(p, q, [0, 0, 2, 2])
+    assert is_one.tolist() == [1, 1, 1]
+
+
+def test_random_jobs_vs_oracle(engine, coracle):
+    rng = Xoshiro(SEED + 40)
+    ks = [1, 2, 3, 4, 5, 6, 9, 2, 4, 1]                                # crosses the KMAX = 4 chunk boundary
+    n = sum(ks)
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.uint64)
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    gt, is_one = engine.multi_pairing(p, q, off)
+    exp = coracle.glued_pairing(proj1(p), proj2(q), off)
+    assert np.array_equal(gt, exp) and not is_one.any()
+    # product == product of single pairings (pairing.rs:1239-1241)
+    single = engine.pairing(p, q)
+    acc = single[0:1]
+    assert np.array_equal(gt[0:1], acc)
+    acc = engine.fp12_mul(single[1:2], single[2:3])
+    assert np.array_equal(gt[1:2], acc)
+
+
+def test_products_equal_to_one(engine):
+    """jobs built so that sum a_ij * b_ij = 0 mod r multiply to one (BLS / Groth16 shapes, k = 2 and 4)."""
+    rng = Xoshiro(SEED + 41)
+    r = R.R_ORDER
+    jobs, a_all, b_all = [], [], []
+    for k in (2, 4, 2, 4, 2, 4, 3, 5):
+        a = [rng.fp() % r for _ in range(k)]
+        b = [rng.fp() % r for _ in range(k - 1)]
+        s = sum(x * y for x, y in zip(a, b)) % r
+        b.append((-s) * pow(a[-1], -1, r) % r)
+        if len(jobs) % 4 == 3:
+            b[-1] = (b[-1] + 1) % r                                    # spoil every 4th job
+        a_all += a; b_all += b; jobs.append(k)
+    n = len(a_all)
+    off = np.concatenate([[0], np.cumsum(jobs)]).astype(np.uint64)
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs(a_all))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs(b_all))
+    _, is_one = engine.multi_pairing(p, q, off, want_gt=False)
+    assert is_one.tolist() == [1, 1, 1, 0, 1, 1, 1, 0]
+
+
+def test_infinity_semantics(engine, coracle):
+    """replay mode reproduces the reference (P = inf neutral, Q = inf collapses the product
+    to Gt(0)); skip mode drops identity pairs as EIP-197 requires."""
+    rng = Xoshiro(SEED + 42)
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), 3, 0), limbs([rng.fp() for _ in range(3)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 3, 0), limbs([rng.fp() for _ in range(3)]))
+    base = engine.pairing(p[:1], q[:1])
+    # P = inf in pair 1 (canonical encoding (0,1))
+    p2 = p.copy(); p2[1] = pack([0, 1], 8)[0]
+    pinf = np.array([0, 1, 0], dtype=np.uint8)
+    gt, _ = engine.multi_pairing(p2[:2], q[:2], [0, 2], p_inf=pinf[:2])
+    assert np.array_equal(gt, base)
+    assert np.array_equal(gt, coracle.glued_pairing(proj1(p2[:2], pinf[:2]), proj2(q[:2]), [0, 2]))
+    # Q = inf in pair 1: reference defect -> all-zero "Gt"
+    q2 = q.copy(); q2[1] = pack([0, 0, 1, 0], 16)[0]
+    qinf = np.array([0, 1, 0], dtype=np.uint8)
+    gt, is_one = engine.multi_pairing(p[:2], q2[:2], [0, 2], q_inf=qinf[:2])
+    exp = coracle.glued_pairing(proj1(p[:2]), proj2(q2[:2], qinf[:2]), [0, 2])
+    assert np.array_equal(gt, exp) and not gt.any() and is_one.tolist() == [0]
+    # EIP-197 semantics: identity pairs are skipped
+    gt, _ = engine.multi_pairing(p[:2], q2[:2], [0, 2], q_inf=qinf[:2], skip_infinity=True)
+    assert np.array_equal(gt, base)
+    gt, is_one = engine.multi_pairing(p2[:2], q2[:2], [0, 2], p_inf=np.array([1, 1], dtype=np.uint8), q_inf=qinf[:2], skip_infinity=True)
+    assert is_one.tolist() == [1]
