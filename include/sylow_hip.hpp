@@ -1,0 +1,164 @@
+// sylow_hip.hpp -- header-only C++17 host layer over the C ABI (sylow_hip.h).
+//
+// The reference is a compiled (Rust) library and no Rust toolchain exists in the build image, so
+// this is the host side "in the reference's shape" that CAN be compiled here: the same item names
+// and argument meaning as sylow's public API for the hot path (src/lib.rs:71-84,179-236;
+// src/pairing.rs:870-893,1029-1037), batch-first.  A Rust shim binding the same C entry points
+// is listed in INTEGRATION.md.  Host containers are array-of-structs (what a Rust
+// Vec<G1Affine> would convert to); the device-side transposition to struct-of-arrays is done by
+// sylow_hip_aos_to_soa / _soa_to_aos, so no host loop touches the limbs.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sylow_hip.h"
+
+namespace sylow {
+
+struct Fp { uint64_t w[4]; };                       // canonical value, little-endian limbs (Fp::value().to_words())
+struct Fp2 { Fp c0, c1; };
+struct Fp12 { Fp c[12]; };
+struct G1Affine { Fp x, y; };                       // 8 words; infinity flags travel separately
+struct G2Affine { Fp2 x, y; };                      // 16 words
+struct Gt { Fp12 v; };
+inline bool operator==(const Gt& a, const Gt& b) {
+  for (int i = 0; i < 12; ++i) for (int k = 0; k < 4; ++k) if (a.v.c[i].w[k] != b.v.c[i].w[k]) return false;
+  return true;
+}
+enum class GroupError { NotOnCurve = 1, NotInSubgroup = 2, CannotHashToGroup = 3, DecodeError = 4 };   // groups/group.rs:38-47
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check(int32_t rc, const char* what) {
+  if (rc != SYLOW_HIP_OK) throw Error(std::string(what) + ": " + sylow_hip_last_error());
+}
+
+class DeviceBuffer {                                 // RAII hipMalloc'ed bytes
+ public:
+  explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { check(sylow_hip_malloc(&p_, bytes), "sylow_hip_malloc"); }
+  ~DeviceBuffer() { if (p_) sylow_hip_free(p_); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; }
+  template <class T> T* as() const { return static_cast<T*>(p_); }
+  size_t bytes() const { return bytes_; }
+ private:
+  void* p_ = nullptr;
+  size_t bytes_;
+};
+
+// host AoS vector of W-word structs -> device SoA [W][n]
+template <class T>
+DeviceBuffer to_device_soa(const std::vector<T>& v, void* stream = nullptr) {
+  constexpr size_t W = sizeof(T) / 8;
+  const size_t n = v.size();
+  DeviceBuffer aos(n * sizeof(T) + 8), soa(n * sizeof(T) + 8);
+  if (n) {
+    check(sylow_hip_memcpy_h2d(aos.as<void>(), v.data(), n * sizeof(T), stream), "h2d");
+    check(sylow_hip_aos_to_soa(aos.as<uint64_t>(), soa.as<uint64_t>(), W, n, stream), "aos_to_soa");
+    check(sylow_hip_stream_sync(stream), "sync");
+  }
+  return soa;
+}
+template <class T>
+std::vector<T> from_device_soa(const DeviceBuffer& soa, size_t n, void* stream = nullptr) {
+  constexpr size_t W = sizeof(T) / 8;
+  std::vector<T> out(n);
+  if (n) {
+    DeviceBuffer aos(n * sizeof(T));
+    check(sylow_hip_soa_to_aos(soa.as<uint64_t>(), aos.as<uint64_t>(), W, n, stream), "soa_to_aos");
+    check(sylow_hip_memcpy_d2h(out.data(), aos.as<void>(), n * sizeof(T), stream), "d2h");
+    check(sylow_hip_stream_sync(stream), "sync");
+  }
+  return out;
+}
+inline DeviceBuffer to_device_bytes(const std::vector<uint8_t>& v) {
+  DeviceBuffer d(v.size() + 8);
+  if (!v.empty()) { check(sylow_hip_memcpy_h2d(d.as<void>(), v.data(), v.size(), nullptr), "h2d"); check(sylow_hip_stream_sync(nullptr), "sync"); }
+  return d;
+}
+
+inline G1Affine g1_generator() { return G1Affine{Fp{{1, 0, 0, 0}}, Fp{{2, 0, 0, 0}}}; }                 // g1.rs:54-60
+inline G2Affine g2_generator() {                                                                       // g2.rs:47-77
+  return G2Affine{Fp2{Fp{{0x46DEBD5CD992F6EDull, 0x674322D4F75EDADDull, 0x426A00665E5C4479ull, 0x1800DEEF121F1E76ull}},
+                      Fp{{0x97E485B7AEF312C2ull, 0xF1AA493335A9E712ull, 0x7260BFB731FB5D25ull, 0x198E9393920D483Aull}}},
+                  Fp2{Fp{{0x4CE6CC0166FA7DAAull, 0xE3D1E7690C43D37Bull, 0x4AAB71808DCB408Full, 0x12C85EA5DB8C6DEBull}},
+                      Fp{{0x55ACDADCD122975Bull, 0xBC4B313370B38EF3ull, 0xEC9E99AD690C3395ull, 0x090689D0585FF075ull}}}};
+}
+
+// pairing(&G1Projective, &G2Projective) -> Gt (pairing.rs:870-893), elementwise over the batch
+inline std::vector<Gt> pairing(const std::vector<G1Affine>& p, const std::vector<G2Affine>& q,
+                               const std::vector<uint8_t>* p_inf = nullptr, const std::vector<uint8_t>* q_inf = nullptr) {
+  if (p.size() != q.size()) throw Error("pairing: length mismatch");
+  const size_t n = p.size();
+  auto dp = to_device_soa(p); auto dq = to_device_soa(q);
+  DeviceBuffer dgt(n * sizeof(Gt) + 8);
+  DeviceBuffer dpi = to_device_bytes(p_inf ? *p_inf : std::vector<uint8_t>()), dqi = to_device_bytes(q_inf ? *q_inf : std::vector<uint8_t>());
+  check(sylow_hip_pairing_batch(dp.as<uint64_t>(), p_inf ? dpi.as<uint8_t>() : nullptr, dq.as<uint64_t>(), q_inf ? dqi.as<uint8_t>() : nullptr,
+                                dgt.as<uint64_t>(), n, nullptr), "sylow_hip_pairing_batch");
+  return from_device_soa<Gt>(dgt, n);
+}
+// glued_pairing(&[G1Projective], &[G2Projective]) -> Gt (pairing.rs:1029-1037): ONE product
+inline Gt glued_pairing(const std::vector<G1Affine>& g1s, const std::vector<G2Affine>& g2s) {
+  const size_t k = g1s.size() < g2s.size() ? g1s.size() : g2s.size();        // zip truncates (pairing.rs:975)
+  std::vector<G1Affine> a(g1s.begin(), g1s.begin() + k);
+  std::vector<G2Affine> b(g2s.begin(), g2s.begin() + k);
+  auto dp = to_device_soa(a); auto dq = to_device_soa(b);
+  uint64_t off[2] = {0, k};
+  DeviceBuffer doff(16), dgt(sizeof(Gt));
+  check(sylow_hip_memcpy_h2d(doff.as<void>(), off, 16, nullptr), "h2d");
+  check(sylow_hip_multi_pairing_batch(dp.as<uint64_t>(), nullptr, dq.as<uint64_t>(), nullptr, doff.as<uint64_t>(), 1, k, 0,
+                                      dgt.as<uint64_t>(), nullptr, nullptr), "sylow_hip_multi_pairing_batch");
+  return from_device_soa<Gt>(dgt, 1)[0];
+}
+// Mul<&Fp> for G1 / G2 (group.rs:639-667), elementwise
+inline std::vector<G1Affine> mul(const std::vector<G1Affine>& p, const std::vector<Fp>& k, std::vector<uint8_t>* inf_out = nullptr) {
+  const size_t n = p.size();
+  auto dp = to_device_soa(p); auto dk = to_device_soa(k);
+  DeviceBuffer dout(n * sizeof(G1Affine) + 8), dinf(n + 8);
+  check(sylow_hip_g1_scalar_mul_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g1_scalar_mul");
+  if (inf_out) { inf_out->resize(n); check(sylow_hip_memcpy_d2h(inf_out->data(), dinf.as<void>(), n, nullptr), "d2h"); }
+  return from_device_soa<G1Affine>(dout, n);
+}
+inline std::vector<G2Affine> mul(const std::vector<G2Affine>& p, const std::vector<Fp>& k) {
+  const size_t n = p.size();
+  auto dp = to_device_soa(p); auto dk = to_device_soa(k);
+  DeviceBuffer dout(n * sizeof(G2Affine) + 8), dinf(n + 8);
+  check(sylow_hip_g2_scalar_mul_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
+  return from_device_soa<G2Affine>(dout, n);
+}
+struct Messages {                                    // concatenated bytes + offsets on the device
+  DeviceBuffer bytes, offsets; size_t n;
+  explicit Messages(const std::vector<std::vector<uint8_t>>& msgs) : bytes(total(msgs) + 8), offsets((msgs.size() + 1) * 8), n(msgs.size()) {
+    std::vector<uint8_t> blob; std::vector<uint64_t> off(1, 0);
+    for (auto& m : msgs) { blob.insert(blob.end(), m.begin(), m.end()); off.push_back(blob.size()); }
+    if (!blob.empty()) check(sylow_hip_memcpy_h2d(bytes.as<void>(), blob.data(), blob.size(), nullptr), "h2d");
+    check(sylow_hip_memcpy_h2d(offsets.as<void>(), off.data(), off.size() * 8, nullptr), "h2d");
+    check(sylow_hip_stream_sync(nullptr), "sync");
+  }
+  static size_t total(const std::vector<std::vector<uint8_t>>& msgs) { size_t t = 0; for (auto& m : msgs) t += m.size(); return t; }
+};
+// sign(&Fp, &[u8]) -> Result<G1Projective, GroupError> (lib.rs:179-187), elementwise
+inline std::vector<G1Affine> sign(const std::vector<Fp>& k, const std::vector<std::vector<uint8_t>>& msgs) {
+  if (k.size() != msgs.size()) throw Error("sign: length mismatch");
+  Messages m(msgs);
+  auto dk = to_device_soa(k);
+  DeviceBuffer dsig(m.n * sizeof(G1Affine) + 8), dinf(m.n + 8);
+  check(sylow_hip_bls_sign_batch(dk.as<uint64_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), dinf.as<uint8_t>(), m.n, nullptr), "sylow_hip_bls_sign_batch");
+  return from_device_soa<G1Affine>(dsig, m.n);
+}
+// verify(&G2Projective, &[u8], &G1Projective) -> Result<bool, GroupError> (lib.rs:223-236), elementwise
+inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig) {
+  if (pubkey.size() != msgs.size() || sig.size() != msgs.size()) throw Error("verify: length mismatch");
+  Messages m(msgs);
+  auto dpk = to_device_soa(pubkey); auto dsig = to_device_soa(sig);
+  DeviceBuffer dok(m.n + 8);
+  check(sylow_hip_bls_verify_batch(dpk.as<uint64_t>(), nullptr, m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), nullptr, dok.as<uint8_t>(), m.n, nullptr), "sylow_hip_bls_verify_batch");
+  std::vector<uint8_t> ok(m.n);
+  if (m.n) { check(sylow_hip_memcpy_d2h(ok.data(), dok.as<void>(), m.n, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync"); }
+  return ok;
+}
+
+}  // namespace sylow

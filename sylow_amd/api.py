@@ -1,0 +1,190 @@
+"""Host-side mirror of sylow's public items for the hot path, batch-first.
+
+Names and argument meaning follow src/lib.rs:71-84,105-236 (`pairing`, `glued_pairing`, `sign`,
+`verify`, `G1Affine`/`G1Projective`, `G2Affine`/`G2Projective`, `Gt`, `Fp`), so tests written against
+the reference read the same here -- except that every object is a BATCH of n values and every call
+runs on the GPU through the C ABI.  Error behaviour mirrors `GroupError` (groups/group.rs:38-47):
+constructors that validate raise `GroupError` with the reference's variant names.
+
+Fp batches are numpy uint64 [n, 4] (little-endian limbs of the canonical value, `Fp::value().to_words()`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import Engine
+
+P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+_M64 = (1 << 64) - 1
+_G2 = (0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
+       0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2,
+       0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA,
+       0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B)
+DST = b"WARLOCK-CHAOS-V01-CS01-SHA-256"   # src/lib.rs:90
+
+_engine: Engine | None = None
+
+
+def engine() -> Engine:
+    global _engine
+    if _engine is None:
+        _engine = Engine(0)
+    return _engine
+
+
+def set_engine(e: Engine) -> None:
+    global _engine
+    _engine = e
+
+
+class GroupError(Exception):
+    """groups/group.rs:38-47"""
+    NOT_ON_CURVE, NOT_IN_SUBGROUP, CANNOT_HASH_TO_GROUP, DECODE_ERROR = "NotOnCurve", "NotInSubgroup", "CannotHashToGroup", "DecodeError"
+
+
+def fp(values) -> np.ndarray:
+    """Fp::new on a list of Python ints (any 256-bit value; reduced on the device like the reference)."""
+    vals = [int(v) for v in np.atleast_1d(np.asarray(values, dtype=object))]
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for k in range(4):
+            out[i, k] = (v >> (64 * k)) & _M64
+    return out
+
+
+def _row(vals):
+    return np.array([[(v >> (64 * k)) & _M64 for v in vals for k in range(4)]], dtype=np.uint64)
+
+
+class _Points:
+    WIDTH = 0
+
+    def __init__(self, xy: np.ndarray, infinity: np.ndarray | None = None):
+        self.xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, self.WIDTH)
+        n = self.xy.shape[0]
+        self.infinity = np.zeros(n, dtype=np.uint8) if infinity is None else np.ascontiguousarray(infinity, dtype=np.uint8).reshape(n)
+
+    def __len__(self):
+        return self.xy.shape[0]
+
+    def __eq__(self, other):                       # GroupAffine ct_eq (group.rs:226-235), elementwise
+        both_inf = (self.infinity & other.infinity).astype(bool)
+        same = (~self.infinity.astype(bool)) & (~other.infinity.astype(bool)) & (self.xy == other.xy).all(axis=1)
+        return both_inf | same
+
+    def is_zero(self):
+        return self.infinity.astype(bool)
+
+
+class G1Affine(_Points):
+    """Batch of G1 points in affine form (g1.rs:30); identity = (0, 1, infinity)."""
+    WIDTH = 8
+
+    @classmethod
+    def generator(cls, n=1):                       # g1.rs:54-60
+        return cls(np.repeat(_row([1, 2]), n, 0))
+
+    @classmethod
+    def zero(cls, n=1):
+        return cls(np.repeat(_row([0, 1]), n, 0), np.ones(n, dtype=np.uint8))
+
+    @classmethod
+    def hash_to_curve(cls, msgs, dst: bytes = DST):     # g1.rs:307-331 with XMDExpander<Keccak256>(dst, 128)
+        xy, inf = engine().hash_to_g1(list(msgs), dst)
+        return cls(xy, inf)
+
+    def __mul__(self, k):                          # Mul<&Fp> (group.rs:639-667)
+        xy, inf = engine().g1_scalar_mul(self.xy, k, self.infinity)
+        return G1Affine(xy, inf)
+
+    def __add__(self, other):                      # Add (group.rs:528-599)
+        xy, inf = engine().g1_add(self.xy, other.xy, self.infinity, other.infinity)
+        return G1Affine(xy, inf)
+
+    def __neg__(self):
+        y = engine().fp_neg(self.xy[:, 4:])
+        return G1Affine(np.concatenate([self.xy[:, :4], y], axis=1), self.infinity)
+
+
+G1Projective = G1Affine   # results are compared after normalisation: one batch type serves both names
+
+
+class G2Affine(_Points):
+    WIDTH = 16
+
+    @classmethod
+    def generator(cls, n=1):                       # g2.rs:47-77
+        return cls(np.repeat(_row(_G2), n, 0))
+
+    @classmethod
+    def zero(cls, n=1):
+        return cls(np.repeat(_row([0, 0, 1, 0]), n, 0), np.ones(n, dtype=np.uint8))
+
+    @classmethod
+    def new(cls, xy):                              # G2Projective::new (g2.rs:460-525): on-curve + subgroup
+        pts = cls(xy)
+        st = engine().g2_subgroup_check(pts.xy, pts.infinity)
+        if (st == 1).any():
+            raise GroupError(GroupError.NOT_ON_CURVE)
+        if (st == 2).any():
+            raise GroupError(GroupError.NOT_IN_SUBGROUP)
+        return pts
+
+    def __mul__(self, k):
+        xy, inf = engine().g2_scalar_mul(self.xy, k, self.infinity)
+        return G2Affine(xy, inf)
+
+    def __neg__(self):
+        y = np.concatenate([engine().fp_neg(self.xy[:, 8:12]), engine().fp_neg(self.xy[:, 12:16])], axis=1)
+        return G2Affine(np.concatenate([self.xy[:, :8], y], axis=1), self.infinity)
+
+
+G2Projective = G2Affine
+
+
+class Gt:
+    """Batch of target-group elements (groups/gt.rs): 12 Fp each; `+` is the group law (Fp12 product)."""
+
+    def __init__(self, v: np.ndarray):
+        self.v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 48)
+
+    @classmethod
+    def identity(cls, n=1):                        # gt.rs:263-265
+        v = np.zeros((n, 48), dtype=np.uint64)
+        v[:, 0] = 1
+        return cls(v)
+
+    def __len__(self):
+        return self.v.shape[0]
+
+    def __eq__(self, other):                       # gt.rs:139-159
+        return (self.v == other.v).all(axis=1)
+
+    def __add__(self, other):                      # gt.rs: Add = Fp12 multiplication
+        return Gt(engine().fp12_mul(self.v, other.v))
+
+
+def pairing(p: G1Affine, q: G2Affine) -> Gt:
+    """pairing(&G1Projective, &G2Projective) -> Gt (pairing.rs:870-893), n independent values."""
+    return Gt(engine().pairing(p.xy, q.xy, p.infinity, q.infinity))
+
+
+def glued_pairing(g1s: G1Affine, g2s: G2Affine, offsets=None, evm_infinity: bool = False) -> Gt:
+    """glued_pairing(&[G1Projective], &[G2Projective]) -> Gt (pairing.rs:1029-1037).  Without `offsets` the
+    whole batch is ONE product (the reference's shape); with offsets, job j multiplies pairs
+    [offsets[j], offsets[j+1])."""
+    if offsets is None:
+        offsets = [0, len(g1s)]
+    gt, _ = engine().multi_pairing(g1s.xy, g2s.xy, offsets, g1s.infinity, g2s.infinity, skip_infinity=evm_infinity)
+    return Gt(gt)
+
+
+def sign(k, msgs) -> G1Affine:
+    """sign(&Fp, &[u8]) (lib.rs:179-187): H(msg) * k."""
+    xy, inf = engine().bls_sign(k, list(msgs))
+    return G1Affine(xy, inf)
+
+
+def verify(pubkey: G2Affine, msgs, sig: G1Affine) -> np.ndarray:
+    """verify(&G2Projective, &[u8], &G1Projective) (lib.rs:223-236): elementwise bool."""
+    return engine().bls_verify(pubkey.xy, list(msgs), sig.xy, pubkey.infinity, sig.infinity).astype(bool)

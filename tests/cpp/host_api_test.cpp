@@ -1,0 +1,43 @@
+// C++ host-layer test (include/sylow_hip.hpp): the shapes of the reference's own tests
+// (pairing.rs:1052-1072, lib.rs:29-42) on small batches.  Prints results for the pytest wrapper
+// (tests/test_gpu_cpp_host.py), which compares them with the golden fixtures and the oracle.
+#include <cstdio>
+#include <cstdlib>
+
+#include "sylow_hip.hpp"
+
+using namespace sylow;
+
+static void print_fp(const Fp& a) { std::printf("%016lx%016lx%016lx%016lx", (unsigned long)a.w[3], (unsigned long)a.w[2], (unsigned long)a.w[1], (unsigned long)a.w[0]); }
+
+int main() {
+  try {
+    check(sylow_hip_init(0), "sylow_hip_init");
+    // test_gt_generator: e(G1gen, G2gen)
+    auto gt = pairing({g1_generator()}, {g2_generator()});
+    std::printf("GT");
+    for (int i = 0; i < 12; ++i) { std::printf(" "); print_fp(gt[0].v.c[i]); }
+    std::printf("\n");
+    // test_signatures / lib.rs doc-test on 4 keys
+    std::vector<Fp> sk = {Fp{{5, 0, 0, 0}}, Fp{{0x1234567890abcdefull, 7, 0, 0}}, Fp{{1, 2, 3, 4}}, Fp{{0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull, 0x1fffffffffffffffull}}};
+    std::vector<std::vector<uint8_t>> msgs(4, std::vector<uint8_t>{0, 0, 0, 20});
+    auto sig = sign(sk, msgs);
+    auto pk = mul(std::vector<G2Affine>(4, g2_generator()), sk);
+    auto ok = verify(pk, msgs, sig);
+    msgs[2] = {1, 2, 3};
+    auto bad = verify(pk, msgs, sig);
+    std::printf("VERIFY %d%d%d%d %d%d%d%d\n", ok[0], ok[1], ok[2], ok[3], bad[0], bad[1], bad[2], bad[3]);
+    std::printf("SIG0 "); print_fp(sig[0].x); std::printf(" "); print_fp(sig[0].y); std::printf("\n");
+    // bilinearity through the glued product: e(5 G1, G2) * e(-G1... ) shape: e(aG1, G2) == e(G1, aG2)
+    auto lhs = pairing(mul(std::vector<G1Affine>(1, g1_generator()), {sk[0]}), {g2_generator()});
+    auto rhs = pairing({g1_generator()}, {pk[0]});
+    std::printf("BILINEAR %d\n", lhs[0] == rhs[0] ? 1 : 0);
+    Gt prod = glued_pairing({g1_generator(), g1_generator()}, {g2_generator(), g2_generator()});
+    auto sq = pairing({G1Affine{Fp{{1, 0, 0, 0}}, Fp{{2, 0, 0, 0}}}}, {mul(std::vector<G2Affine>(1, g2_generator()), {Fp{{2, 0, 0, 0}}})[0]});
+    std::printf("GLUED %d\n", prod == sq[0] ? 1 : 0);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "FAILED: %s\n", e.what());
+    return 1;
+  }
+}

@@ -1,0 +1,76 @@
+"""The reference's own pairing / signature tests (src/pairing.rs:1038-1251, src/lib.rs:29-42), replayed
+on batches through the host-side mirror of sylow's API (sylow_amd/api.py)."""
+import numpy as np
+import pytest
+
+from helpers import SEED, Xoshiro
+
+pytestmark = pytest.mark.gpu
+MSG = (20).to_bytes(4, "big")          # `20_i32.to_be_bytes()`, pairing.rs:1046 / benches/sig.rs:7
+
+
+@pytest.fixture(scope="module")
+def api(engine):
+    from sylow_amd import api
+    api.set_engine(engine)
+    return api
+
+
+def test_gt_generator(api, kats):
+    """pairing.rs:1052-1057"""
+    gt = api.pairing(api.G1Projective.generator(), api.G2Projective.generator())
+    assert [sum(int(gt.v[0, 4 * i + k]) << (64 * k) for k in range(4)) for i in range(12)] == [int(x, 16) for x in kats["gt_generator"]["value"]]
+
+
+def test_signatures(api):
+    """pairing.rs:1059-1072 on a batch of 64 keys"""
+    rng = Xoshiro(SEED + 50)
+    n = 64
+    private_key = api.fp([rng.fp() for _ in range(n)])
+    hashed_message = api.G1Projective.hash_to_curve([MSG] * n)
+    signature = hashed_message * private_key
+    public_key = api.G2Projective.generator(n) * private_key
+    lhs = api.pairing(signature, api.G2Projective.generator(n))
+    rhs = api.pairing(hashed_message, public_key)
+    assert (lhs == rhs).all()
+    # lib.rs:29-42 doc-test: sign / verify
+    sig = api.sign(private_key, [MSG] * n)
+    assert (sig == signature).all()
+    assert api.verify(public_key, [MSG] * n, sig).all()
+    assert not api.verify(public_key, [b"Hello, World!"] * n, sig).any()
+
+
+def test_identities(api):
+    """pairing.rs:1101-1120"""
+    g1z, g2 = api.G1Projective.zero(), api.G2Projective.generator()
+    assert (api.pairing(g1z, g2) == api.Gt.identity()).all()
+    assert (api.pairing(api.G1Projective.generator(), api.G2Projective.zero()) == api.Gt.identity()).all()
+    g, h = api.G1Projective.generator(), api.G2Projective.generator()
+    q = api.pairing(g, -h)
+    r = api.pairing(-g, h)
+    assert (q == r).all()
+    assert ((q + api.pairing(g, h)) == api.Gt.identity()).all()      # p = -pairing(g, h)
+
+
+def test_batches(api):
+    """pairing.rs:1216-1242: glued_pairing(&[], &[]) == identity; e(sP, Q) products == e(P, sQ) products"""
+    rng = Xoshiro(SEED + 51)
+    empty = api.glued_pairing(api.G1Projective(np.zeros((0, 8), np.uint64)), api.G2Projective(np.zeros((0, 16), np.uint64)))
+    assert (empty == api.Gt.identity()).all()
+    RANGE = 50
+    p = api.G1Projective.generator(RANGE) * api.fp([rng.fp() for _ in range(RANGE)])
+    q = api.G2Projective.generator(RANGE) * api.fp([rng.fp() for _ in range(RANGE)])
+    s = api.fp([rng.fp() for _ in range(RANGE)])
+    b_batch = api.glued_pairing(p * s, q)
+    c_batch = api.glued_pairing(p, q * s)
+    assert (b_batch == c_batch).all() and not (b_batch == api.Gt.identity()).any()
+
+
+def test_group_errors(api):
+    """G2Projective::new error variants (g2.rs:460-525; groups/mod.rs invalid-subgroup fixtures)"""
+    good = api.G2Projective.generator(2)
+    assert len(api.G2Affine.new(good.xy)) == 2
+    bad = good.xy.copy()
+    bad[0, 8] ^= np.uint64(1)
+    with pytest.raises(api.GroupError, match="NotOnCurve"):
+        api.G2Affine.new(bad)
