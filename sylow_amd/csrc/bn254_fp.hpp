@@ -98,6 +98,37 @@ BN_DEV Fp fp_cond_sub_p(const u32 r[8], u32 top) {
   return out;
 }
 
+// t >= c ? t - c : t for a 256-bit constant c given as limbs (c = p, 2p or 4p)
+BN_DEV void cond_sub_const(u32 (&r)[8], u32 c0, u32 c1, u32 c2, u32 c3, u32 c4, u32 c5, u32 c6, u32 c7) {
+  u32 s[8];
+  u32 bor;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "v_cndmask_b32 %8, 0, -1, vcc"
+      : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]),
+        "=&v"(bor)
+      : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(c0), "v"(c1),
+        "v"(c2), "v"(c3), "v"(c4), "v"(c5), "v"(c6), "v"(c7)
+      : "vcc");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (bor != 0) ? r[i] : s[i];
+}
+// any 256-bit value -> canonical residue, like Fp::new (fp.rs:199-201) but without a Montgomery round
+// trip: 2^256 < 6p, so conditional subtractions of 4p, 2p, p suffice (4p = 0xc19139cb... < 2^256)
+BN_DEV Fp fp_reduce_plain(const Fp& x) {
+  u32 r[8] = {x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7]};
+  cond_sub_const(r, 0x61f3f51cu, 0xf082305bu, 0xa1c72a34u, 0x5e05aa45u, 0x06056176u, 0xe14116dau, 0x84c680a6u, 0xc19139cbu);  // 4p
+  cond_sub_const(r, 0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u, 0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2p
+  cond_sub_const(r, BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
+  return fp_from_limbs(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+}
+
 // Montgomery product a*b/R mod p, inputs and output canonical (fp.rs:387-393).
 // Out-of-line leaf: 8 + 8 argument registers is exactly what the AMDGPU C ABI passes in VGPRs
 // (16), the result comes back in 8, and the body touches ~50 VGPRs, so callers keep ~200

@@ -138,39 +138,56 @@ BN_DEV Naf compute_naf(const u32 k[8]) {
   for (int i = 0; i < 8; ++i) { u32 cc = xh[i] ^ x3[i]; n.np[i] = x3[i] & cc; n.nm[i] = xh[i] & cc; }
   return n;
 }
-BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
-  Naf n = compute_naf(k);
-  G1P res = proj_zero<OpsFp>();
-  G1P neg = proj_neg<OpsFp>(p);
+// k*P for the batch kernels: signed fixed-window (w = 4) double-and-add with a WAVE-UNIFORM schedule.
+// The reference walks the 256 NAF digits of k with a data-dependent add (group.rs:653-664); on a
+// 64-wide wavefront that makes every step pay for an addition (some lane always has a non-zero
+// digit).  Here every lane does 4 doublings + one complete addition of +-T[|d|] per window
+// (T[0] = identity: the RCB formulas are complete, so adding it is exact), 64 windows, table of
+// 1P..8P in the lane's scratch frame.  k*P as a group element is the same; only affine-normalised
+// results cross the boundary.  k is the Fp VALUE (< p, not reduced mod r: N4).
+template <class O, class DBL, class ADD>
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add) {
+  typedef Proj<typename O::F> Pt;
+  // signed recoding: k = sum d_i 16^i, d_i in [-8, 7]; k < 2^254 so the top digit cannot overflow
+  signed char dig[64];
+  int carry = 0;
 #pragma unroll 1
-  for (int i = 255; i >= 0; --i) {
-    res = g1_double(res);
-    u32 bp = (n.np[i >> 5] >> (i & 31)) & 1, bm = (n.nm[i >> 5] >> (i & 31)) & 1;
-    if (bp | bm) {
-      G1P q;
-      q.x = p.x; q.z = p.z;
-      q.y = fp_select(p.y, neg.y, bm != 0);
-      res = g1_add(res, q);
+  for (int i = 0; i < 64; ++i) {
+    int d = (int)((k[i >> 3] >> (4 * (i & 7))) & 15) + carry;
+    carry = d >= 8;
+    dig[i] = (signed char)(d - (carry << 4));
+  }
+  Pt T[9];
+  T[0] = proj_zero<O>();
+  T[1] = p;
+  T[2] = dbl(p);
+  T[3] = add(T[2], p);
+  T[4] = dbl(T[2]);
+  T[5] = add(T[4], p);
+  T[6] = dbl(T[3]);
+  T[7] = add(T[6], p);
+  T[8] = dbl(T[4]);
+  Pt res = proj_zero<O>();
+#pragma unroll 1
+  for (int i = 63; i >= 0; --i) {
+    if (i != 63) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) res = dbl(res);
     }
+    int d = dig[i];
+    int m = d < 0 ? -d : d;
+    Pt q = T[m];
+    q.y = O::select(q.y, O::neg(q.y), d < 0);
+    res = add(res, q);
   }
   return res;
 }
+BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
+  return scalar_mul_window<OpsFp>(p, k, [](const G1P& a) { return g1_double(a); }, [](const G1P& a, const G1P& b) { return g1_add(a, b); });
+}
 BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
-  Naf n = compute_naf(k);
-  G2P res = proj_zero<OpsFp2>();
-  Fp2 negy = fp2_neg(p.y);
-#pragma unroll 1
-  for (int i = 255; i >= 0; --i) {
-    g2_double(res, res);
-    u32 bp = (n.np[i >> 5] >> (i & 31)) & 1, bm = (n.nm[i >> 5] >> (i & 31)) & 1;
-    if (bp | bm) {
-      G2P q;
-      q.x = p.x; q.z = p.z;
-      q.y = fp2_select(p.y, negy, bm != 0);
-      g2_add(res, res, q);
-    }
-  }
-  out = res;
+  out = scalar_mul_window<OpsFp2>(p, k, [](const G2P& a) { G2P r; g2_double(r, a); return r; },
+                                  [](const G2P& a, const G2P& b) { G2P r; g2_add(r, a, b); return r; });
 }
 
 // group.rs:475-495: affine = (X/Z, Y/Z); infinity iff Z^-1 == 0 -> (0, 1, inf)

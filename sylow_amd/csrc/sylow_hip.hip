@@ -50,38 +50,66 @@ constexpr int BLOCK = 256;
 // ------------------------------------------------------------------ Fp kernels ----------------
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
 
-// a*b for canonical inputs without a round trip through Montgomery form for the second operand:
-// mont(mont(a, R^2), b) = a*b.  Two Montgomery products per element; the kernel is HBM-bound
-// (96 B per element) as long as those stay under the memory time.
+// HBM-bound kernels (96 B per element): each lane handles TWO adjacent elements so that every limb
+// plane is read / written with one 16-byte access per lane (1 KiB per wavefront instruction).
+// a*b for canonical inputs: mont(mont(a, R^2), b) = a*b, two Montgomery products per element.
+// add / sub / neg: inputs are reduced like Fp::new by conditional subtraction (no multiplications).
+BN_DEV void load_plain2(Fp& e0, Fp& e1, const u64* __restrict__ base, size_t n, size_t i) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(base + (size_t)k * n + i);
+    e0.v[2 * k] = (u32)w.x; e0.v[2 * k + 1] = (u32)(w.x >> 32);
+    e1.v[2 * k] = (u32)w.y; e1.v[2 * k + 1] = (u32)(w.y >> 32);
+  }
+}
+BN_DEV void store_plain2(u64* __restrict__ base, size_t n, size_t i, const Fp& e0, const Fp& e1) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ulonglong2 w;
+    w.x = (u64)e0.v[2 * k] | ((u64)e0.v[2 * k + 1] << 32);
+    w.y = (u64)e1.v[2 * k] | ((u64)e1.v[2 * k + 1] << 32);
+    *reinterpret_cast<ulonglong2*>(base + (size_t)k * n + i) = w;
+  }
+}
+template <int OP>
+BN_DEV Fp fp_binop_one(const Fp& x, const Fp& y) {
+  if (OP == OP_MUL) return fp_mul_inline(fp_mul_inline(x, fp_r2()), y);
+  Fp xr = fp_reduce_plain(x), yr = fp_reduce_plain(y);
+  return (OP == OP_ADD) ? fp_add(xr, yr) : fp_sub(xr, yr);
+}
 template <int OP>
 __global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, size_t n) {
-  size_t i = TID;
+  size_t i = 2 * TID;
   if (i >= n) return;
-  Fp x = load_plain(a, n, i, 0), y = load_plain(b, n, i, 0), r;
-  if (OP == OP_MUL) {
-    r = fp_mul_inline(fp_mul_inline(x, fp_r2()), y);
+  const bool vec = ((n & 1) == 0);          // planes stay 16-byte aligned only for even n
+  if (vec) {
+    Fp x0, x1, y0, y1;
+    load_plain2(x0, x1, a, n, i);
+    load_plain2(y0, y1, b, n, i);
+    store_plain2(out, n, i, fp_binop_one<OP>(x0, y0), fp_binop_one<OP>(x1, y1));
   } else {
-    // reduce arbitrary 256-bit inputs like Fp::new, then add/sub on canonical values (no Montgomery needed)
-    x = fp_from_mont(fp_to_mont(x));
-    y = fp_from_mont(fp_to_mont(y));
-    r = (OP == OP_ADD) ? fp_add(x, y) : fp_sub(x, y);
+    for (size_t j = i; j < n && j < i + 2; ++j)
+      store_plain(out, n, j, 0, fp_binop_one<OP>(load_plain(a, n, j, 0), load_plain(b, n, j, 0)));
   }
-  store_plain(out, n, i, 0, r);
+}
+template <int OP>
+BN_DEV Fp fp_unop_one(const Fp& x) {
+  if (OP == OP_SQR) { Fp xm = fp_mul_inline(x, fp_r2()); return fp_from_mont(fp_mul_inline(xm, xm)); }
+  if (OP == OP_NEG) return fp_neg(fp_reduce_plain(x));
+  return fp_from_mont(fp_inv(fp_to_mont(x)));
 }
 template <int OP>
 __global__ void __launch_bounds__(BLOCK) k_fp_unop(const u64* __restrict__ a, u64* __restrict__ out, size_t n) {
-  size_t i = TID;
+  size_t i = 2 * TID;
   if (i >= n) return;
-  Fp x = load_plain(a, n, i, 0), r;
-  if (OP == OP_SQR) {
-    Fp xm = fp_to_mont(x);
-    r = fp_from_mont(fp_mul(xm, xm));
-  } else if (OP == OP_NEG) {
-    r = fp_neg(fp_from_mont(fp_to_mont(x)));
+  const bool vec = ((n & 1) == 0);
+  if (vec) {
+    Fp x0, x1;
+    load_plain2(x0, x1, a, n, i);
+    store_plain2(out, n, i, fp_unop_one<OP>(x0), fp_unop_one<OP>(x1));
   } else {
-    r = fp_from_mont(fp_inv(fp_to_mont(x)));
+    for (size_t j = i; j < n && j < i + 2; ++j) store_plain(out, n, j, 0, fp_unop_one<OP>(load_plain(a, n, j, 0)));
   }
-  store_plain(out, n, i, 0, r);
 }
 
 // ------------------------------------------------------------------ tower test hooks ----------
@@ -498,13 +526,13 @@ int32_t sylow_hip_soa_to_aos(const uint64_t* soa, uint64_t* aos, size_t words, s
 #define FP_BIN(name, OP)                                                                                         \
   int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) { \
     ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;                                                           \
-    k_fp_binop<OP><<<GRID(n)>>>(a, b, out, n); LAUNCHED();                                                        \
+    k_fp_binop<OP><<<GRID((n + 1) / 2)>>>(a, b, out, n); LAUNCHED();                                                        \
   }
 FP_BIN(add, OP_ADD) FP_BIN(sub, OP_SUB) FP_BIN(mul, OP_MUL)
 #define FP_UN(name, OP)                                                                                  \
   int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {           \
     ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;                                                        \
-    k_fp_unop<OP><<<GRID(n)>>>(a, out, n); LAUNCHED();                                                    \
+    k_fp_unop<OP><<<GRID((n + 1) / 2)>>>(a, out, n); LAUNCHED();                                                    \
   }
 FP_UN(sqr, OP_SQR) FP_UN(neg, OP_NEG) FP_UN(inv, OP_INV)
 
