@@ -30,8 +30,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ISSUE_PEAK_GINSTR = 580.0             # measured VOP3 wave-instr/s ceiling, profiles/r01_issue_rate_ubench.txt
 PAIRING_BYTES = 576                   # 64 (G1 affine) + 128 (G2 affine) + 384 (Gt)  -- SURVEY.md §8(d)
 VERIFY_BYTES = 225                    # pk 128 + sig 64 + 32-byte msg + flag
-# VALU wave-instructions per wave (64 pairings) of k_pairing, from SQ_INSTS_VALU (profiles/): filled by PMC run
-PAIRING_VALU_INSTR_PER_WAVE = float(os.environ.get("SYLOW_PAIRING_VALU_PER_WAVE", "0") or 0)
+# rocprofv3 PMC facts about k_pairing (profiles/r01_pairing_v2/pmc_k_pairing.json, n = 2^20 = 16384 waves);
+# bench.py cannot collect PMC counters itself, so the per-launch constants measured there are reused here
+# and scale with n.  Refresh them with tools/prof_pairing.sh whenever the kernel changes.
+PAIRING_VALU_INSTR_PER_WAVE = 1.33572673536e11 / 16384          # SQ_INSTS_VALU per wavefront (64 pairings)
+PAIRING_HBM_BYTES_PER_WAVE = (2 * 263583935.0 + 412824846.1875) * 1024 / 16384   # 2*FETCH_SIZE + WRITE_SIZE (KiB), gfx950 correction
 
 G1 = [1, 2]
 G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
@@ -174,7 +177,7 @@ def main():
     # ---- untimed aux leg: batched BLS verify + aggregate AND over ranks (RCCL MIN) ----------------
     aux = {}
     if not args.no_aux:
-        nv = min(n, 1 << 16)
+        nv = min(n, 1 << 18)
         rng = np.random.default_rng(7 + rank)
         msgs_np = rng.integers(0, 256, size=(nv, 32), dtype=np.uint8)
         off = (np.arange(nv + 1, dtype=np.uint64) * np.uint64(32))
@@ -196,8 +199,20 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # AND over ranks, 4 bytes over xGMI
         fence()
         dtv = time.perf_counter() - tv
+        eng._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)  # warm (+ builds the G2gen line table)
+        fence()
+        tf = time.perf_counter()
+        eng._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
+        flag2 = torch.ones(1, dtype=torch.int32, device="cuda")
+        eng._call("sylow_hip_flags_all", ok.ptr, nv, flag2.data_ptr())
+        if dist is not None:
+            dist.all_reduce(flag2, op=dist.ReduceOp.MIN)
+        fence()
+        dtf = time.perf_counter() - tf
         aux = {"bls_verifies_per_s": world * nv / dtv, "bls_verify_batch_per_gpu": nv,
-               "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9}
+               "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
+               "bls_verifies_per_s_fused": world * nv / dtf, "bls_all_valid_fused": int(flag2.item()),
+               "note": "verify = lib.rs:223-236 as written (hash + two full pairings); fused = e(sig,G2gen)*e(-H,pk)==1, one final exponentiation"}
 
     if rank == 0:
         total = world * n * args.steps
@@ -212,13 +227,17 @@ def main():
                                    "(BASELINE.json configs[2] shape at the metric's batch=2^20), affine SoA inputs resident in HBM",
                        "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": PAIRING_HBM_BYTES_PER_WAVE * (n / 64),
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pairing_v2): "
+                                         "per-lane scratch frames of Fp12 temporaries, not algorithmic re-reads",
                          "kernel": "k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
         }
         if PAIRING_VALU_INSTR_PER_WAVE:
             ginstr = PAIRING_VALU_INSTR_PER_WAVE * (n / 64) / (kern_ms * 1e-3) / 1e9
             out["issue_roofline"] = {"bound": "valu-issue", "achieved": ginstr, "peak": ISSUE_PEAK_GINSTR,
-                                     "unit": "G wave-instr/s", "frac": ginstr / ISSUE_PEAK_GINSTR}
+                                     "unit": "G wave-instr/s", "frac": ginstr / ISSUE_PEAK_GINSTR,
+                                     "note": "the roof that actually binds a pairing (integer carry chains): SQ_INSTS_VALU per launch / "
+                                             "kernel time vs the measured VOP3 issue ceiling (profiles/r01_issue_rate_ubench.txt)"}
         if aux:
             out["aux"] = aux
         if not args.no_cpu:

@@ -453,6 +453,100 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
   okout[i] = fp12_eq(lhs, rhs) ? 1 : 0;
 }
 
+
+// ------------------------------------------------------------------ fused BLS verify ------------
+// The batch-verify shape sylow's own examples recommend (examples/verify_multiple_messages_same_signer.rs:41-60,
+// threshold_signing.rs:92-121): e(sig, G2gen) * e(-H(msg), pk) == 1 with ONE shared-squaring Miller loop
+// and ONE final exponentiation.  Pairs with an identity contribute 1, exactly as pairing() treats them
+// (pairing.rs:876-886), so for points in G1 x G2 the boolean equals verify()'s (lib.rs:223-236).
+// The G2 generator is fixed, so its 87 line-coefficient triples (pairing.rs:676-708) are computed once
+// per device into g_g2gen_lines and read with wave-uniform (scalar) loads.
+__device__ u32 g_g2gen_lines[87 * 48];
+__global__ void k_g2gen_lines() {
+  if (TID != 0) return;
+  const Fp2 qx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, qy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
+  G2P r{qx, qy, fp2_one()};
+  const Fp2 nqy = fp2_neg(qy);
+  Fp2 l0, l1, l2;
+  int idx = 0;
+  auto put = [&](int at) {
+    const Fp* src[6] = {&l0.c0, &l0.c1, &l1.c0, &l1.c1, &l2.c0, &l2.c1};
+    for (int c = 0; c < 6; ++c) for (int j = 0; j < 8; ++j) g_g2gen_lines[at * 48 + c * 8 + j] = src[c]->v[j];
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step(r, l0, l1, l2); put(idx++);
+    if ((nz >> (63 - i)) & 1) { g2_addition_step(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(idx++); }
+  }
+  Fp2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qx, qy);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  g2_addition_step(r, q1x, q1y, l0, l1, l2); put(idx++);
+  g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2); put(idx++);
+}
+BN_DEV Fp2 table_fp2(int at, int c) {
+  const u32* t = g_g2gen_lines + at * 48 + c * 16;
+  return Fp2{fp_from_limbs(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]), fp_from_limbs(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15])};
+}
+__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                                const u64* sigxy, const uint8_t* siginf, uint8_t* okout, size_t n) {
+  size_t i = TID;
+  const bool active = i < n;
+  const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
+  G1P h;
+  hash_to_g1(h, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
+  Fp hx, hy; bool hinf;
+  g1_to_affine(hx, hy, hinf, h);
+  hy = fp_neg(hy);                            // pair B is (-H, pk)
+  const bool liveA = !(siginf && siginf[ii]);
+  const bool liveB = !(hinf || (pkinf && pkinf[ii]));
+  const Fp sx = load_fp(sigxy, n, ii, 0), sy = load_fp(sigxy, n, ii, 4);
+  const Fp2 gx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, gy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
+  // a dead pair B steps the generator instead (any curve point keeps the arithmetic defined) and multiplies by the unit line
+  const Fp2 qx = fp2_select(gx, load_fp2(pkxy, n, ii, 0), liveB), qy = fp2_select(gy, load_fp2(pkxy, n, ii, 8), liveB);
+  const Fp2 nqy = fp2_neg(qy);
+  G2P r{qx, qy, fp2_one()};
+  Fp12 f;
+  fp12_set_one(f);
+  Fp2 l0, l1, l2;
+  const Fp2 u0 = fp2_one(), u1 = fp2_zero();
+  auto lineA = [&](int at) {
+    Fp2 a0 = table_fp2(at, 0), a1 = fp2_scale(table_fp2(at, 1), sy), a2 = fp2_scale(table_fp2(at, 2), sx);
+    fp12_sparse_mul(f, fp2_select(u0, a0, liveA), fp2_select(u1, a1, liveA), fp2_select(u1, a2, liveA));
+  };
+  auto lineB = [&]() {
+    fp12_sparse_mul(f, fp2_select(u0, l0, liveB), fp2_select(u1, fp2_scale(l1, hy), liveB), fp2_select(u1, fp2_scale(l2, hx), liveB));
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+  int idx = 0;
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    fp12_sqr(f, f);
+    lineA(idx++);
+    g2_doubling_step(r, l0, l1, l2);
+    lineB();
+    if ((nz >> (63 - it)) & 1) {
+      lineA(idx++);
+      g2_addition_step(r, qx, ((ng >> (63 - it)) & 1) ? nqy : qy, l0, l1, l2);
+      lineB();
+    }
+  }
+  Fp2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qx, qy);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  lineA(idx++);
+  g2_addition_step(r, q1x, q1y, l0, l1, l2);
+  lineB();
+  lineA(idx++);
+  g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2);
+  lineB();
+  Fp12 g, one;
+  final_exponentiation(g, f);
+  fp12_set_one(one);
+  if (active) okout[i] = fp12_eq(g, one) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ layout helpers --------------
 __global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
   size_t t = TID;
@@ -637,6 +731,29 @@ int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf,
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; dst_arg(dp, nullptr, 0);
   k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+}
+
+// one-time (per device) construction of the G2-generator line table used by the fused verifier
+static int32_t ensure_g2gen_lines(void* stream) {
+  static bool ready[64] = {false};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { snprintf(g_err, sizeof(g_err), "device index out of range"); return SYLOW_HIP_E_ARG; }
+  if (!ready[dev]) {
+    k_g2gen_lines<<<1, 64, 0, (hipStream_t)stream>>>();
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return fail(e_, "k_g2gen_lines launch");
+    ready[dev] = true;
+  }
+  return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  int32_t rc = ensure_g2gen_lines(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  DstPrime dp; dst_arg(dp, nullptr, 0);
+  k_bls_verify_fused<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));

@@ -1,0 +1,110 @@
+"""BASELINE.json's full sizes through size-independent properties (bit-exact integer work):
+C2a 2^20 Fp mul vs the oracle; C2b 2^20 G1 scalar-mul distributivity; C3 2^18 pairings bilinearity;
+C4 2^20 BLS verifies with a planted corruption pattern; C5 2^16 ecPairing jobs (k = 2 and 4)."""
+import numpy as np
+import pytest
+
+from helpers import P, fast_rand_fp_array, limbs, pack
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+G1 = [1, 2]
+G2 = list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1])
+R_ORDER = R.R_ORDER
+
+
+def test_c2a_fp_mul_2_20_vs_oracle(engine, coracle):
+    n = 1 << 20
+    a, b = fast_rand_fp_array(101, n, 1), fast_rand_fp_array(102, n, 1)
+    got = engine.fp_mul(a, b)
+    assert np.array_equal(got, coracle.fp_op("mul", a, b))
+    assert np.array_equal(engine.fp_add(a, b), coracle.fp_op("add", a, b))
+    assert np.array_equal(engine.fp_sub(a, b), coracle.fp_op("sub", a, b))
+    # odd batch size exercises the non-vector path
+    assert np.array_equal(engine.fp_mul(a[:12345], b[:12345]), got[:12345])
+
+
+def test_c2b_g1_scalar_mul_2_20(engine, coracle):
+    n = 1 << 20
+    g = np.repeat(pack(G1, 8), n, 0)
+    a, b = fast_rand_fp_array(103, n, 1), fast_rand_fp_array(104, n, 1)
+    a[:, 3] >>= np.uint64(2); b[:, 3] >>= np.uint64(2)
+    ap, ainf = engine.g1_scalar_mul(g, a)
+    bp, _ = engine.g1_scalar_mul(g, b)
+    sp, _ = engine.g1_scalar_mul(g, engine.fp_add(a, b))
+    sum_xy, sum_inf = engine.g1_add(ap, bp)
+    assert np.array_equal(sum_xy, sp) and not sum_inf.any() and not ainf.any()
+    # a sample against the oracle (affine)
+    idx = np.random.default_rng(1).choice(n, 512, replace=False)
+    one = np.zeros((512, 4), dtype=np.uint64); one[:, 0] = 1
+    exp, _ = coracle.g1_to_affine(coracle.g1_scalar_mul(np.concatenate([g[idx], one], axis=1), a[idx]))
+    assert np.array_equal(ap[idx], exp)
+
+
+def test_c3_pairings_2_18_bilinearity(engine, coracle):
+    n = 1 << 18
+    g1, g2 = np.repeat(pack(G1, 8), n, 0), np.repeat(pack(G2, 16), n, 0)
+    a, b = fast_rand_fp_array(105, n, 1), fast_rand_fp_array(106, n, 1)
+    pa, _ = engine.g1_scalar_mul(g1, a)
+    qb, _ = engine.g2_scalar_mul(g2, b)
+    lhs = engine.pairing(pa, qb)                                       # e(aP, bQ)
+    # e(aP, bQ) == e(bP', aQ')... use the swap: e(aG1, bG2) == e(bG1, aG2)
+    pb, _ = engine.g1_scalar_mul(g1, b)
+    qa, _ = engine.g2_scalar_mul(g2, a)
+    assert np.array_equal(lhs, engine.pairing(pb, qa))
+    # sample >= 4096 indices against the oracle
+    idx = np.random.default_rng(2).choice(n, 4096, replace=False)
+    one = np.zeros((4096, 4), dtype=np.uint64); one[:, 0] = 1
+    p_proj = np.concatenate([pa[idx], one], axis=1)
+    q_proj = np.concatenate([qb[idx], one, np.zeros((4096, 4), dtype=np.uint64)], axis=1)
+    assert np.array_equal(lhs[idx], coracle.pairing(p_proj, q_proj))
+
+
+def test_c4_bls_verify_2_20_planted(engine):
+    n = 1 << 20
+    g = np.random.default_rng(107)
+    blob = g.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(32)
+    dm, doff = engine.to_device(blob.reshape(-1)), engine.to_device(off)
+    sk_aos = fast_rand_fp_array(108, n, 1)
+    sk = engine.to_device_soa(sk_aos, 4)
+    g2 = engine.to_device_soa(np.repeat(pack(G2, 16), n, 0), 16)
+    pk, pki = engine.empty((16, n)), engine.empty((n,), np.uint8)
+    sig, sigi = engine.empty((8, n)), engine.empty((n,), np.uint8)
+    engine._call("sylow_hip_g2_scalar_mul_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr, n)
+    engine._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, n)
+    # corrupt 1/1024 of the signatures: sig + G1gen at PRNG-chosen indices
+    plant = g.random(n) < 1 / 1024
+    sig_aos = engine.from_device_soa(sig)
+    bad, _ = engine.g1_add(sig_aos[plant], np.repeat(pack(G1, 8), int(plant.sum()), 0))
+    sig_aos[plant] = bad
+    sig2 = engine.to_device_soa(sig_aos, 8)
+    ok = engine.empty((n,), np.uint8)
+    engine._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig2.ptr, None, ok.ptr, n)
+    flags = ok.download().astype(bool)
+    assert np.array_equal(flags, ~plant)
+    assert engine.flags_all(ok) == 0
+    engine._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig2.ptr, None, ok.ptr, n)
+    assert np.array_equal(ok.download().astype(bool), ~plant)
+    engine._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, n)
+    assert engine.flags_all(ok) == 1
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_c5_ecpairing_2_16_jobs(engine, k):
+    nj = 1 << 16
+    n = nj * k
+    g = np.random.default_rng(109 + k)
+    a = [int(x) for x in g.integers(1, 1 << 62, size=n)]
+    b = [int(x) for x in g.integers(1, 1 << 62, size=n)]
+    # make each job multiply to one: last b chosen so that sum a_i b_i = 0 mod r; spoil every 5th job
+    for j in range(nj):
+        s = sum(a[j * k + i] * b[j * k + i] for i in range(k - 1)) % R_ORDER
+        b[j * k + k - 1] = (-s) * pow(a[j * k + k - 1], -1, R_ORDER) % R_ORDER
+        if j % 5 == 4:
+            b[j * k + k - 1] = (b[j * k + k - 1] + 1) % R_ORDER
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs(a))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs(b))
+    _, is_one = engine.multi_pairing(p, q, np.arange(nj + 1, dtype=np.uint64) * np.uint64(k), skip_infinity=True, want_gt=False)
+    expect = np.array([0 if j % 5 == 4 else 1 for j in range(nj)], dtype=np.uint8)
+    assert np.array_equal(is_one, expect)

@@ -79,3 +79,30 @@ def test_verify_batch_planted_pattern_large(engine):
     d_ok = engine.to_device(ok)
     assert engine.flags_all(d_ok) == 0
     assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1
+
+
+def test_fused_verify_equals_reference_shape(engine):
+    """sylow_hip_bls_verify_fused_batch: e(sig, G2gen) * e(-H, pk) == 1 (the shape of the reference's
+    examples) must give the same booleans as the two-pairing verify() on G1 x G2 inputs, incl. planted
+    corruption and identity inputs."""
+    rng = Xoshiro(SEED + 31)
+    msgs = messages() * 7                                    # 147 elements: spans three wavefronts with a ragged tail
+    n = len(msgs)
+    sk = limbs([rng.fp() for _ in range(n)])
+    sig_xy, _ = engine.bls_sign(sk, msgs)
+    pk_xy, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    assert engine.bls_verify(pk_xy, msgs, sig_xy, fused=True).tolist() == [1] * n
+    bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
+    plant = np.random.default_rng(9).random(n) < 0.2
+    mixed = np.where(plant[:, None], bad_sig, sig_xy)
+    got = engine.bls_verify(pk_xy, msgs, mixed, fused=True)
+    assert np.array_equal(got.astype(bool), ~plant)
+    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed))
+    assert engine.bls_verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy, fused=True).sum() == 0
+    # identity handling equals pairing()'s: random flags on both sides
+    g = np.random.default_rng(10)
+    pinf, sinf = (g.random(n) < 0.3).astype(np.uint8), (g.random(n) < 0.3).astype(np.uint8)
+    a = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf, fused=True)
+    b = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf)
+    assert np.array_equal(a, b)
+    assert a[(pinf & sinf).astype(bool)].all()               # both sides identity -> 1 == 1
