@@ -148,6 +148,20 @@ int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf,
  * points in G1 x G2 (subgroup-checked keys); ~1.5x faster. */
 int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                          const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* ---- EVM alt_bn128 precompile shapes: examples/reth_bn128.rs:99-217 (EIP-196 / EIP-197) --------- */
+/* Byte-level batches.  Field elements are 32-byte big-endian and must be < p (else DECODE_ERROR =
+ * Bn128FieldPointNotAMember); (0,0) is the identity; G1 points must be on the curve, G2 points on the twist
+ * and in the r-torsion (else NOT_ON_CURVE / NOT_IN_SUBGROUP = Bn128AffineGFailedToCreate).
+ * ecadd: in [n][128] = two points, out [n][64] (identity -> 64 zero bytes, to_be_bytes_scrubbed g1.rs:182-192).
+ * ecmul: in [n][96] = point | 32-byte scalar (any 256-bit value, reduced mod r), out [n][64].
+ * ecpairing: `in` = n_pairs 192-byte elements (G1 x|y, G2 x.c1|x.c0|y.c1|y.c0), job j owns elements
+ * [pair_offsets[j], pair_offsets[j+1]); result[j] = 1 iff the product of pairings is one (empty job -> 1).
+ * Identity pairs are skipped as EIP-197 requires (the reference adapter inherits glued_pairing's Q = identity
+ * defect and answers false there).  Padding, length % 192 and gas rules are host-side (sylow_amd/evm.py). */
+int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_evm_ecmul_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
+                                      uint8_t* result, uint8_t* status, void* stream);
 /* AND of a flag array -> one int32 on the device (1 = all set); the multi-GPU aggregate then
  * MIN-reduces that word over ranks (RCCL has no bit-AND; min over {0,1} is AND). */
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream);

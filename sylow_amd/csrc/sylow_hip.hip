@@ -547,6 +547,150 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   if (active) okout[i] = fp12_eq(g, one) ? 1 : 0;
 }
 
+
+// ------------------------------------------------------------------ EVM alt_bn128 adapter -------
+// Byte-level batches of the three precompile shapes of examples/reth_bn128.rs:99-217 (EIP-196/197):
+// 32-byte big-endian field elements (Fp::from_be_bytes rejects >= p, fp.rs:686-719), (0,0) encodes the
+// identity, G1 points must be on the curve (G1Affine::new, g1.rs:111-132), G2 points on the twist AND in
+// the r-torsion (G2Projective::new, g2.rs:460-525); G2 is encoded x.c1 | x.c0 | y.c1 | y.c0.
+// status: OK, DECODE_ERROR (= Bn128FieldPointNotAMember), NOT_ON_CURVE / NOT_IN_SUBGROUP (= Bn128AffineGFailedToCreate).
+BN_DEV bool read_be_fp(Fp& out, const uint8_t* b) {         // returns false when the value is >= p
+  Fp x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = b + 28 - 4 * j;
+    x.v[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  const u32 pl[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    if (!decided && x.v[j] != pl[j]) { lt = x.v[j] < pl[j]; decided = true; }
+  }
+  out = x;
+  return lt;
+}
+BN_DEV void write_be_fp(uint8_t* b, const Fp& plain) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32 w = plain.v[j];
+    uint8_t* q = b + 28 - 4 * j;
+    q[0] = (uint8_t)(w >> 24); q[1] = (uint8_t)(w >> 16); q[2] = (uint8_t)(w >> 8); q[3] = (uint8_t)w;
+  }
+}
+// read_point + new_g1_point (reth_bn128.rs:107-128): Montgomery-form affine point or identity
+BN_DEV uint8_t evm_read_g1(G1P& out, const uint8_t* b) {
+  Fp x, y;
+  bool okx = read_be_fp(x, b), oky = read_be_fp(y, b + 32);
+  if (!(okx && oky)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_DECODE_ERROR; }
+  if (fp_is_zero(x) && fp_is_zero(y)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_OK; }
+  Fp xm = fp_to_mont(x), ym = fp_to_mont(y);
+  out = G1P{xm, ym, fp_one()};
+  return g1_on_curve_affine(xm, ym) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
+// to_be_bytes_scrubbed (g1.rs:182-192): all-zero bytes for the identity
+BN_DEV void evm_write_g1(uint8_t* b, const G1P& p) {
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, p);
+  Fp zero = fp_zero();
+  write_be_fp(b, inf ? zero : fp_from_mont(x));
+  write_be_fp(b + 32, inf ? zero : fp_from_mont(y));
+}
+// subgroup test shared with k_g2_subgroup_check (g2.rs:488-513); q on the twist, affine
+BN_NOINLINE bool g2_in_subgroup(const Fp2& x, const Fp2& y) {
+  G2P q{x, y, fp2_one()};
+  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
+  G2P a;
+  g2_scalar_mul(a, q, bx);
+  auto psi = [](G2P& r, const G2P& p) {
+    r.x = fp2_mul(fp2_const(C_EPS_EXP0), fp2_conj(p.x));
+    r.y = fp2_mul(fp2_const(C_EPS_EXP1), fp2_conj(p.y));
+    r.z = fp2_conj(p.z);
+  };
+  G2P b, c, l, r;
+  psi(b, a);
+  g2_add(a, a, q);
+  psi(c, b);
+  g2_add(l, c, b);
+  g2_add(l, l, a);
+  psi(r, c);
+  g2_double(r, r);
+  G2P nl = proj_neg<OpsFp2>(l);
+  g2_add(r, r, nl);
+  return fp2_is_zero(r.z);
+}
+__global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a, b;
+  uint8_t sa = evm_read_g1(a, in + 128 * i), sb = evm_read_g1(b, in + 128 * i + 64);
+  uint8_t st = sa ? sa : sb;
+  status[i] = st;
+  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  evm_write_g1(out + 64 * i, g1_add(a, b));
+}
+__global__ void __launch_bounds__(BLOCK) k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a;
+  uint8_t st = evm_read_g1(a, in + 96 * i);
+  status[i] = st;
+  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  Fp kx;
+  read_be_fp(kx, in + 96 * i + 64);
+  // EIP-196 accepts any 256-bit scalar; G1 has prime order r, so reduce mod r (2^256 < 6r).  (The reference
+  // adapter unwraps Fr::from_be_bytes and would panic for k >= r, reth_bn128.rs:144.)
+  u32 k[8] = {kx.v[0], kx.v[1], kx.v[2], kx.v[3], kx.v[4], kx.v[5], kx.v[6], kx.v[7]};
+  cond_sub_const(k, 0xc0000004u, 0x0f87d64fu, 0xe6e5c245u, 0xa0cfa121u, 0x06056174u, 0xe14116dau, 0x84c680a6u, 0xc19139cbu);  // 4r
+  cond_sub_const(k, 0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2r
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);  // r
+  evm_write_g1(out + 64 * i, g1_scalar_mul(a, k));
+}
+// one lane per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes
+__global__ void HEAVY_BOUNDS k_evm_decode_pairs(const uint8_t* in, size_t n_pairs, u64* pxy, uint8_t* pinf, u64* qxy, uint8_t* qinf, uint8_t* pst) {
+  size_t i = TID;
+  if (i >= n_pairs) return;
+  const uint8_t* b = in + 192 * i;
+  Fp f[6];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ok = read_be_fp(f[k], b + 32 * k) && ok;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool ainf = true, binf = true;
+  if (!ok) {
+    st = SYLOW_HIP_ST_DECODE_ERROR;
+  } else {
+    ainf = fp_is_zero(f[0]) && fp_is_zero(f[1]);
+    if (!ainf && !g1_on_curve_affine(fp_to_mont(f[0]), fp_to_mont(f[1]))) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    binf = fp_is_zero(f[2]) && fp_is_zero(f[3]) && fp_is_zero(f[4]) && fp_is_zero(f[5]);
+    if (!st && !binf) {
+      Fp2 x{fp_to_mont(f[3]), fp_to_mont(f[2])}, y{fp_to_mont(f[5]), fp_to_mont(f[4])};   // (bax, bay), (bbx, bby)
+      if (!g2_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+      else if (!g2_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+    }
+  }
+  bool dead = st != SYLOW_HIP_ST_OK;
+  Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  // identities (and invalid pairs, whose job is rejected anyway) are stored in the canonical (0, 1) encoding
+  store_plain(pxy, n_pairs, i, 0, (ainf || dead) ? zero : f[0]);
+  store_plain(pxy, n_pairs, i, 4, (ainf || dead) ? one : f[1]);
+  store_plain(qxy, n_pairs, i, 0, (binf || dead) ? zero : f[3]);
+  store_plain(qxy, n_pairs, i, 4, (binf || dead) ? zero : f[2]);
+  store_plain(qxy, n_pairs, i, 8, (binf || dead) ? one : f[5]);
+  store_plain(qxy, n_pairs, i, 12, (binf || dead) ? zero : f[4]);
+  pinf[i] = (ainf || dead) ? 1 : 0;
+  qinf[i] = (binf || dead) ? 1 : 0;
+  pst[i] = st;
+}
+__global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst, const u64* offsets, size_t n_jobs, const uint8_t* is_one, uint8_t* result, uint8_t* status) {
+  size_t j = TID;
+  if (j >= n_jobs) return;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  for (u64 k = offsets[j]; k < offsets[j + 1]; ++k) if (!st && pst[k]) st = pst[k];     // first failing pair, like the `?` in run_pair
+  status[j] = st;
+  result[j] = st ? 0 : is_one[j];
+}
+
 // ------------------------------------------------------------------ layout helpers --------------
 __global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
   size_t t = TID;
@@ -754,6 +898,38 @@ int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* p
   if (rc != SYLOW_HIP_OK) return rc;
   DstPrime dp; dst_arg(dp, nullptr, 0);
   k_bls_verify_fused<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+}
+
+int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;
+  k_evm_ecadd<<<GRID(n)>>>(in, out, status, n); LAUNCHED();
+}
+int32_t sylow_hip_evm_ecmul_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;
+  k_evm_ecmul<<<GRID(n)>>>(in, out, status, n); LAUNCHED();
+}
+int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
+                                      uint8_t* result, uint8_t* status, void* stream) {
+  ARGCHK(pair_offsets && result && status && (in || !n_pairs)); if (!n_jobs) return SYLOW_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t np = n_pairs ? n_pairs : 1;
+  // stream-ordered workspace: decoded SoA points, flags, per-pair status, per-job product flag
+  uint8_t* ws = nullptr;
+  const size_t bytes = np * (8 + 16) * 8 + 3 * np + n_jobs + 64;
+  HIPCHK(hipMallocAsync((void**)&ws, bytes, st));
+  u64* pxy = (u64*)ws;
+  u64* qxy = pxy + 8 * np;
+  uint8_t* pinf = (uint8_t*)(qxy + 16 * np);
+  uint8_t* qinf = pinf + np;
+  uint8_t* pst = qinf + np;
+  uint8_t* isone = pst + np;
+  if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
+  k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
+  k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
+  hipError_t e_ = hipGetLastError();
+  HIPCHK(hipFreeAsync(ws, st));
+  if (e_ != hipSuccess) return fail(e_, "kernel launch");
+  return SYLOW_HIP_OK;
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));
