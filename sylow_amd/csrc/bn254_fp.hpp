@@ -184,6 +184,38 @@ BN_DEV Fp fp_add(const Fp& a, const Fp& b) {
   return fp_cond_sub_p(s, 0);  // a + b < 2p < 2^255: no carry out of the top limb
 }
 
+// a + b WITHOUT the conditional subtraction: for canonical a, b the sum is < 2p < 2^255.  Only used as a
+// direct operand of fp_mul: the Montgomery product of x < 2p and y < 2p is < 4p^2/R + p < 1.76p, which the
+// multiplier's own conditional subtraction brings into [0, p) -- same residue, 16 instructions saved.
+BN_DEV Fp fp_add_lazy(const Fp& a, const Fp& b) {
+  Fp s;
+  asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+      "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+      : "=&v"(s.v[0]), "=&v"(s.v[1]), "=&v"(s.v[2]), "=&v"(s.v[3]), "=&v"(s.v[4]), "=&v"(s.v[5]), "=&v"(s.v[6]), "=&v"(s.v[7])
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+        "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  return s;
+}
+// a / 2 mod p: (a + (a odd ? p : 0)) >> 1.  Halving commutes with the Montgomery factor, so this is exactly
+// a * TWO_INV (fp2.rs:18-23) at ~26 instructions instead of a full product.
+BN_DEV Fp fp_halve(const Fp& a) {
+  const u32 mask = 0u - (a.v[0] & 1u);
+  const u32 q[8] = {BN_P0 & mask, BN_P1 & mask, BN_P2 & mask, BN_P3 & mask, BN_P4 & mask, BN_P5 & mask, BN_P6 & mask, BN_P7 & mask};
+  Fp t = fp_add_lazy(a, fp_from_limbs(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]));   // < 2p < 2^255: no carry out
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r.v[i] = (t.v[i] >> 1) | (t.v[i + 1] << 31);
+  r.v[7] = t.v[7] >> 1;
+  return r;
+}
+
 // (a - b) mod p  (fp.rs:340-347)
 BN_DEV Fp fp_sub(const Fp& a, const Fp& b) {
   u32 d[8];

@@ -219,14 +219,13 @@ BN_DEV void g2_psi_affine(Fp2& xo, Fp2& yo, const Fp2& x, const Fp2& y) {
 // ---------------------------------------------------------------- Miller loop -----------------
 // pairing.rs:798-818: doubling step on the twist; returns the three non-zero line coefficients
 BN_NOINLINE void g2_doubling_step(G2P& r, Fp2& l0, Fp2& l1, Fp2& l2) {
-  const Fp two_inv = fp_const(C_TWO_INV[0]);
-  Fp2 a = fp2_scale(fp2_mul(r.x, r.y), two_inv);
+  Fp2 a = fp2_halve(fp2_mul(r.x, r.y));          // .scale(TWO_INV), pairing.rs:799
   Fp2 b = fp2_sqr(r.y);
   Fp2 c = fp2_sqr(r.z);
   Fp2 d = fp2_add(fp2_dbl(c), c);
   Fp2 e = fp2_mul(fp2_const(C_TWIST_B), d);
   Fp2 f = fp2_add(fp2_dbl(e), e);
-  Fp2 g = fp2_scale(fp2_add(b, f), two_inv);
+  Fp2 g = fp2_halve(fp2_add(b, f));              // .scale(TWO_INV), pairing.rs:805
   Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));
   Fp2 i = fp2_sub(e, b);
   Fp2 j = fp2_sqr(r.x);
@@ -314,16 +313,28 @@ BN_NOINLINE void cyclotomic_sqr(Fp12& r, const Fp12& f) {
   r.c0.c0 = z0; r.c0.c1 = z4; r.c0.c2 = z3;
   r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
 }
-// pairing.rs:366-392: f^x then conjugate.  The reference walks all 256 bits of the 63-bit x
-// starting from one; squaring one in the cyclotomic formulas gives exactly one, so starting at
-// the top set bit is the same value.
+// pairing.rs:366-392: f^x then conjugate.  The reference walks all 256 bits of the 63-bit x with
+// square-and-multiply from one (62 useful squarings + 27 products).  f lives in the cyclotomic subgroup
+// here (every caller passes a value that went through the easy part), where f^-1 is the conjugate, so
+// the same power f^x is reached with the width-3 signed-digit form of x (digits in {+-1, +-3}, 18
+// non-zero): 62 cyclotomic squarings + 17 products + f^3.  Same field element, bit for bit.
+#define BN_X_W3_NZ 0x4908924444891211ull   // bit i set iff digit i != 0        (x = sum d_i 2^i, top digit d_62 = +1)
+#define BN_X_W3_NEG 0x0108000400880210ull  // digit i negative
+#define BN_X_W3_THREE 0x0108804404880200ull  // |digit i| == 3
 BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
-  Fp12 res = f;
-  const u64 x = BN_BLS_X;
+  Fp12 f3, res, t;
+  cyclotomic_sqr(t, f);
+  fp12_mul(f3, t, f);
+  res = f;
+  const u64 nz = BN_X_W3_NZ, ng = BN_X_W3_NEG, th = BN_X_W3_THREE;
 #pragma unroll 1
   for (int i = 61; i >= 0; --i) {
     cyclotomic_sqr(res, res);
-    if ((x >> i) & 1) fp12_mul(res, res, f);
+    if ((nz >> i) & 1) {
+      const Fp12& m = ((th >> i) & 1) ? f3 : f;
+      if ((ng >> i) & 1) { fp12_conj(t, m); fp12_mul(res, res, t); }
+      else fp12_mul(res, res, m);
+    }
   }
   fp12_conj(r, res);
 }

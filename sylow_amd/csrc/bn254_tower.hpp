@@ -2,11 +2,10 @@
 // Batched replacement for sylow's src/fields/{extensions,fp2,fp6,fp12}.rs.  All values are exact
 // residues, so Karatsuba here vs. the reference's schoolbook forms is bit-identical.
 //
-// Code-size policy (the instruction cache is what a fully inlined pairing would destroy): the
-// Fp2 product and square are the out-of-line leaves (~1000 / ~700 instructions each); Fp6/Fp12
-// products, the sparse line multiplication and the cyclotomic square are out-of-line mid-level
-// routines taking references, so Fp12-sized values live in the per-lane scratch frame while
-// Fp2-sized values stay in VGPRs.
+// Code-size / register policy: the out-of-line leaf is fp_mul(Fp, Fp) (16 ABI argument registers,
+// ~50-VGPR footprint); the Fp2 layer is inlined; Fp6/Fp12 products, the sparse line multiplication and
+// the cyclotomic square are out-of-line mid-level routines taking references, so Fp12-sized values
+// live in the per-lane scratch frame while Fp2-sized values stay in VGPRs.
 #pragma once
 #include "bn254_constants.hpp"
 #include "bn254_fp.hpp"
@@ -38,18 +37,19 @@ BN_DEV Fp2 fp2_select(const Fp2& a, const Fp2& b, bool c) { return Fp2{fp_select
 BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
   Fp v0 = fp_mul(a.c0, b.c0);
   Fp v1 = fp_mul(a.c1, b.c1);
-  Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  Fp s = fp_mul(fp_add_lazy(a.c0, a.c1), fp_add_lazy(b.c0, b.c1));   // operands < 2p: see fp_add_lazy
   return Fp2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
 // fp2.rs:164-171: (a0+a1)(a0-a1), 2 a0 a1
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {
-  Fp s = fp_add(a.c0, a.c1);
+  Fp s = fp_add_lazy(a.c0, a.c1);                                     // < 2p, times d < p
   Fp d = fp_sub(a.c0, a.c1);
   Fp t = fp_mul(a.c0, a.c1);
   return Fp2{fp_mul(s, d), fp_dbl(t)};
 }
 // extensions.rs:86-94 with F = Fp
 BN_DEV Fp2 fp2_scale(const Fp2& a, const Fp& k) { return Fp2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
+BN_DEV Fp2 fp2_halve(const Fp2& a) { return Fp2{fp_halve(a.c0), fp_halve(a.c1)}; }   // == scale(TWO_INV)
 // x (9+u): (9a - b, a + 9b)  (fp2.rs:99-107); 9x = 8x + x by doublings
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {
   Fp a8 = fp_dbl(fp_dbl(fp_dbl(a.c0)));
