@@ -131,11 +131,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    # debugging aid for boxes with fewer GPUs than ranks: SYLOW_BENCH_BACKEND=gloo SYLOW_BENCH_SINGLE_DEVICE=1 runs every
+    # rank on cuda:0 with CPU-side collectives, exercising the same barrier / MAX / MIN logic as the RCCL path
+    backend = os.environ.get("SYLOW_BENCH_BACKEND", "nccl")
+    if os.environ.get("SYLOW_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -170,7 +179,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -196,6 +205,7 @@ def main():
         flag = torch.ones(1, dtype=torch.int32, device="cuda")
         eng._call("sylow_hip_flags_all", ok.ptr, nv, flag.data_ptr())
         if dist is not None:
+            flag = flag.to(coll_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # AND over ranks, 4 bytes over xGMI
         fence()
         dtv = time.perf_counter() - tv
@@ -206,6 +216,7 @@ def main():
         flag2 = torch.ones(1, dtype=torch.int32, device="cuda")
         eng._call("sylow_hip_flags_all", ok.ptr, nv, flag2.data_ptr())
         if dist is not None:
+            flag2 = flag2.to(coll_dev)
             dist.all_reduce(flag2, op=dist.ReduceOp.MIN)
         fence()
         dtf = time.perf_counter() - tf
