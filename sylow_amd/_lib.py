@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsylow_hip.so")
+LIB_PATH = os.environ.get("SYLOW_HIP_LIB") or os.path.join(_HERE, "libsylow_hip.so")   # override: A/B builds
 _lib = None
 
 c_u64p = ctypes.c_void_p

@@ -164,6 +164,57 @@ BN_DEV Fp fp_mul_inline(const Fp& a, const Fp& b) {
 }
 
 BN_NOINLINE Fp fp_mul(Fp a, Fp b) { return fp_mul_inline(a, b); }
+
+// (a*b + c*d) / R mod p in ONE column pass and ONE Montgomery reduction (lazy reduction at the Fp2 level):
+// for inputs <= p the sum is <= 2p^2 < p*R, so the reduced value is < 2p^2/R + p < 1.4p and a single
+// conditional subtraction is enough.  The 3-word column accumulator absorbs the extra products for free.
+BN_DEV Fp fp_dot2_inline(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+  const u32 p[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+  u32 m[8];
+  u32 r[8];
+  u64 acc = 0;
+  u32 ovf = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { mac(acc, ovf, a.v[i], b.v[k - i]); mac(acc, ovf, c.v[i], d.v[k - i]); }
+#pragma unroll
+    for (int i = 0; i < k; ++i) mac_s(acc, ovf, m[i], p[k - i]);
+    m[k] = (u32)acc * BN_PINV32;
+    mac_s(acc, ovf, m[k], p[0]);
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; ++k) {
+#pragma unroll
+    for (int i = k - 7; i < 8; ++i) { mac(acc, ovf, a.v[i], b.v[k - i]); mac(acc, ovf, c.v[i], d.v[k - i]); }
+#pragma unroll
+    for (int i = k - 7; i < 8; ++i) mac_s(acc, ovf, m[i], p[k - i]);
+    r[k - 8] = (u32)acc;
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+  return fp_cond_sub_p(r, (u32)acc);
+}
+// p - a for canonical a (in (0, p]; p itself stands for 0 and is fine as a fp_dot2 operand)
+BN_DEV Fp fp_neg_lazy(const Fp& a) {
+  Fp r;
+  const u32 p0 = BN_P0, p1 = BN_P1, p2 = BN_P2, p3 = BN_P3, p4 = BN_P4, p5 = BN_P5, p6 = BN_P6, p7 = BN_P7;
+  asm("v_sub_co_u32 %0, vcc, %8, %16\n\t"
+      "v_subb_co_u32 %1, vcc, %9, %17, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %15, %23, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7),
+        "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7])
+      : "vcc");
+  return r;
+}
 BN_DEV Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }  // fp.rs:620-622
 
 // (a + b) mod p  (fp.rs:304-310)

@@ -217,51 +217,64 @@ BN_DEV void g2_psi_affine(Fp2& xo, Fp2& yo, const Fp2& x, const Fp2& y) {
 }
 
 // ---------------------------------------------------------------- Miller loop -----------------
-// pairing.rs:798-818: doubling step on the twist; returns the three non-zero line coefficients
+// pairing.rs:798-818: doubling step on the twist; returns the three non-zero line coefficients.
+// Same values as the reference's a..j sequence, evaluated in an order that keeps at most five Fp2
+// temporaries live (everything below Fp6 is inlined, so live ranges decide the scratch traffic).
 BN_NOINLINE void g2_doubling_step(G2P& r, Fp2& l0, Fp2& l1, Fp2& l2) {
-  Fp2 a = fp2_halve(fp2_mul(r.x, r.y));          // .scale(TWO_INV), pairing.rs:799
-  Fp2 b = fp2_sqr(r.y);
-  Fp2 c = fp2_sqr(r.z);
-  Fp2 d = fp2_add(fp2_dbl(c), c);
-  Fp2 e = fp2_mul(fp2_const(C_TWIST_B), d);
-  Fp2 f = fp2_add(fp2_dbl(e), e);
-  Fp2 g = fp2_halve(fp2_add(b, f));              // .scale(TWO_INV), pairing.rs:805
-  Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));
-  Fp2 i = fp2_sub(e, b);
-  Fp2 j = fp2_sqr(r.x);
+  Fp2 a = fp2_halve(fp2_mul(r.x, r.y));          // a = (X*Y) * TWO_INV
+  {
+    Fp2 j = fp2_sqr(r.x);                        // j = X^2
+    l2 = fp2_add(fp2_dbl(j), j);                 // ell.2 = 3j
+  }
+  Fp2 b = fp2_sqr(r.y);                          // b = Y^2
+  Fp2 c = fp2_sqr(r.z);                          // c = Z^2
+  Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));   // h = (Y+Z)^2 - (b+c)
+  Fp2 e = fp2_mul(fp2_const(C_TWIST_B), fp2_add(fp2_dbl(c), c)); // e = b' * 3c
+  l1 = fp2_neg(h);                               // ell.1 = -h
+  r.z = fp2_mul(b, h);                           // Z3 = b*h
+  l0 = fp2_mul_xi(fp2_sub(e, b));                // ell.0 = xi * (e - b)
+  Fp2 f = fp2_add(fp2_dbl(e), e);                // f = 3e
+  r.x = fp2_mul(a, fp2_sub(b, f));               // X3 = a*(b - f)
+  Fp2 g = fp2_halve(fp2_add(b, f));              // g = (b+f) * TWO_INV
   Fp2 esq = fp2_sqr(e);
-  r.x = fp2_mul(a, fp2_sub(b, f));
-  r.y = fp2_sub(fp2_sqr(g), fp2_add(fp2_dbl(esq), esq));
-  r.z = fp2_mul(b, h);
-  l0 = fp2_mul_xi(i);
-  l1 = fp2_neg(h);
-  l2 = fp2_add(fp2_dbl(j), j);
+  r.y = fp2_sub(fp2_sqr(g), fp2_add(fp2_dbl(esq), esq));        // Y3 = g^2 - 3e^2
 }
-// pairing.rs:756-772: mixed addition step R += (bx, by)
+// pairing.rs:756-772: mixed addition step R += (bx, by), same values, short live ranges
 BN_NOINLINE void g2_addition_step(G2P& r, const Fp2& bx, const Fp2& by, Fp2& l0, Fp2& l1, Fp2& l2) {
   Fp2 d = fp2_sub(r.x, fp2_mul(r.z, bx));
   Fp2 e = fp2_sub(r.y, fp2_mul(r.z, by));
-  Fp2 f = fp2_sqr(d);
-  Fp2 g = fp2_sqr(e);
-  Fp2 h = fp2_mul(d, f);
-  Fp2 i = fp2_mul(r.x, f);
-  Fp2 j = fp2_sub(fp2_add(fp2_mul(r.z, g), h), fp2_dbl(i));
-  Fp2 ny = fp2_sub(fp2_mul(e, fp2_sub(i, j)), fp2_mul(h, r.y));
-  r.x = fp2_mul(d, j);
-  r.y = ny;
-  r.z = fp2_mul(r.z, h);
   l0 = fp2_mul_xi(fp2_sub(fp2_mul(e, bx), fp2_mul(d, by)));
   l1 = d;
   l2 = fp2_neg(e);
+  Fp2 h, i;
+  {
+    Fp2 f = fp2_sqr(d);
+    h = fp2_mul(d, f);
+    i = fp2_mul(r.x, f);
+  }
+  Fp2 j = fp2_sub(fp2_add(fp2_mul(r.z, fp2_sqr(e)), h), fp2_dbl(i));
+  r.z = fp2_mul(r.z, h);
+  r.x = fp2_mul(d, j);
+  r.y = fp2_sub(fp2_mul(e, fp2_sub(i, j)), fp2_mul(h, r.y));
 }
-// f <- f * line(P): sparse_mul(c0, c1 * P.y, c2 * P.x)  (pairing.rs:598)
-BN_DEV void line_mul(Fp12& f, const Fp2& l0, const Fp2& l1, const Fp2& l2, const Fp& px, const Fp& py) {
-  fp12_sparse_mul(f, l0, fp2_scale(l1, py), fp2_scale(l2, px));
-}
+// Two Fp12 accumulators used alternately: squaring and the sparse line product are both out-of-place,
+// so every step reads one buffer and writes the other (no copies, operands re-loadable).
+struct Acc12 {
+  Fp12 buf[2];
+  int cur;
+  BN_DEV Fp12& get() { return buf[cur]; }
+  BN_DEV void set_one() { cur = 0; fp12_set_one(buf[0]); }
+  BN_DEV void square() { fp12_sqr(buf[cur ^ 1], buf[cur]); cur ^= 1; }
+  // f <- f * (l0 + l_vw w^3... ) (fp12.rs:426-503)
+  BN_DEV void sparse(const Fp2& l0, const Fp2& lvw, const Fp2& lvv) { fp12_sparse_mul(buf[cur ^ 1], buf[cur], l0, lvw, lvv); cur ^= 1; }
+  // f <- f * line(P): sparse_mul(c0, c1 * P.y, c2 * P.x)  (pairing.rs:598)
+  BN_DEV void line(const Fp2& l0, const Fp2& l1, const Fp2& l2, const Fp& px, const Fp& py) { sparse(l0, fp2_scale(l1, py), fp2_scale(l2, px)); }
+};
 // pairing.rs:590-619 fused with :676-708 (coefficients produced and consumed on the fly).
 // P = (px, py), Q = (qx, qy) affine, neither at infinity (callers substitute, pairing.rs:876-878).
-BN_NOINLINE void miller_loop(Fp12& f, const Fp& px, const Fp& py, const Fp2& qx, const Fp2& qy) {
-  fp12_set_one(f);
+BN_NOINLINE void miller_loop(Fp12& fout, const Fp& px, const Fp& py, const Fp2& qx, const Fp2& qy) {
+  Acc12 f;
+  f.set_one();
   G2P r{qx, qy, fp2_one()};
   const Fp2 nqy = fp2_neg(qy);
   Fp2 l0, l1, l2;
@@ -269,12 +282,12 @@ BN_NOINLINE void miller_loop(Fp12& f, const Fp& px, const Fp& py, const Fp2& qx,
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
     g2_doubling_step(r, l0, l1, l2);
-    fp12_sqr(f, f);
-    line_mul(f, l0, l1, l2, px, py);
+    f.square();
+    f.line(l0, l1, l2, px, py);
     if ((nz >> (63 - i)) & 1) {
       bool neg = (ng >> (63 - i)) & 1;
       g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
-      line_mul(f, l0, l1, l2, px, py);
+      f.line(l0, l1, l2, px, py);
     }
   }
   // Q1 = psi(Q), Q2 = -psi(psi(Q))  (pairing.rs:701-706)
@@ -283,9 +296,10 @@ BN_NOINLINE void miller_loop(Fp12& f, const Fp& px, const Fp& py, const Fp2& qx,
   g2_psi_affine(q2x, q2y, q1x, q1y);
   q2y = fp2_neg(q2y);
   g2_addition_step(r, q1x, q1y, l0, l1, l2);
-  line_mul(f, l0, l1, l2, px, py);
+  f.line(l0, l1, l2, px, py);
   g2_addition_step(r, q2x, q2y, l0, l1, l2);
-  line_mul(f, l0, l1, l2, px, py);
+  f.line(l0, l1, l2, px, py);
+  fout = f.get();
 }
 
 // ---------------------------------------------------------------- final exponentiation --------

@@ -33,12 +33,14 @@ BN_DEV bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.
 BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BN_DEV Fp2 fp2_select(const Fp2& a, const Fp2& b, bool c) { return Fp2{fp_select(a.c0, b.c0, c), fp_select(a.c1, b.c1, c)}; }
 
-// fp2.rs:285-306 (value); Karatsuba: 3 Fp products
+// fp2.rs:285-306 (value): (a0 b0 - a1 b1, a0 b1 + a1 b0) with lazy reduction -- each coordinate is one fused
+// two-product column pass + one Montgomery reduction (fp_dot2_inline), -a1 entering as p - a1.
+// Out-of-line leaf: `a` travels in the 16 ABI argument registers, `b` by pointer (it usually already lives
+// in the caller's scratch frame: a coefficient of an Fp6/Fp12 operand or a constant).
 BN_DEV Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
-  Fp v0 = fp_mul(a.c0, b.c0);
-  Fp v1 = fp_mul(a.c1, b.c1);
-  Fp s = fp_mul(fp_add_lazy(a.c0, a.c1), fp_add_lazy(b.c0, b.c1));   // operands < 2p: see fp_add_lazy
-  return Fp2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+  Fp c0 = fp_dot2_inline(a.c0, b.c0, fp_neg_lazy(a.c1), b.c1);
+  Fp c1 = fp_dot2_inline(a.c0, b.c1, a.c1, b.c0);
+  return Fp2{c0, c1};
 }
 // fp2.rs:164-171: (a0+a1)(a0-a1), 2 a0 a1
 BN_DEV Fp2 fp2_sqr(const Fp2& a) {
@@ -180,38 +182,58 @@ BN_NOINLINE void fp12_frobenius(Fp12& r, const Fp12& a) {
   r.c1 = y1;
 }
 // fp12.rs:426-503: f * (ell_0 + ell_vv v^2... ) with the sparse operand in slots 0, 2, 4 of the
-// [z0..z5] = [c0.0,c0.1,c0.2,c1.0,c1.1,c1.2] view (x0 = ell_0, x2 = ell_vv, x4 = ell_vw): 13 Fp2 products
-BN_NOINLINE void fp12_sparse_mul(Fp12& f, const Fp2& ell_0, const Fp2& ell_vw, const Fp2& ell_vv) {
-  const Fp2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
+// [z0..z5] = [c0.0,c0.1,c0.2,c1.0,c1.1,c1.2] view (x0 = ell_0, x2 = ell_vv, x4 = ell_vw): the 13 Fp2
+// products of the reference's mul_by_024 sequence, re-ordered so that only the three line coefficients,
+// d0/d2/d4 and the running sum s1 stay live (7 Fp2 = 112 VGPRs) while the z_i are re-read from the
+// scratch copy of f when needed -- loads instead of spill stores.  OUT-OF-PLACE (o must not alias f):
+// callers ping-pong between two accumulators, so f stays read-only and its coefficients can be re-loaded.
+BN_DEV void sched_fence() { asm volatile("" ::: "memory"); }
+BN_NOINLINE void fp12_sparse_mul(Fp12& __restrict__ o, const Fp12& __restrict__ f, const Fp2& ell_0, const Fp2& ell_vw, const Fp2& ell_vv) {
   const Fp2 x0 = ell_0, x2 = ell_vv, x4 = ell_vw;
-  Fp2 d0 = fp2_mul(z0, x0);
-  Fp2 d2 = fp2_mul(z2, x2);
-  Fp2 d4 = fp2_mul(z4, x4);
-  Fp2 s1 = fp2_mul(z1, x2);
-  f.c0.c0 = fp2_add(fp2_mul_xi(fp2_add(s1, d4)), d0);
-  Fp2 t3 = fp2_mul(z5, x4);
-  s1 = fp2_add(s1, t3);
-  Fp2 t4 = fp2_mul_xi(fp2_add(t3, d2));
-  t3 = fp2_mul(z1, x0);
-  s1 = fp2_add(s1, t3);
-  f.c0.c1 = fp2_add(t4, t3);
-  t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(z0, z2), fp2_add(x0, x2)), d0), d2);
-  t4 = fp2_mul(z3, x4);
-  s1 = fp2_add(s1, t4);
-  f.c0.c2 = fp2_add(t3, t4);
-  t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(z2, z4), fp2_add(x2, x4)), d2), d4);
-  t4 = fp2_mul_xi(t3);
-  t3 = fp2_mul(z3, x0);
-  s1 = fp2_add(s1, t3);
-  f.c1.c0 = fp2_add(t4, t3);
-  t3 = fp2_mul(z5, x2);
-  s1 = fp2_add(s1, t3);
-  t4 = fp2_mul_xi(t3);
-  t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(z0, z4), fp2_add(x0, x4)), d0), d4);
-  f.c1.c1 = fp2_add(t4, t3);
-  Fp2 s0 = fp2_add(fp2_add(z1, z3), z5);
-  Fp2 t0 = fp2_add(fp2_add(x0, x2), x4);
-  f.c1.c2 = fp2_sub(fp2_mul(s0, t0), s1);
+  const Fp2 d0 = fp2_mul(f.c0.c0, x0);
+  const Fp2 d2 = fp2_mul(f.c0.c2, x2);
+  const Fp2 d4 = fp2_mul(f.c1.c1, x4);
+  // out0 = xi(z1 x2 + d4) + d0 ; out1 = xi(z5 x4 + d2) + z1 x0
+  Fp2 s1 = fp2_mul(f.c0.c1, x2);
+  o.c0.c0 = fp2_add(fp2_mul_xi(fp2_add(s1, d4)), d0);
+  sched_fence();
+  {
+    Fp2 t3 = fp2_mul(f.c1.c2, x4);
+    s1 = fp2_add(s1, t3);
+    Fp2 t4 = fp2_mul_xi(fp2_add(t3, d2));
+    t3 = fp2_mul(f.c0.c1, x0);
+    s1 = fp2_add(s1, t3);
+    o.c0.c1 = fp2_add(t4, t3);
+  }
+  sched_fence();
+  {  // out2 = (z0 + z2)(x0 + x2) - d0 - d2 + z3 x4
+    Fp2 t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(f.c0.c0, f.c0.c2), fp2_add(x0, x2)), d0), d2);
+    Fp2 t4 = fp2_mul(f.c1.c0, x4);
+    s1 = fp2_add(s1, t4);
+    o.c0.c2 = fp2_add(t3, t4);
+  }
+  sched_fence();
+  {  // out3 = xi((z2 + z4)(x2 + x4) - d2 - d4) + z3 x0
+    Fp2 t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(f.c0.c2, f.c1.c1), fp2_add(x2, x4)), d2), d4);
+    Fp2 t4 = fp2_mul_xi(t3);
+    t3 = fp2_mul(f.c1.c0, x0);
+    s1 = fp2_add(s1, t3);
+    o.c1.c0 = fp2_add(t4, t3);
+  }
+  sched_fence();
+  {  // out4 = xi(z5 x2) + (z0 + z4)(x0 + x4) - d0 - d4
+    Fp2 t3 = fp2_mul(f.c1.c2, x2);
+    s1 = fp2_add(s1, t3);
+    Fp2 t4 = fp2_mul_xi(t3);
+    t3 = fp2_sub(fp2_sub(fp2_mul(fp2_add(f.c0.c0, f.c1.c1), fp2_add(x0, x4)), d0), d4);
+    o.c1.c1 = fp2_add(t4, t3);
+  }
+  sched_fence();
+  {  // out5 = (z1 + z3 + z5)(x0 + x2 + x4) - s1
+    Fp2 s0 = fp2_add(fp2_add(f.c0.c1, f.c1.c0), f.c1.c2);
+    Fp2 t0 = fp2_add(fp2_add(x0, x2), x4);
+    o.c1.c2 = fp2_sub(fp2_mul(s0, t0), s1);
+  }
 }
 BN_DEV bool fp6_eq(const Fp6& a, const Fp6& b) { return fp2_eq(a.c0, b.c0) && fp2_eq(a.c1, b.c1) && fp2_eq(a.c2, b.c2); }
 BN_DEV bool fp12_eq(const Fp12& a, const Fp12& b) { return fp6_eq(a.c0, b.c0) && fp6_eq(a.c1, b.c1); }

@@ -147,8 +147,7 @@ __global__ void HEAVY_BOUNDS k_fp12_op(int op, const u64* a, const u64* b, u64* 
     case OP12_CYCSQR: cyclotomic_sqr(r, x); break;
     default: {
       Fp2 l0 = load_fp2(b, n, i, 0), lvw = load_fp2(b, n, i, 8), lvv = load_fp2(b, n, i, 16);
-      r = x;
-      fp12_sparse_mul(r, l0, lvw, lvv);
+      fp12_sparse_mul(r, x, l0, lvw, lvv);
     }
   }
   store_fp12(out, n, i, r);
@@ -344,17 +343,17 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
     }
     const int kw = wave_max(k);
     if (kw == 0) continue;
-    Fp12 f;
-    fp12_set_one(f);
+    Acc12 f;
+    f.set_one();
     Fp2 l0, l1, l2;
     const Fp2 u0 = fp2_one(), u1 = fp2_zero();
     auto apply = [&](PairState& s) {          // f *= line, or *= 1 for a dead slot
       bool lv = s.live;
-      fp12_sparse_mul(f, fp2_select(u0, l0, lv), fp2_select(u1, fp2_scale(l1, s.py), lv), fp2_select(u1, fp2_scale(l2, s.px), lv));
+      f.sparse(fp2_select(u0, l0, lv), fp2_select(u1, fp2_scale(l1, s.py), lv), fp2_select(u1, fp2_scale(l2, s.px), lv));
     };
 #pragma unroll 1
     for (int i = 0; i < 64; ++i) {
-      fp12_sqr(f, f);
+      f.square();
 #pragma unroll 1
       for (int j = 0; j < kw; ++j) { g2_doubling_step(st[j].r, l0, l1, l2); apply(st[j]); }
       if ((nz >> (63 - i)) & 1) {
@@ -383,7 +382,7 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
         apply(st[j]);
       }
     }
-    fp12_mul(acc, acc, f);
+    fp12_mul(acc, acc, f.get());
   }
   Fp12 g;
   final_exponentiation(g, acc);
@@ -507,22 +506,22 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const Fp2 qx = fp2_select(gx, load_fp2(pkxy, n, ii, 0), liveB), qy = fp2_select(gy, load_fp2(pkxy, n, ii, 8), liveB);
   const Fp2 nqy = fp2_neg(qy);
   G2P r{qx, qy, fp2_one()};
-  Fp12 f;
-  fp12_set_one(f);
+  Acc12 f;
+  f.set_one();
   Fp2 l0, l1, l2;
   const Fp2 u0 = fp2_one(), u1 = fp2_zero();
   auto lineA = [&](int at) {
     Fp2 a0 = table_fp2(at, 0), a1 = fp2_scale(table_fp2(at, 1), sy), a2 = fp2_scale(table_fp2(at, 2), sx);
-    fp12_sparse_mul(f, fp2_select(u0, a0, liveA), fp2_select(u1, a1, liveA), fp2_select(u1, a2, liveA));
+    f.sparse(fp2_select(u0, a0, liveA), fp2_select(u1, a1, liveA), fp2_select(u1, a2, liveA));
   };
   auto lineB = [&]() {
-    fp12_sparse_mul(f, fp2_select(u0, l0, liveB), fp2_select(u1, fp2_scale(l1, hy), liveB), fp2_select(u1, fp2_scale(l2, hx), liveB));
+    f.sparse(fp2_select(u0, l0, liveB), fp2_select(u1, fp2_scale(l1, hy), liveB), fp2_select(u1, fp2_scale(l2, hx), liveB));
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
   int idx = 0;
 #pragma unroll 1
   for (int it = 0; it < 64; ++it) {
-    fp12_sqr(f, f);
+    f.square();
     lineA(idx++);
     g2_doubling_step(r, l0, l1, l2);
     lineB();
@@ -542,7 +541,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2);
   lineB();
   Fp12 g, one;
-  final_exponentiation(g, f);
+  final_exponentiation(g, f.get());
   fp12_set_one(one);
   if (active) okout[i] = fp12_eq(g, one) ? 1 : 0;
 }
