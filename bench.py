@@ -30,11 +30,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ISSUE_PEAK_GINSTR = 580.0             # measured VOP3 wave-instr/s ceiling, profiles/r01_issue_rate_ubench.txt
 PAIRING_BYTES = 576                   # 64 (G1 affine) + 128 (G2 affine) + 384 (Gt)  -- SURVEY.md §8(d)
 VERIFY_BYTES = 225                    # pk 128 + sig 64 + 32-byte msg + flag
-# rocprofv3 PMC facts about k_pairing (profiles/r01_pairing_v2/pmc_k_pairing.json, n = 2^20 = 16384 waves);
+# rocprofv3 PMC facts about k_pairing (profiles/r01_pairing_v4/pmc_k_pairing.json, n = 2^20 = 16384 waves);
 # bench.py cannot collect PMC counters itself, so the per-launch constants measured there are reused here
 # and scale with n.  Refresh them with tools/prof_pairing.sh whenever the kernel changes.
-PAIRING_VALU_INSTR_PER_WAVE = 1.33572673536e11 / 16384          # SQ_INSTS_VALU per wavefront (64 pairings)
-PAIRING_HBM_BYTES_PER_WAVE = (2 * 263583935.0 + 412824846.1875) * 1024 / 16384   # 2*FETCH_SIZE + WRITE_SIZE (KiB), gfx950 correction
+PAIRING_VALU_INSTR_PER_WAVE = 1.0627981312e11 / 16384          # SQ_INSTS_VALU per wavefront (64 pairings)
+PAIRING_HBM_BYTES_PER_WAVE = (2 * 226712579.0625 + 365548158.625) * 1024 / 16384   # 2*FETCH_SIZE + WRITE_SIZE (KiB), gfx950 correction
 
 G1 = [1, 2]
 G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
@@ -239,7 +239,7 @@ def main():
                        "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": PAIRING_HBM_BYTES_PER_WAVE * (n / 64),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pairing_v2): "
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pairing_v4): "
                                          "per-lane scratch frames of Fp12 temporaries, not algorithmic re-reads",
                          "kernel": "k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
         }
