@@ -148,6 +148,16 @@ int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf,
  * points in G1 x G2 (subgroup-checked keys); ~1.5x faster. */
 int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                          const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* ---- wire formats: G1Affine/G2Affine::{to,from}_be_bytes (g1.rs:151-280, g2.rs:319-433) -------------- */
+/* G1: 64 bytes x | y big-endian; G2: 128 bytes x.c1 | x.c0 | y.c1 | y.c0; bit 7 of byte 0 is the infinity flag and
+ * the identity is written as (0, 1) + flag.  from_be_bytes masks the flag, then: a coordinate >= p, or a set flag
+ * with coordinates other than (0, 1) -> DECODE_ERROR (the reference's CtOption is none); off the curve ->
+ * NOT_ON_CURVE; G2 outside the r-torsion -> NOT_IN_SUBGROUP.  Failed elements decode to the identity. */
+int32_t sylow_hip_g1_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out /*[n][64]*/, size_t n, void* stream);
+int32_t sylow_hip_g1_from_be_bytes_batch(const uint8_t* in /*[n][64]*/, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out /*[n][128]*/, size_t n, void* stream);
+int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in /*[n][128]*/, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream);
+
 /* ---- EVM alt_bn128 precompile shapes: examples/reth_bn128.rs:99-217 (EIP-196 / EIP-197) --------- */
 /* Byte-level batches.  Field elements are 32-byte big-endian and must be < p (else DECODE_ERROR =
  * Bn128FieldPointNotAMember); (0,0) is the identity; G1 points must be on the curve, G2 points on the twist

@@ -690,6 +690,83 @@ __global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst,
   result[j] = st ? 0 : is_one[j];
 }
 
+
+// ------------------------------------------------------------------ wire formats -----------------
+// G1Affine::to_be_bytes / from_be_bytes (g1.rs:151-280): x | y big-endian, bit 7 of byte 0 = infinity flag,
+// identity encoded as (0, 1) + flag; decoding masks the flag, rejects coordinates >= p (DECODE_ERROR),
+// a set flag with (x, y) != (0, 1) (DECODE_ERROR) and off-curve points (NOT_ON_CURVE).
+// G2: x.c1 | x.c0 | y.c1 | y.c0 (g2.rs:319-433); decoding also runs the subgroup check of G2Projective::new.
+__global__ void __launch_bounds__(BLOCK) k_g1_to_bytes(const u64* xy, const uint8_t* inf, uint8_t* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool z = inf && inf[i];
+  Fp x = z ? fp_zero() : fp_reduce_plain(load_plain(xy, n, i, 0));
+  Fp y = z ? fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0) : fp_reduce_plain(load_plain(xy, n, i, 4));
+  write_be_fp(out + 64 * i, x);
+  write_be_fp(out + 64 * i + 32, y);
+  if (z) out[64 * i] |= 0x80;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  uint8_t b[64];
+  for (int k = 0; k < 64; ++k) b[k] = in[64 * i + k];
+  bool flag = (b[0] >> 7) & 1;
+  b[0] &= 0x7f;
+  Fp x, y;
+  bool ok = read_be_fp(x, b);
+  ok = read_be_fp(y, b + 32) && ok;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool is01 = fp_is_zero(x) && fp_eq(y, fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0));
+  if (!ok) st = SYLOW_HIP_ST_DECODE_ERROR;
+  else if (flag) st = is01 ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_DECODE_ERROR;
+  else if (!g1_on_curve_affine(fp_to_mont(x), fp_to_mont(y))) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+  bool z = flag || st != SYLOW_HIP_ST_OK;
+  store_plain(xy, n, i, 0, z ? fp_zero() : x);
+  store_plain(xy, n, i, 4, z ? fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0) : y);
+  inf[i] = z ? 1 : 0;
+  status[i] = st;
+}
+__global__ void __launch_bounds__(BLOCK) k_g2_to_bytes(const u64* xy, const uint8_t* inf, uint8_t* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool z = inf && inf[i];
+  const Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  Fp xc0 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 0)), xc1 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 4));
+  Fp yc0 = z ? one : fp_reduce_plain(load_plain(xy, n, i, 8)), yc1 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 12));
+  uint8_t* o = out + 128 * i;
+  write_be_fp(o, xc1); write_be_fp(o + 32, xc0); write_be_fp(o + 64, yc1); write_be_fp(o + 96, yc0);
+  if (z) o[0] |= 0x80;
+}
+__global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  uint8_t b[128];
+  for (int k = 0; k < 128; ++k) b[k] = in[128 * i + k];
+  bool flag = (b[0] >> 7) & 1;
+  b[0] &= 0x7f;
+  Fp xc1, xc0, yc1, yc0;
+  bool ok = read_be_fp(xc1, b);
+  ok = read_be_fp(xc0, b + 32) && ok;
+  ok = read_be_fp(yc1, b + 64) && ok;
+  ok = read_be_fp(yc0, b + 96) && ok;
+  const Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool is01 = fp_is_zero(xc0) && fp_is_zero(xc1) && fp_eq(yc0, one) && fp_is_zero(yc1);
+  if (!ok) st = SYLOW_HIP_ST_DECODE_ERROR;
+  else if (flag) st = is01 ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_DECODE_ERROR;
+  else {
+    Fp2 x{fp_to_mont(xc0), fp_to_mont(xc1)}, y{fp_to_mont(yc0), fp_to_mont(yc1)};
+    if (!g2_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    else if (!g2_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+  }
+  bool z = flag || st != SYLOW_HIP_ST_OK;
+  store_plain(xy, n, i, 0, z ? zero : xc0); store_plain(xy, n, i, 4, z ? zero : xc1);
+  store_plain(xy, n, i, 8, z ? one : yc0); store_plain(xy, n, i, 12, z ? zero : yc1);
+  inf[i] = z ? 1 : 0;
+  status[i] = st;
+}
+
 // ------------------------------------------------------------------ layout helpers --------------
 __global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
   size_t t = TID;
@@ -929,6 +1006,19 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   HIPCHK(hipFreeAsync(ws, st));
   if (e_ != hipSuccess) return fail(e_, "kernel launch");
   return SYLOW_HIP_OK;
+}
+
+int32_t sylow_hip_g1_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {
+  ARGCHK(p_xy && out); if (!n) return SYLOW_HIP_OK; k_g1_to_bytes<<<GRID(n)>>>(p_xy, p_inf, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g1_from_bytes<<<GRID(n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {
+  ARGCHK(p_xy && out); if (!n) return SYLOW_HIP_OK; k_g2_to_bytes<<<GRID(n)>>>(p_xy, p_inf, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g2_from_bytes<<<GRID(n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));

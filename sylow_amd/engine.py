@@ -222,6 +222,29 @@ class Engine:
         gt = self.from_device_soa(dgt)[:nj] if want_gt else None
         return gt, dis.download()[:nj]
 
+    # ---- wire formats ----------------------------------------------------------------------
+    def _to_bytes(self, name, width, nbytes, xy, inf):
+        xy = _aos(xy, width)
+        n = xy.shape[0]
+        d, di = self.to_device_soa(xy, width), self._flags(inf, n)
+        do = self.empty((n * nbytes,), np.uint8)
+        self._call(name, d.ptr, self._ptr(di), do.ptr, n)
+        raw = do.download().tobytes()
+        return [raw[nbytes * i:nbytes * (i + 1)] for i in range(n)]
+
+    def _from_bytes(self, name, width, nbytes, blobs):
+        n = len(blobs)
+        assert all(len(b) == nbytes for b in blobs)
+        din = self.to_device(np.frombuffer(b"".join(blobs), dtype=np.uint8))
+        dxy, dinf, dst = self.empty((width, n)), self.empty((n,), np.uint8), self.empty((n,), np.uint8)
+        self._call(name, din.ptr, dxy.ptr, dinf.ptr, dst.ptr, n)
+        return self.from_device_soa(dxy), dinf.download(), dst.download()
+
+    def g1_to_be_bytes(self, xy, inf=None): return self._to_bytes("sylow_hip_g1_to_be_bytes_batch", 8, 64, xy, inf)
+    def g2_to_be_bytes(self, xy, inf=None): return self._to_bytes("sylow_hip_g2_to_be_bytes_batch", 16, 128, xy, inf)
+    def g1_from_be_bytes(self, blobs): return self._from_bytes("sylow_hip_g1_from_be_bytes_batch", 8, 64, blobs)
+    def g2_from_be_bytes(self, blobs): return self._from_bytes("sylow_hip_g2_from_be_bytes_batch", 16, 128, blobs)
+
     # ---- hashing / BLS ---------------------------------------------------------------------
     def _msgs(self, msgs):
         off = np.zeros(len(msgs) + 1, dtype=np.uint64)
