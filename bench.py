@@ -220,7 +220,13 @@ def main():
             dist.all_reduce(flag2, op=dist.ReduceOp.MIN)
         fence()
         dtf = time.perf_counter() - tf
-        aux = {"bls_verifies_per_s": world * nv / dtv, "bls_verify_batch_per_gpu": nv,
+        eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)   # warm
+        fence()
+        ts = time.perf_counter()
+        eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
+        fence()
+        dts = time.perf_counter() - ts
+        aux = {"bls_verifies_per_s": world * nv / dtv, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
                "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
                "bls_verifies_per_s_fused": world * nv / dtf, "bls_all_valid_fused": int(flag2.item()),
                "note": "verify = lib.rs:223-236 as written (hash + two full pairings); fused = e(sig,G2gen)*e(-H,pk)==1, one final exponentiation"}

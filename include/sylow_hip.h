@@ -172,6 +172,15 @@ int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* stat
 int32_t sylow_hip_evm_ecmul_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream);
 int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
                                       uint8_t* result, uint8_t* status, void* stream);
+/* Same-signer batch (examples/verify_multiple_messages_same_signer.rs:41-60): ONE public key (pk_xy is a
+ * 1-element SoA array, pk_inf one byte or NULL) against n (message, signature) pairs.  The key's G2PreComputed
+ * line table is built once per call and both pairs of every element read wave-uniform tables, so the Miller
+ * loops contain no G2 arithmetic. */
+int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                               const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* G2Affine::precompute (pairing.rs:676-708): the 87 line-coefficient triples [Ell; 87] of each point, canonical
+ * words, SoA [87*24][n] (triple t = words 24t..24t+23 = ell.0, ell.1, ell.2 as Fp2).  Strict replay. */
+int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream);
 /* AND of a flag array -> one int32 on the device (1 = all set); the multi-GPU aggregate then
  * MIN-reduces that word over ranks (RCCL has no bit-AND; min over {0,1} is AND). */
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream);

@@ -138,6 +138,9 @@ class G2Affine(_Points):
         y = np.concatenate([engine().fp_neg(self.xy[:, 8:12]), engine().fp_neg(self.xy[:, 12:16])], axis=1)
         return G2Affine(np.concatenate([self.xy[:, :8], y], axis=1), self.infinity)
 
+    def precompute(self) -> "G2PreComputed":        # pairing.rs:676
+        return G2PreComputed(self)
+
 
 G2Projective = G2Affine
 
@@ -164,6 +167,34 @@ class Gt:
         return Gt(engine().fp12_mul(self.v, other.v))
 
 
+class MillerLoopResult:
+    """Batch of raw Miller values (pairing.rs:72): public but NOT unique -- the engine replays the reference's
+    line formulas and digit schedule, so these match `G2PreComputed::miller_loop` bit for bit (SURVEY.md N2)."""
+
+    def __init__(self, v: np.ndarray):
+        self.v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 48)
+
+    def __eq__(self, other):
+        return (self.v == other.v).all(axis=1)
+
+    def __mul__(self, other):                      # Mul<&MillerLoopResult> (pairing.rs:98-128): Fp12 product
+        return MillerLoopResult(engine().fp12_mul(self.v, other.v))
+
+    def final_exponentiation(self) -> "Gt":        # pairing.rs:245-492
+        return Gt(engine().final_exp(self.v))
+
+
+class G2PreComputed:
+    """G2Affine::precompute() (pairing.rs:556,676-708): q plus the 87 line-coefficient triples, [n, 87*24] words."""
+
+    def __init__(self, q: "G2Affine"):
+        self.q = q
+        self.coeffs = engine().g2_precompute(q.xy)
+
+    def miller_loop(self, g1: G1Affine) -> MillerLoopResult:     # pairing.rs:590-619
+        return MillerLoopResult(engine().miller_loop(g1.xy, self.q.xy))
+
+
 def pairing(p: G1Affine, q: G2Affine) -> Gt:
     """pairing(&G1Projective, &G2Projective) -> Gt (pairing.rs:870-893), n independent values."""
     return Gt(engine().pairing(p.xy, q.xy, p.infinity, q.infinity))
@@ -177,6 +208,12 @@ def glued_pairing(g1s: G1Affine, g2s: G2Affine, offsets=None, evm_infinity: bool
         offsets = [0, len(g1s)]
     gt, _ = engine().multi_pairing(g1s.xy, g2s.xy, offsets, g1s.infinity, g2s.infinity, skip_infinity=evm_infinity)
     return Gt(gt)
+
+
+def verify_same_signer(pubkey: G2Affine, msgs, sig: G1Affine) -> np.ndarray:
+    """examples/verify_multiple_messages_same_signer.rs:41-60: one key, many (message, signature) pairs."""
+    assert len(pubkey) == 1
+    return engine().bls_verify_same_signer(pubkey.xy, list(msgs), sig.xy, pubkey.infinity, sig.infinity).astype(bool)
 
 
 def sign(k, msgs) -> G1Affine:

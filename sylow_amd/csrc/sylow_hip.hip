@@ -461,34 +461,56 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
 // The G2 generator is fixed, so its 87 line-coefficient triples (pairing.rs:676-708) are computed once
 // per device into g_g2gen_lines and read with wave-uniform (scalar) loads.
 __device__ u32 g_g2gen_lines[87 * 48];
-__global__ void k_g2gen_lines() {
-  if (TID != 0) return;
-  const Fp2 qx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, qy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
+// the 87 line-coefficient triples of G2Affine::precompute (pairing.rs:676-708) for one affine point, Montgomery form
+template <class PUT>
+BN_DEV void g2_line_table(const Fp2& qx, const Fp2& qy, PUT put) {
   G2P r{qx, qy, fp2_one()};
   const Fp2 nqy = fp2_neg(qy);
   Fp2 l0, l1, l2;
   int idx = 0;
-  auto put = [&](int at) {
-    const Fp* src[6] = {&l0.c0, &l0.c1, &l1.c0, &l1.c1, &l2.c0, &l2.c1};
-    for (int c = 0; c < 6; ++c) for (int j = 0; j < 8; ++j) g_g2gen_lines[at * 48 + c * 8 + j] = src[c]->v[j];
-  };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
-    g2_doubling_step(r, l0, l1, l2); put(idx++);
-    if ((nz >> (63 - i)) & 1) { g2_addition_step(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(idx++); }
+    g2_doubling_step(r, l0, l1, l2); put(idx++, l0, l1, l2);
+    if ((nz >> (63 - i)) & 1) { g2_addition_step(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(idx++, l0, l1, l2); }
   }
   Fp2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qx, qy);
   g2_psi_affine(q2x, q2y, q1x, q1y);
-  g2_addition_step(r, q1x, q1y, l0, l1, l2); put(idx++);
-  g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2); put(idx++);
+  g2_addition_step(r, q1x, q1y, l0, l1, l2); put(idx++, l0, l1, l2);
+  g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2); put(idx++, l0, l1, l2);
 }
-BN_DEV Fp2 table_fp2(int at, int c) {
-  const u32* t = g_g2gen_lines + at * 48 + c * 16;
+// one lane builds the Montgomery-form u32 table [87][48] of a single point: the generator (qxy == nullptr) or
+// element `idx` of an SoA G2 array
+__global__ void k_g2_lines(const u64* qxy, size_t n, size_t idx, u32* table) {
+  if (TID != 0) return;
+  Fp2 qx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, qy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
+  if (qxy) { qx = load_fp2(qxy, n, idx, 0); qy = load_fp2(qxy, n, idx, 8); }
+  u32* t = table ? table : g_g2gen_lines;
+  g2_line_table(qx, qy, [&](int at, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    const Fp* src[6] = {&l0.c0, &l0.c1, &l1.c0, &l1.c1, &l2.c0, &l2.c1};
+    for (int c = 0; c < 6; ++c) for (int j = 0; j < 8; ++j) t[at * 48 + c * 8 + j] = src[c]->v[j];
+  });
+}
+// G2Affine::precompute for a batch (pairing.rs:676-708): canonical words, SoA [87*24][n], triple t of point i at
+// words 24t .. 24t+23 = (ell.0, ell.1, ell.2) as Fp2 each -- the reference's [Ell; 87] in its own order
+__global__ void HEAVY_BOUNDS k_g2_precompute(const u64* qxy, u64* coeffs, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp2 qx = load_fp2(qxy, n, i, 0), qy = load_fp2(qxy, n, i, 8);
+  g2_line_table(qx, qy, [&](int at, const Fp2& l0, const Fp2& l1, const Fp2& l2) {
+    store_fp2(coeffs, n, i, 24 * at, l0); store_fp2(coeffs, n, i, 24 * at + 8, l1); store_fp2(coeffs, n, i, 24 * at + 16, l2);
+  });
+}
+BN_DEV Fp2 table_fp2(const u32* table, int at, int c) {
+  const u32* t = table + at * 48 + c * 16;
   return Fp2{fp_from_limbs(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]), fp_from_limbs(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15])};
 }
-__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
+// PK_TABLE: every element is checked against ONE public key whose line table was precomputed (the same-signer
+// shape of examples/verify_multiple_messages_same_signer.rs): both pairs read wave-uniform tables and the loop
+// contains no G2 arithmetic at all.
+template <bool PK_TABLE>
+__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const u32* pk_table, const uint8_t* msgs, const u64* off, DstPrime dp,
                                                 const u64* sigxy, const uint8_t* siginf, uint8_t* okout, size_t n) {
   size_t i = TID;
   const bool active = i < n;
@@ -499,11 +521,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   g1_to_affine(hx, hy, hinf, h);
   hy = fp_neg(hy);                            // pair B is (-H, pk)
   const bool liveA = !(siginf && siginf[ii]);
-  const bool liveB = !(hinf || (pkinf && pkinf[ii]));
+  const bool liveB = !(hinf || (pkinf && pkinf[PK_TABLE ? 0 : ii]));
   const Fp sx = load_fp(sigxy, n, ii, 0), sy = load_fp(sigxy, n, ii, 4);
   const Fp2 gx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, gy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
   // a dead pair B steps the generator instead (any curve point keeps the arithmetic defined) and multiplies by the unit line
-  const Fp2 qx = fp2_select(gx, load_fp2(pkxy, n, ii, 0), liveB), qy = fp2_select(gy, load_fp2(pkxy, n, ii, 8), liveB);
+  const Fp2 qx = PK_TABLE ? gx : fp2_select(gx, load_fp2(pkxy, n, ii, 0), liveB), qy = PK_TABLE ? gy : fp2_select(gy, load_fp2(pkxy, n, ii, 8), liveB);
   const Fp2 nqy = fp2_neg(qy);
   G2P r{qx, qy, fp2_one()};
   Acc12 f;
@@ -511,10 +533,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   Fp2 l0, l1, l2;
   const Fp2 u0 = fp2_one(), u1 = fp2_zero();
   auto lineA = [&](int at) {
-    Fp2 a0 = table_fp2(at, 0), a1 = fp2_scale(table_fp2(at, 1), sy), a2 = fp2_scale(table_fp2(at, 2), sx);
+    Fp2 a0 = table_fp2(g_g2gen_lines, at, 0), a1 = fp2_scale(table_fp2(g_g2gen_lines, at, 1), sy), a2 = fp2_scale(table_fp2(g_g2gen_lines, at, 2), sx);
     f.sparse(fp2_select(u0, a0, liveA), fp2_select(u1, a1, liveA), fp2_select(u1, a2, liveA));
   };
-  auto lineB = [&]() {
+  auto lineB = [&](int at) {
+    if (PK_TABLE) { l0 = table_fp2(pk_table, at, 0); l1 = table_fp2(pk_table, at, 1); l2 = table_fp2(pk_table, at, 2); }
     f.sparse(fp2_select(u0, l0, liveB), fp2_select(u1, fp2_scale(l1, hy), liveB), fp2_select(u1, fp2_scale(l2, hx), liveB));
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
@@ -522,24 +545,26 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
 #pragma unroll 1
   for (int it = 0; it < 64; ++it) {
     f.square();
-    lineA(idx++);
-    g2_doubling_step(r, l0, l1, l2);
-    lineB();
+    lineA(idx);
+    if (!PK_TABLE) g2_doubling_step(r, l0, l1, l2);
+    lineB(idx);
+    ++idx;
     if ((nz >> (63 - it)) & 1) {
-      lineA(idx++);
-      g2_addition_step(r, qx, ((ng >> (63 - it)) & 1) ? nqy : qy, l0, l1, l2);
-      lineB();
+      lineA(idx);
+      if (!PK_TABLE) g2_addition_step(r, qx, ((ng >> (63 - it)) & 1) ? nqy : qy, l0, l1, l2);
+      lineB(idx);
+      ++idx;
     }
   }
   Fp2 q1x, q1y, q2x, q2y;
-  g2_psi_affine(q1x, q1y, qx, qy);
-  g2_psi_affine(q2x, q2y, q1x, q1y);
-  lineA(idx++);
-  g2_addition_step(r, q1x, q1y, l0, l1, l2);
-  lineB();
-  lineA(idx++);
-  g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2);
-  lineB();
+  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, qx, qy); g2_psi_affine(q2x, q2y, q1x, q1y); }
+  lineA(idx);
+  if (!PK_TABLE) g2_addition_step(r, q1x, q1y, l0, l1, l2);
+  lineB(idx);
+  ++idx;
+  lineA(idx);
+  if (!PK_TABLE) g2_addition_step(r, q2x, fp2_neg(q2y), l0, l1, l2);
+  lineB(idx);
   Fp12 g, one;
   final_exponentiation(g, f.get());
   fp12_set_one(one);
@@ -960,9 +985,9 @@ static int32_t ensure_g2gen_lines(void* stream) {
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { snprintf(g_err, sizeof(g_err), "device index out of range"); return SYLOW_HIP_E_ARG; }
   if (!ready[dev]) {
-    k_g2gen_lines<<<1, 64, 0, (hipStream_t)stream>>>();
+    k_g2_lines<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, nullptr);
     hipError_t e_ = hipGetLastError();
-    if (e_ != hipSuccess) return fail(e_, "k_g2gen_lines launch");
+    if (e_ != hipSuccess) return fail(e_, "k_g2_lines launch");
     ready[dev] = true;
   }
   return SYLOW_HIP_OK;
@@ -973,7 +998,27 @@ int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* p
   int32_t rc = ensure_g2gen_lines(stream);
   if (rc != SYLOW_HIP_OK) return rc;
   DstPrime dp; dst_arg(dp, nullptr, 0);
-  k_bls_verify_fused<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+  k_bls_verify_fused<false><<<GRID(n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                               const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  int32_t rc = ensure_g2gen_lines(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  u32* table = nullptr;
+  HIPCHK(hipMallocAsync((void**)&table, 87 * 48 * sizeof(u32), st));
+  k_g2_lines<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);          // the key is a 1-element SoA array
+  DstPrime dp; dst_arg(dp, nullptr, 0);
+  k_bls_verify_fused<true><<<GRID(n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n);
+  hipError_t e_ = hipGetLastError();
+  HIPCHK(hipFreeAsync(table, st));
+  if (e_ != hipSuccess) return fail(e_, "kernel launch");
+  return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
+  ARGCHK(q_xy && coeffs); if (!n) return SYLOW_HIP_OK;
+  k_g2_precompute<<<GRID(n)>>>(q_xy, coeffs, n); LAUNCHED();
 }
 
 int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {

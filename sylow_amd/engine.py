@@ -279,6 +279,25 @@ class Engine:
         self._call("sylow_hip_bls_verify_fused_batch" if fused else "sylow_hip_bls_verify_batch", dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
         return dok.download()
 
+    def bls_verify_same_signer(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None):
+        pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
+        assert pk_xy.shape[0] == 1
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        dpk, dsig = self.to_device_soa(pk_xy, 16), self.to_device_soa(sig_xy, 8)
+        dpi, dsi = self._flags(pk_inf, 1), self._flags(sig_inf, n)
+        dok = self.empty((n,), np.uint8)
+        self._call("sylow_hip_bls_verify_same_signer_batch", dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
+        return dok.download()
+
+    def g2_precompute(self, q_xy):
+        q_xy = _aos(q_xy, 16)
+        n = q_xy.shape[0]
+        dq = self.to_device_soa(q_xy, 16)
+        dc = self.empty((87 * 24, n))
+        self._call("sylow_hip_g2_precompute_batch", dq.ptr, dc.ptr, n)
+        return self.from_device_soa(dc)
+
     def flags_all(self, dflags: DeviceArray) -> int:
         out = self.empty((1,), np.int32)
         self._call("sylow_hip_flags_all", dflags.ptr, dflags.shape[0], out.ptr)

@@ -74,3 +74,19 @@ def test_group_errors(api):
     bad[0, 8] ^= np.uint64(1)
     with pytest.raises(api.GroupError, match="NotOnCurve"):
         api.G2Affine.new(bad)
+
+
+def test_precompute_and_miller_types(api, coracle):
+    """G2Affine::precompute / G2PreComputed::miller_loop / MillerLoopResult::final_exponentiation (pairing.rs:556-619)"""
+    rng = Xoshiro(SEED + 52)
+    n = 16
+    p = api.G1Projective.generator(n) * api.fp([rng.fp() for _ in range(n)])
+    q = api.G2Projective.generator(n) * api.fp([rng.fp() for _ in range(n)])
+    pre = q.precompute()
+    assert np.array_equal(pre.coeffs, coracle.g2_precompute(q.xy))
+    ml = pre.miller_loop(p)
+    assert np.array_equal(ml.v, coracle.miller_loop(p.xy, q.xy))
+    assert (ml.final_exponentiation() == api.pairing(p, q)).all()
+    # MillerLoopResult default * x == x (pairing.rs:1244-1250)
+    one = np.zeros((n, 48), dtype=np.uint64); one[:, 0] = 1
+    assert ((api.MillerLoopResult(one) * ml) == ml).all()

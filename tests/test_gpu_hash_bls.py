@@ -106,3 +106,29 @@ def test_fused_verify_equals_reference_shape(engine):
     b = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf)
     assert np.array_equal(a, b)
     assert a[(pinf & sinf).astype(bool)].all()               # both sides identity -> 1 == 1
+
+
+def test_same_signer_and_precompute(engine, coracle):
+    """G2Affine::precompute replayed coefficient by coefficient (pairing.rs:676-708), and the same-signer batch
+    verify of examples/verify_multiple_messages_same_signer.rs against the per-element verifier."""
+    rng = Xoshiro(SEED + 32)
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 9, 0), limbs([rng.fp() for _ in range(9)]))
+    q = np.concatenate([q, pack(G2, 16)])
+    assert np.array_equal(engine.g2_precompute(q), coracle.g2_precompute(q))
+    msgs = messages() * 4
+    n = len(msgs)
+    sk = limbs([rng.fp()])
+    pk, _ = engine.g2_scalar_mul(pack(G2, 16), sk)
+    sig, _ = engine.bls_sign(np.repeat(sk, n, 0), msgs)
+    assert engine.bls_verify_same_signer(pk, msgs, sig).tolist() == [1] * n
+    bad, _ = engine.g1_add(sig, np.repeat(pack([1, 2], 8), n, 0))
+    plant = np.random.default_rng(3).random(n) < 0.25
+    mixed = np.where(plant[:, None], bad, sig)
+    got = engine.bls_verify_same_signer(pk, msgs, mixed)
+    assert np.array_equal(got.astype(bool), ~plant)
+    assert np.array_equal(got, engine.bls_verify(np.repeat(pk, n, 0), msgs, mixed))
+    other, _ = engine.g2_scalar_mul(pack(G2, 16), limbs([rng.fp()]))
+    assert engine.bls_verify_same_signer(other, msgs, sig).sum() == 0
+    sinf = (np.random.default_rng(4).random(n) < 0.3).astype(np.uint8)
+    assert np.array_equal(engine.bls_verify_same_signer(pk, msgs, mixed, sig_inf=sinf), engine.bls_verify(np.repeat(pk, n, 0), msgs, mixed, sig_inf=sinf))
+    assert np.array_equal(engine.bls_verify_same_signer(pk, msgs, mixed, pk_inf=[1], sig_inf=sinf).astype(bool), sinf.astype(bool))
