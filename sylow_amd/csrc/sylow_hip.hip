@@ -422,37 +422,6 @@ __global__ void __launch_bounds__(BLOCK) k_bls_sign(const u64* sk, const uint8_t
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
   oinf[i] = inf ? 1 : 0;
 }
-// lib.rs:223-236: ok = pairing(sig, G2gen) == pairing(H(msg), pk), two full pairings as written
-__global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
-                                          const u64* sigxy, const uint8_t* siginf, uint8_t* okout, size_t n) {
-  size_t i = TID;
-  if (i >= n) return;
-  G1P h;
-  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
-  Fp hx, hy; bool hinf;
-  g1_to_affine(hx, hy, hinf, h);
-  Fp12 f, lhs, rhs;
-  // lhs = pairing(sig, G2gen)
-  if (siginf && siginf[i]) {
-    fp12_set_one(lhs);
-  } else {
-    Fp sx = load_fp(sigxy, n, i, 0), sy = load_fp(sigxy, n, i, 4);
-    Fp2 gx{fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1])}, gy{fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3])};
-    miller_loop(f, sx, sy, gx, gy);
-    final_exponentiation(lhs, f);
-  }
-  // rhs = pairing(H, pk)
-  if (hinf || (pkinf && pkinf[i])) {
-    fp12_set_one(rhs);
-  } else {
-    Fp2 qx = load_fp2(pkxy, n, i, 0), qy = load_fp2(pkxy, n, i, 8);
-    miller_loop(f, hx, hy, qx, qy);
-    final_exponentiation(rhs, f);
-  }
-  okout[i] = fp12_eq(lhs, rhs) ? 1 : 0;
-}
-
-
 // ------------------------------------------------------------------ fused BLS verify ------------
 // The batch-verify shape sylow's own examples recommend (examples/verify_multiple_messages_same_signer.rs:41-60,
 // threshold_signing.rs:92-121): e(sig, G2gen) * e(-H(msg), pk) == 1 with ONE shared-squaring Miller loop
@@ -506,6 +475,61 @@ BN_DEV Fp2 table_fp2(const u32* table, int at, int c) {
   const u32* t = table + at * 48 + c * 16;
   return Fp2{fp_from_limbs(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]), fp_from_limbs(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15])};
 }
+
+// G2PreComputed::miller_loop (pairing.rs:590-619) against a precomputed line table (Montgomery u32 [87][48])
+BN_NOINLINE void miller_loop_table(Fp12& fout, const Fp& px, const Fp& py, const u32* table) {
+  Acc12 f;
+  f.set_one();
+  const u64 nz = BN_ATE_NAF_NZ;
+  int idx = 0;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    f.square();
+    f.line(table_fp2(table, idx, 0), table_fp2(table, idx, 1), table_fp2(table, idx, 2), px, py);
+    ++idx;
+    if ((nz >> (63 - i)) & 1) {
+      f.line(table_fp2(table, idx, 0), table_fp2(table, idx, 1), table_fp2(table, idx, 2), px, py);
+      ++idx;
+    }
+  }
+  f.line(table_fp2(table, idx, 0), table_fp2(table, idx, 1), table_fp2(table, idx, 2), px, py);
+  ++idx;
+  f.line(table_fp2(table, idx, 0), table_fp2(table, idx, 1), table_fp2(table, idx, 2), px, py);
+  fout = f.get();
+}
+
+// lib.rs:223-236: ok = pairing(sig, G2gen) == pairing(H(msg), pk), two full pairings as written
+// (the generator's line coefficients are read from the precomputed table: same G2PreComputed values)
+__global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                          const u64* sigxy, const uint8_t* siginf, uint8_t* okout, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  Fp hx, hy; bool hinf;
+  g1_to_affine(hx, hy, hinf, h);
+  Fp12 f, lhs, rhs;
+  // lhs = pairing(sig, G2gen)
+  if (siginf && siginf[i]) {
+    fp12_set_one(lhs);
+  } else {
+    Fp sx = load_fp(sigxy, n, i, 0), sy = load_fp(sigxy, n, i, 4);
+    miller_loop_table(f, sx, sy, g_g2gen_lines);     // Q = G2 generator: its [Ell; 87] comes from the per-device table
+    final_exponentiation(lhs, f);
+  }
+  // rhs = pairing(H, pk)
+  if (hinf || (pkinf && pkinf[i])) {
+    fp12_set_one(rhs);
+  } else {
+    Fp2 qx = load_fp2(pkxy, n, i, 0), qy = load_fp2(pkxy, n, i, 8);
+    miller_loop(f, hx, hy, qx, qy);
+    final_exponentiation(rhs, f);
+  }
+  okout[i] = fp12_eq(lhs, rhs) ? 1 : 0;
+}
+
+
+
 // PK_TABLE: every element is checked against ONE public key whose line table was precomputed (the same-signer
 // shape of examples/verify_multiple_messages_same_signer.rs): both pairs read wave-uniform tables and the loop
 // contains no G2 arithmetic at all.
@@ -971,13 +995,6 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
   DstPrime dp; dst_arg(dp, nullptr, 0);
   k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
 }
-int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
-  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  DstPrime dp; dst_arg(dp, nullptr, 0);
-  k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
-}
-
 // one-time (per device) construction of the G2-generator line table used by the fused verifier
 static int32_t ensure_g2gen_lines(void* stream) {
   static bool ready[64] = {false};
@@ -992,6 +1009,15 @@ static int32_t ensure_g2gen_lines(void* stream) {
   }
   return SYLOW_HIP_OK;
 }
+int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  int32_t rc = ensure_g2gen_lines(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  DstPrime dp; dst_arg(dp, nullptr, 0);
+  k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+}
+
 int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                          const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
