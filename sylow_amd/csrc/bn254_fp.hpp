@@ -165,6 +165,71 @@ BN_DEV Fp fp_mul_inline(const Fp& a, const Fp& b) {
 
 BN_NOINLINE Fp fp_mul(Fp a, Fp b) { return fp_mul_inline(a, b); }
 
+// a*b mod p for plain (non-Montgomery) operands -- any 256-bit values -- by Barrett reduction (HAC 14.42, b = 2^32, k = 8,
+// mu = floor(2^512 / p), 9 limbs): T = a*b (64 products), q3 = top limbs of (T >> 224) * mu with the partial
+// products below column 7 dropped (53 products; the dropped mass is < 28 b^8, i.e. at most one unit of q3),
+// r = (T - q3*p) mod 2^288 (43 products) < 4p, then conditional subtraction of 2p and p.  160 multiply-adds
+// instead of the 256 of two Montgomery products: what the HBM-bound canonical-domain batch multiply uses.
+BN_DEV Fp fp_mulmod_plain(const Fp& a, const Fp& b) {
+  const u32 p[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+  const u32 mu[9] = {0x9bf90e51u, 0xf3aed8a1u, 0x7cd4c086u, 0xe965e176u, 0x8073013au, 0xb074a586u, 0x23a04a7au, 0x4a474626u, 0x00000005u};
+  u32 T[16];
+  u64 acc = 0;
+  u32 ovf = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+#pragma unroll
+    for (int i = (k > 7 ? k - 7 : 0); i <= (k < 7 ? k : 7); ++i) mac(acc, ovf, a.v[i], b.v[k - i]);
+    T[k] = (u32)acc;
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+  T[15] = (u32)acc;
+  // q1 = T[7..15] (9 limbs); q2 columns 7..17 of q1 * mu; q3 = columns 9..17 (9 limbs: operands may be any
+  // 256-bit values, like Fp::new accepts, so q can reach 2^259)
+  u32 q3[9];
+  acc = 0; ovf = 0;
+#pragma unroll
+  for (int k = 7; k < 18; ++k) {
+#pragma unroll
+    for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); ++i) mac_s(acc, ovf, T[7 + i], mu[k - i]);
+    if (k >= 9) q3[k - 9] = (u32)acc;
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+  // low 9 limbs of q3 * p
+  u32 qp[9];
+  acc = 0; ovf = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = (k > 7 ? k - 7 : 0); i <= k; ++i) mac_s(acc, ovf, q3[i], p[k - i]);
+    qp[k] = (u32)acc;
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+  // r = T[0..8] - qp[0..8] mod 2^288 (the true remainder is < 4p < 2^256, so limb 8 ends up 0)
+  u32 r[8];
+  u32 r8;
+  asm("v_sub_co_u32 %0, vcc, %9, %18\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %19, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %20, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %21, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %22, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %23, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %24, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %25, vcc\n\t"
+      "v_subb_co_u32 %8, vcc, %17, %26, vcc"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r8)
+      : "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6]), "v"(T[7]), "v"(T[8]),
+        "v"(qp[0]), "v"(qp[1]), "v"(qp[2]), "v"(qp[3]), "v"(qp[4]), "v"(qp[5]), "v"(qp[6]), "v"(qp[7]), "v"(qp[8])
+      : "vcc");
+  (void)r8;
+  cond_sub_const(r, 0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u, 0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2p
+  cond_sub_const(r, BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
+  return fp_from_limbs(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+}
+
 // (a*b + c*d) / R mod p in ONE column pass and ONE Montgomery reduction (lazy reduction at the Fp2 level):
 // for inputs <= p the sum is <= 2p^2 < p*R, so the reduced value is < 2p^2/R + p < 1.4p and a single
 // conditional subtraction is enough.  The 3-word column accumulator absorbs the extra products for free.

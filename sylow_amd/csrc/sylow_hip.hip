@@ -52,8 +52,8 @@ enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
 
 // HBM-bound kernels (96 B per element): each lane handles TWO adjacent elements so that every limb
 // plane is read / written with one 16-byte access per lane (1 KiB per wavefront instruction).
-// a*b for canonical inputs: mont(mont(a, R^2), b) = a*b, two Montgomery products per element.
-// add / sub / neg: inputs are reduced like Fp::new by conditional subtraction (no multiplications).
+// Inputs are reduced like Fp::new by conditional subtraction (no multiplications); a*b is then ONE Barrett
+// multiplication in the canonical domain (fp_mulmod_plain) -- no round trip through Montgomery form.
 BN_DEV void load_plain2(Fp& e0, Fp& e1, const u64* __restrict__ base, size_t n, size_t i) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -73,7 +73,7 @@ BN_DEV void store_plain2(u64* __restrict__ base, size_t n, size_t i, const Fp& e
 }
 template <int OP>
 BN_DEV Fp fp_binop_one(const Fp& x, const Fp& y) {
-  if (OP == OP_MUL) return fp_mul_inline(fp_mul_inline(x, fp_r2()), y);
+  if (OP == OP_MUL) return fp_mulmod_plain(x, y);      // Barrett takes any 256-bit operands
   Fp xr = fp_reduce_plain(x), yr = fp_reduce_plain(y);
   return (OP == OP_ADD) ? fp_add(xr, yr) : fp_sub(xr, yr);
 }
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, c
 }
 template <int OP>
 BN_DEV Fp fp_unop_one(const Fp& x) {
-  if (OP == OP_SQR) { Fp xm = fp_mul_inline(x, fp_r2()); return fp_from_mont(fp_mul_inline(xm, xm)); }
+  if (OP == OP_SQR) return fp_mulmod_plain(x, x);
   if (OP == OP_NEG) return fp_neg(fp_reduce_plain(x));
   return fp_from_mont(fp_inv(fp_to_mont(x)));
 }
