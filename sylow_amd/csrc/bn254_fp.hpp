@@ -332,6 +332,44 @@ BN_DEV Fp fp_halve(const Fp& a) {
   return r;
 }
 
+// (9a + s*b) mod p for s = +-1: the two coordinates of x*(9+u) (fp2.rs:99-107) as ONE multiply-by-9 pass instead of
+// five modular add/subs.  t = 9a + (s > 0 ? b : p - b) is a 9-word value < 10p; its quotient by p is estimated
+// from the top bits (h = t >> 250 <= 120, q^ = 677 h >> 13 is q or q-1 -- checked exhaustively over every h
+// boundary and every multiple of p in tools/check_mulxi_quotient.py), so r = t - q^ p < 2p and one conditional
+// subtraction finishes.  ~70 instructions instead of 120.
+template <bool ADD>
+BN_DEV Fp fp_mul9_addsub(const Fp& a, const Fp& b) {
+  const u32 p[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+  // w = ADD ? b : p - b   (in (0, p])
+  Fp w = ADD ? b : fp_neg_lazy(b);
+  // t = 9a + w, 9 words
+  u32 t[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc += (u64)a.v[i] * 9u + w.v[i];      // < 9*2^32 + 2^32 + carry: no overflow
+    t[i] = (u32)acc;
+    acc >>= 32;
+  }
+  t[8] = (u32)acc;                          // < 10
+  // q^ from the top bits: h = t >> 250 = (t[8] << 6) | (t[7] >> 26)
+  u32 h = (t[8] << 6) | (t[7] >> 26);
+  u32 q = (h * 677u) >> 13;
+  // r = t - q*p (fits 8 words: r < 2p)
+  u32 r[8];
+  u64 bor = 0;                              // running (q*p) carry and borrow folded: compute qp limb by limb
+  u64 mp = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    mp += (u64)q * p[i];
+    u64 d = (u64)t[i] - (u32)mp - bor;
+    r[i] = (u32)d;
+    bor = (d >> 32) & 1;
+    mp >>= 32;
+  }
+  return fp_cond_sub_p(r, 0);
+}
+
 // (a - b) mod p  (fp.rs:340-347)
 BN_DEV Fp fp_sub(const Fp& a, const Fp& b) {
   u32 d[8];

@@ -52,11 +52,9 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {
 // extensions.rs:86-94 with F = Fp
 BN_DEV Fp2 fp2_scale(const Fp2& a, const Fp& k) { return Fp2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
 BN_DEV Fp2 fp2_halve(const Fp2& a) { return Fp2{fp_halve(a.c0), fp_halve(a.c1)}; }   // == scale(TWO_INV)
-// x (9+u): (9a - b, a + 9b)  (fp2.rs:99-107); 9x = 8x + x by doublings
+// x (9+u): (9a - b, a + 9b)  (fp2.rs:99-107), one multiply-by-9 pass per coordinate
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {
-  Fp a8 = fp_dbl(fp_dbl(fp_dbl(a.c0)));
-  Fp b8 = fp_dbl(fp_dbl(fp_dbl(a.c1)));
-  return Fp2{fp_sub(fp_add(a8, a.c0), a.c1), fp_add(fp_add(b8, a.c1), a.c0)};
+  return Fp2{fp_mul9_addsub<false>(a.c0, a.c1), fp_mul9_addsub<true>(a.c1, a.c0)};
 }
 // fp2.rs:355-360: conj / (a0^2 + a1^2); inv(0) = 0
 BN_DEV Fp2 fp2_inv(const Fp2& a) {
