@@ -34,7 +34,6 @@ struct OpsFp {
   static BN_DEV F select(const F& a, const F& b, bool c) { return fp_select(a, b, c); }
   // 3*b = 9: x9 by doublings
   static BN_DEV F mul_b3(const F& a) { return fp_add(fp_dbl(fp_dbl(fp_dbl(a))), a); }
-  static BN_DEV F inv(const F& a) { return fp_inv(a); }
 };
 struct OpsFp2 {
   typedef Fp2 F;
@@ -47,7 +46,6 @@ struct OpsFp2 {
   static BN_DEV bool is_zero(const F& a) { return fp2_is_zero(a); }
   static BN_DEV F select(const F& a, const F& b, bool c) { return fp2_select(a, b, c); }
   static BN_DEV F mul_b3(const F& a) { return fp2_mul(a, fp2_const(C_TWIST_B3)); }
-  static BN_DEV F inv(const F& a) { return fp2_inv(a); }
 };
 
 template <class O> BN_DEV Proj<typename O::F> proj_zero() { return Proj<typename O::F>{O::zero(), O::one(), O::zero()}; }
@@ -121,25 +119,8 @@ BN_NOINLINE G1P g1_add(G1P p, G1P q) { return proj_add<OpsFp>(p, q); }
 BN_NOINLINE void g2_double(G2P& r, const G2P& p) { r = proj_double<OpsFp2>(p); }
 BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp2>(p, q); }
 
-// group.rs:639-667 + fp.rs:653-662: k*P by MSB-first signed-digit double-and-add over the
-// digits x3&c / xh&c of the scalar VALUE (an Fp, i.e. k < p; NOT reduced mod r -- SURVEY N4).
-// The leading zero digits only double the identity, so starting at the top set digit gives the
-// same projective value as the reference's 256 iterations.
-struct Naf { u32 np[8], nm[8]; };
-BN_DEV Naf compute_naf(const u32 k[8]) {
-  u32 xh[8], x3[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xh[i] = (k[i] >> 1) | (i < 7 ? (k[i + 1] << 31) : 0);
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { c += (u64)k[i] + xh[i]; x3[i] = (u32)c; c >>= 32; }
-  Naf n;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { u32 cc = xh[i] ^ x3[i]; n.np[i] = x3[i] & cc; n.nm[i] = xh[i] & cc; }
-  return n;
-}
 // k*P for the batch kernels: signed fixed-window (w = 4) double-and-add with a WAVE-UNIFORM schedule.
-// The reference walks the 256 NAF digits of k with a data-dependent add (group.rs:653-664); on a
+// The reference walks the 256 NAF digits of k (fp.rs:653-662) with a data-dependent add (group.rs:653-664); on a
 // 64-wide wavefront that makes every step pay for an addition (some lane always has a non-zero
 // digit).  Here every lane does 4 doublings + one complete addition of +-T[|d|] per window
 // (T[0] = identity: the RCB formulas are complete, so adding it is exact), 64 windows, table of
