@@ -90,6 +90,10 @@ int32_t sylow_hip_fp12_frobenius_batch(const uint64_t* a, int32_t exponent, uint
 /* Fp12::sparse_mul(ell_0, ell_vw, ell_vv): ell is [24][n] = (ell_0, ell_vw, ell_vv) as Fp2 each */
 int32_t sylow_hip_fp12_sparse_mul_batch(const uint64_t* f, const uint64_t* ell, uint64_t* out, size_t n, void* stream);
 
+/* test hook for the carry-free 9 x 29-bit core used inside the final exponentiation (csrc/bn254_f29.hpp):
+ * op 0: round trip; 1: a*b; 2: 2ab via the fused two-product pass; 3: 2a(b-a) through lazy add/sub + normalise */
+int32_t sylow_hip_f29_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+
 /* ---- groups: src/groups/group.rs, g1.rs, g2.rs ----------------------------------------------- */
 /* Mul<&Fp> for &G1Projective / &G2Projective (group.rs:639-667): out_i = k_i * P_i.
  * Points affine in (+ optional infinity flags), affine out + infinity flags (comparison is by

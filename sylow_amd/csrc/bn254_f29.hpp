@@ -1,0 +1,343 @@
+// Carry-free field core for the final-exponentiation hot loop: Fp elements as 9 signed limbs of 29 bits
+// (value = sum v[i] 2^(29 i)), Montgomery factor R' = 2^261.
+//
+// Why: in the saturated 8 x 32 form every partial product costs a v_mad_u64_u32 AND a v_addc (the mad has no
+// carry-in); with 29-bit limbs a 64-bit column accumulator absorbs a whole column (9 products of < 2^58, plus the
+// 9 reduction products) with no carry handling, so a product costs one mad -- measured 1.37x faster in isolation
+// (tools/ubench/f29_bench.hip) -- and add/sub are 9 limb-wise instructions with no reduction at all.
+//
+// Bounds discipline (all worst-case, not probabilistic).  L(x) = max_i<8 |x.v[i]| / 2^29, V(x) = |value| / p.
+//  * "normalized": v[0..7] in [0, 2^29), v[8] signed with |v[8]| < 2^28           (L <= 1)
+//  * lazy add/sub/neg: limb-wise, L and V add; a difference of two normalized values has L <= 1, a sum L <= 2;
+//    every limb must stay inside int32: L <= 3
+//  * f29_mul(a, b): requires 9 L(a) L(b) + 9 < 31.9, i.e. L(a) L(b) <= 2.5  (signed 64-bit columns);
+//    output normalized, value in (-(V(a)V(b)/169) p, (V(a)V(b)/169 + 1) p)  [p / 2^261 = 1/169.3]
+//  * every function states the bounds it needs; the builders of Fp2/Fp12 routines keep V <= 40 so that
+//    |v[8]| <= V p / 2^232 < 2^28 holds everywhere.
+// Values enter from / leave to the saturated Montgomery (R = 2^256) form through f29_from_fp / f29_to_fp, which
+// also change the Montgomery factor (x 2^5 in, exact / 2^5 out), so both cores compute the same residues and
+// every routine here is checked bit-for-bit against its saturated twin (tests/test_gpu_fields.py).
+#pragma once
+#include "bn254_tower.hpp"
+
+namespace bn254 {
+
+typedef int32_t i32;
+typedef int64_t i64;
+
+struct F29 { i32 v[9]; };
+#define BN_M29 0x1fffffff
+#define BN_PINV29 0x04866389u          // -p^-1 mod 2^29
+
+BN_DEV void f29_p(i32 (&p)[9]) {
+  p[0] = 0x187cfd47; p[1] = 0x010460b6; p[2] = 0x1c72a34f; p[3] = 0x02d522d0; p[4] = 0x1585d978;
+  p[5] = 0x02db40c0; p[6] = 0x00a6e141; p[7] = 0x0e5c2634; p[8] = 0x0030644e;
+}
+
+// ---- lazy linear operations (no carries, no reduction) -------------------------------------------------
+BN_DEV F29 f29_add(const F29& a, const F29& b) { F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r; }
+BN_DEV F29 f29_sub(const F29& a, const F29& b) { F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] - b.v[i];
+  return r; }
+BN_DEV F29 f29_neg(const F29& a) { F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = -a.v[i];
+  return r; }
+BN_DEV F29 f29_dbl(const F29& a) { return f29_add(a, a); }
+
+// carry propagation of a lazy value (any L <= 3): limbs 0..7 back into [0, 2^29), top limb keeps the sign
+BN_DEV F29 f29_norm(const F29& a) {
+  F29 r;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    i32 t = a.v[i] + c;
+    r.v[i] = t & BN_M29;
+    c = t >> 29;                 // arithmetic shift: floor
+  }
+  r.v[8] = a.v[8] + c;
+  return r;
+}
+
+// ---- Montgomery product, R' = 2^261 ----------------------------------------------------------------------
+// Column sums are split over two accumulators (merged once per column) so that consecutive multiply-adds are
+// independent.  Measured notes (A/B on one box, k_final_exp at n = 2^20): this loop executes 27 % fewer VALU
+// instructions than the saturated one but only runs 4.5 % faster -- it is multiply-add dense (54 % v_mad_*64)
+// and the chip clocks it at 2.07 GHz instead of 2.26 GHz (GRBM_GUI_ACTIVE / time): power-, not issue-limited.
+// Column-interleaving the two passes of an Fp2 product, or replacing the 64-bit shifts by v_alignbit, did not help.
+// requires L(a) L(b) <= 2.5; output normalized
+BN_DEV F29 f29_mul(const F29& a, const F29& b) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    i64 x = acc, y = 0;
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { if ((i - lo) & 1) y += (i64)a.v[i] * b.v[k - i]; else x += (i64)a.v[i] * b.v[k - i]; }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;                   // m[k] is not known yet
+      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+    }
+    acc = x + y;
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      acc += (i64)m[k] * p[0];
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+// (a*b + c*d) / R': one column pass, one reduction.  Requires 9 (L(a)L(b) + L(c)L(d)) + 9 < 31.9, i.e. all four
+// operands normalized (27 < 31.9).  Output normalized, value in (-(VaVb+VcVd)/169 p, ((VaVb+VcVd)/169 + 1) p).
+BN_DEV F29 f29_dot2(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    i64 x = acc, y = 0;
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { x += (i64)a.v[i] * b.v[k - i]; y += (i64)c.v[i] * d.v[k - i]; }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+    }
+    acc = x + y;
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      acc += (i64)m[k] * p[0];
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+
+// ---- conversions ---------------------------------------------------------------------------------------------
+// saturated Montgomery (x * 2^256, canonical 8 x 32) -> this core (x * 2^261): the digits of (X << 5).
+// Output normalized, value = 32 X in [0, 32 p): V <= 32.
+BN_DEV F29 f29_from_fp(const Fp& x) {
+  F29 r;
+  r.v[0] = (i32)((x.v[0] << 5) & BN_M29);
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    const int bit = 29 * i - 5;          // first source bit of digit i
+    const int w = bit >> 5, s = bit & 31;
+    u32 lo = x.v[w] >> s;
+    u32 hi = (s != 0 && w + 1 < 8) ? (x.v[w + 1] << (32 - s)) : 0u;
+    r.v[i] = (i32)((lo | hi) & BN_M29);
+  }
+  return r;
+}
+// this core -> saturated canonical Montgomery form.  Input normalized with value in (-64 p, 64 p).
+// v + 64 p >= 0; exact division by 32 (a 5-bit Montgomery step: add m p with m = -v p^-1 mod 32); the quotient is
+// < 5 p, reduced by conditional subtraction of 4p, 2p, p.
+BN_DEV Fp f29_to_fp(const F29& a) {
+  i32 p[9]; f29_p(p);
+  // digits of 64 p (p << 6), normalized: precomputed
+  const i32 k64[9] = {0x1f3f51c0, 0x01182db0, 0x1ca8d3c2, 0x1548b438, 0x01765e05, 0x16d0302b, 0x09b85045, 0x17098d01, 0x0c19139c};
+  // m = (-(v + 64p) * p^-1) mod 32, from the low limb
+  u32 low = (u32)(a.v[0] + k64[0]);
+  u32 m = (low * BN_PINV29) & 31u;
+  // w = (a + 64 p + m p) as normalized digits, then >> 5 while re-packing into 32-bit words
+  i64 acc = 0;
+  u32 d[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    acc += (i64)a.v[i] + k64[i] + (i64)m * p[i];
+    if (i < 8) { d[i] = (u32)acc & BN_M29; acc >>= 29; } else d[i] = (u32)acc;
+  }
+  // value = sum d[i] 2^(29 i), divisible by 32; out = value >> 5 (< 5p < 2^257: 9th word may hold one bit)
+  u32 o[9];
+#pragma unroll
+  for (int w = 0; w < 9; ++w) o[w] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i - 5;          // destination bit of digit i (digit 0 loses its low 5 zero bits)
+    if (i == 0) { o[0] |= d[0] >> 5; continue; }
+    const int w = bit >> 5, s = bit & 31;
+    o[w] |= d[i] << s;
+    if (s > 3 && w + 1 < 9) o[w + 1] |= d[i] >> (32 - s);     // a 29-bit digit (32-bit for the top one) spills past the word when s > 3
+  }
+  u32 r[8] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+  // o[8] can only be 0 or 1 (value < 5p < 2^257); fold it in by subtracting 4p first using the 9-word compare
+  // 4p = 0xc19139cb... < 2^256: if o[8] is set the value is >= 2^256 > 4p, so subtract 4p unconditionally then
+  {
+    u32 s4[8];
+    u32 bor;
+    const u32 c0 = 0x61f3f51cu, c1 = 0xf082305bu, c2 = 0xa1c72a34u, c3 = 0x5e05aa45u, c4 = 0x06056176u, c5 = 0xe14116dau, c6 = 0x84c680a6u, c7 = 0xc19139cbu;
+    asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_subb_co_u32 %8, vcc, %25, 0, vcc"
+        : "=&v"(s4[0]), "=&v"(s4[1]), "=&v"(s4[2]), "=&v"(s4[3]), "=&v"(s4[4]), "=&v"(s4[5]), "=&v"(s4[6]), "=&v"(s4[7]), "=&v"(bor)
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(c0), "v"(c1), "v"(c2), "v"(c3),
+          "v"(c4), "v"(c5), "v"(c6), "v"(c7), "v"(o[8])
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bor != 0) ? r[i] : s4[i];
+  }
+  cond_sub_const(r, 0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u, 0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2p
+  cond_sub_const(r, BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
+  return fp_from_limbs(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+}
+
+
+// ---- reduce-and-normalise pass ------------------------------------------------------------------------------------
+// Lazy linear combinations keep the LIMBS small but not the VALUE (3t - 2z doubles the bound every squaring), so
+// stored results go through one pass that subtracts q p with q = round(value / p) estimated from the top limb and
+// propagates carries at the same time: r normalised, |value(r)| < 0.51 p.
+// `limb(i)` returns limb i of the lazy combination as int64; requirements: |limb(i)| < 2^36 for i < 8 and
+// |limb(8)| < 2^31.  Estimate accuracy: value / 2^232 = limb(8) + eps with |eps| < 2^8, p / 2^232 = 3171406.4,
+// K = floor(2^44 / 3171406): |value - q p| < p/2 + (2^8 + 1) 2^232 + 2^-13 p < 0.51 p.
+template <class LIMB>
+BN_DEV F29 f29_reduce_from(LIMB limb) {
+  i32 p[9]; f29_p(p);
+  const i64 t8 = limb(8);
+  const i64 q = (t8 * 5547168ll + (1ll << 43)) >> 44;
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc += limb(i) - q * p[i];
+    r.v[i] = (i32)((u32)acc & BN_M29);
+    acc >>= 29;
+  }
+  r.v[8] = (i32)(acc + t8 - q * p[8]);
+  return r;
+}
+
+// ---- Fp2 on the carry-free core ---------------------------------------------------------------------------------------
+struct U2 { F29 c0, c1; };
+BN_DEV U2 u2_add(const U2& a, const U2& b) { return U2{f29_add(a.c0, b.c0), f29_add(a.c1, b.c1)}; }
+BN_DEV U2 u2_sub(const U2& a, const U2& b) { return U2{f29_sub(a.c0, b.c0), f29_sub(a.c1, b.c1)}; }
+BN_DEV U2 u2_norm(const U2& a) { return U2{f29_norm(a.c0), f29_norm(a.c1)}; }
+// (a0 b0 - a1 b1, a0 b1 + a1 b0): two fused passes.  Inputs: |limbs| < 2^29 (signs free), |V| <= 8 -> |V(out)| < 1.8
+BN_DEV U2 u2_mul(const U2& a, const U2& b) {
+  return U2{f29_dot2(a.c0, b.c0, f29_neg(a.c1), b.c1), f29_dot2(a.c0, b.c1, a.c1, b.c0)};
+}
+// ((a0+a1)(a0-a1), 2 a0 a1).  Input limbs in [0, 2^29) (so that a0 - a1 has |limbs| < 2^29), |V| <= 4
+BN_DEV U2 u2_sqr(const U2& a) {
+  return U2{f29_mul(f29_add(a.c0, a.c1), f29_sub(a.c0, a.c1)), f29_mul(f29_dbl(a.c0), a.c1)};
+}
+// reduce-and-normalise of  k * x + xi_flag * (xi * y) + z  style combinations, written out per use below
+// r = reduce(ka * a + kb * b)
+BN_DEV F29 f29_lin2(const F29& a, int ka, const F29& b, int kb) {
+  return f29_reduce_from([&](int i) { return (i64)a.v[i] * ka + (i64)b.v[i] * kb; });
+}
+BN_DEV U2 u2_lin2(const U2& a, int ka, const U2& b, int kb) { return U2{f29_lin2(a.c0, ka, b.c0, kb), f29_lin2(a.c1, ka, b.c1, kb)}; }
+// r = reduce(k * xi * x + m * y),  xi = 9 + u:  (9 x0 - x1, x0 + 9 x1).   |x limbs|, |y limbs| < 2^31
+BN_DEV U2 u2_xi_lin(const U2& x, int k, const U2& y, int m) {
+  return U2{f29_reduce_from([&](int i) { return ((i64)x.c0.v[i] * 9 - x.c1.v[i]) * k + (i64)y.c0.v[i] * m; }),
+            f29_reduce_from([&](int i) { return ((i64)x.c0.v[i] + (i64)x.c1.v[i] * 9) * k + (i64)y.c1.v[i] * m; })};
+}
+
+// ---- Fp6 / Fp12 values in scratch: 6 Fp2 coefficients z-ordered like Fp12 (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2)
+struct U6 { U2 c0, c1, c2; };
+struct U12 { U6 c0, c1; };
+BN_DEV U2 u2_from_fp2(const Fp2& a) { return U2{f29_from_fp(a.c0), f29_from_fp(a.c1)}; }
+BN_DEV Fp2 u2_to_fp2(const U2& a) { return Fp2{f29_to_fp(a.c0), f29_to_fp(a.c1)}; }
+BN_DEV void u12_from_fp12(U12& r, const Fp12& a) {
+  r.c0.c0 = u2_from_fp2(a.c0.c0); r.c0.c1 = u2_from_fp2(a.c0.c1); r.c0.c2 = u2_from_fp2(a.c0.c2);
+  r.c1.c0 = u2_from_fp2(a.c1.c0); r.c1.c1 = u2_from_fp2(a.c1.c1); r.c1.c2 = u2_from_fp2(a.c1.c2);
+}
+BN_DEV void u12_to_fp12(Fp12& r, const U12& a) {
+  r.c0.c0 = u2_to_fp2(a.c0.c0); r.c0.c1 = u2_to_fp2(a.c0.c1); r.c0.c2 = u2_to_fp2(a.c0.c2);
+  r.c1.c0 = u2_to_fp2(a.c1.c0); r.c1.c1 = u2_to_fp2(a.c1.c1); r.c1.c2 = u2_to_fp2(a.c1.c2);
+}
+// values entering from the saturated core have V <= 32 (f29_from_fp); one reduce pass brings them to |V| < 0.51
+BN_DEV void u12_reduce(U12& r) {
+  U2* c[6] = {&r.c0.c0, &r.c0.c1, &r.c0.c2, &r.c1.c0, &r.c1.c1, &r.c1.c2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const U2 t = *c[k];
+    c[k]->c0 = f29_reduce_from([&](int i) { return (i64)t.c0.v[i]; });
+    c[k]->c1 = f29_reduce_from([&](int i) { return (i64)t.c1.v[i]; });
+  }
+}
+// conjugate (fp12.rs:381-383): negated limbs are fine as product operands (|limbs| < 2^29)
+BN_DEV void u12_conj(U12& r, const U12& a) {
+  r.c0 = a.c0;
+  r.c1.c0 = U2{f29_neg(a.c1.c0.c0), f29_neg(a.c1.c0.c1)};
+  r.c1.c1 = U2{f29_neg(a.c1.c1.c0), f29_neg(a.c1.c1.c1)};
+  r.c1.c2 = U2{f29_neg(a.c1.c2.c0), f29_neg(a.c1.c2.c1)};
+}
+
+// fp6.rs:283-367 (value), Karatsuba over v with normalised pre-additions.  Inputs: |limbs| < 2^29, |V| <= 1.8.
+// Outputs reduced: limbs in [0, 2^29), |V| < 0.51.
+BN_NOINLINE void u6_mul(U6& r, const U6& a, const U6& b) {
+  const U2 v0 = u2_mul(a.c0, b.c0);
+  const U2 v1 = u2_mul(a.c1, b.c1);
+  const U2 v2 = u2_mul(a.c2, b.c2);
+  const U2 t0 = u2_mul(u2_norm(u2_add(a.c1, a.c2)), u2_norm(u2_add(b.c1, b.c2)));
+  const U2 t1 = u2_mul(u2_norm(u2_add(a.c0, a.c1)), u2_norm(u2_add(b.c0, b.c1)));
+  const U2 t2 = u2_mul(u2_norm(u2_add(a.c0, a.c2)), u2_norm(u2_add(b.c0, b.c2)));
+  // r0 = v0 + xi (t0 - v1 - v2);  r1 = (t1 - v0 - v1) + xi v2;  r2 = t2 - v0 - v2 + v1
+  const U2 x0 = u2_sub(u2_sub(t0, v1), v2);            // limbs in (-2^30, 2^29)
+  r.c0 = u2_xi_lin(x0, 1, v0, 1);
+  const U2 y1 = u2_sub(u2_sub(t1, v0), v1);
+  r.c1 = u2_xi_lin(v2, 1, y1, 1);
+  const U2 y2 = u2_add(u2_sub(u2_sub(t2, v0), v2), v1); // limbs in (-2^30, 2^30)
+  r.c2 = U2{f29_reduce_from([&](int i) { return (i64)y2.c0.v[i]; }), f29_reduce_from([&](int i) { return (i64)y2.c1.v[i]; })};
+}
+// fp12.rs:229-238 (value).  Inputs/outputs as u6_mul.
+BN_NOINLINE void u12_mul(U12& r, const U12& a, const U12& b) {
+  U6 t0, t1, t2, sa, sb;
+  u6_mul(t0, a.c0, b.c0);
+  u6_mul(t1, a.c1, b.c1);
+  sa.c0 = u2_norm(u2_add(a.c0.c0, a.c1.c0)); sa.c1 = u2_norm(u2_add(a.c0.c1, a.c1.c1)); sa.c2 = u2_norm(u2_add(a.c0.c2, a.c1.c2));
+  sb.c0 = u2_norm(u2_add(b.c0.c0, b.c1.c0)); sb.c1 = u2_norm(u2_add(b.c0.c1, b.c1.c1)); sb.c2 = u2_norm(u2_add(b.c0.c2, b.c1.c2));
+  u6_mul(t2, sa, sb);                                   // |V(sa)|, |V(sb)| <= 1.1 (two reduced values)... or 3.6: both fine for u2_mul
+  // c1 = t2 - t0 - t1
+  r.c1.c0 = u2_lin2(u2_sub(t2.c0, t0.c0), 1, t1.c0, -1);
+  r.c1.c1 = u2_lin2(u2_sub(t2.c1, t0.c1), 1, t1.c1, -1);
+  r.c1.c2 = u2_lin2(u2_sub(t2.c2, t0.c2), 1, t1.c2, -1);
+  // c0 = t0 + v * t1 = (t0.c0 + xi t1.c2, t0.c1 + t1.c0, t0.c2 + t1.c1)
+  r.c0.c0 = u2_xi_lin(t1.c2, 1, t0.c0, 1);
+  r.c0.c1 = u2_lin2(t0.c1, 1, t1.c0, 1);
+  r.c0.c2 = u2_lin2(t0.c2, 1, t1.c1, 1);
+}
+// pairing.rs:274-350: Granger-Scott squaring in the cyclotomic subgroup.  Input: reduced (limbs in [0,2^29), |V| < 0.51)
+// or any nonneg-limbed value with |V| <= 1.1; output reduced.
+BN_DEV void u_fp4_square(U2& c0, U2& c1, const U2& a, const U2& b) {
+  const U2 t0 = u2_sqr(a);
+  const U2 t1 = u2_sqr(b);
+  c0 = u2_xi_lin(t1, 1, t0, 1);                                        // xi t1 + t0, reduced
+  c1 = u2_sub(u2_sub(u2_sqr(u2_norm(u2_add(a, b))), t0), t1);         // lazy, limbs in (-2^30, 2^29), |V| < 4
+}
+BN_NOINLINE void u12_cyclotomic_sqr(U12& r, const U12& f) {
+  const U2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  U2 t0, t1, t2, t3;
+  u_fp4_square(t0, t1, z0, z1);
+  r.c0.c0 = u2_lin2(t0, 3, z0, -2);                                    // z0 = 3 t0 - 2 z0
+  r.c1.c1 = u2_lin2(t1, 3, z1, 2);                                     // z1 = 3 t1 + 2 z1
+  u_fp4_square(t0, t1, z2, z3);
+  u_fp4_square(t2, t3, z4, z5);
+  r.c0.c1 = u2_lin2(t0, 3, z4, -2);                                    // z4 = 3 t0 - 2 z4
+  r.c1.c2 = u2_lin2(t1, 3, z5, 2);                                     // z5 = 3 t1 + 2 z5
+  r.c1.c0 = u2_xi_lin(t3, 3, z2, 2);                                   // z2 = 3 xi t3 + 2 z2
+  r.c0.c2 = u2_lin2(t2, 3, z3, -2);                                    // z3 = 3 t2 - 2 z3
+}
+
+}  // namespace bn254

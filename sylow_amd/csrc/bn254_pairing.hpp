@@ -11,7 +11,7 @@
 //    the line coefficients are consumed on the fly instead of being materialised as the
 //    reference's [Ell; 87] table (16.8 KB per point, pairing.rs:556).
 #pragma once
-#include "bn254_tower.hpp"
+#include "bn254_f29.hpp"
 
 namespace bn254 {
 
@@ -316,7 +316,8 @@ BN_NOINLINE void cyclotomic_sqr(Fp12& r, const Fp12& f) {
 #define BN_X_W3_NZ 0x4908924444891211ull   // bit i set iff digit i != 0        (x = sum d_i 2^i, top digit d_62 = +1)
 #define BN_X_W3_NEG 0x0108000400880210ull  // digit i negative
 #define BN_X_W3_THREE 0x0108804404880200ull  // |digit i| == 3
-BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
+// saturated-core version (kept as the test twin of the carry-free one below)
+BN_NOINLINE void exp_by_neg_z_sat(Fp12& r, const Fp12& f) {
   Fp12 f3, res, t;
   cyclotomic_sqr(t, f);
   fp12_mul(f3, t, f);
@@ -332,6 +333,28 @@ BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
     }
   }
   fp12_conj(r, res);
+}
+// The same chain on the carry-free 9 x 29-bit core (bn254_f29.hpp): f is converted once, the 62 cyclotomic
+// squarings and 18 products run without carry handling or modular add/subs, the result is converted back.
+BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
+  U12 uf, uf3, res, t;
+  u12_from_fp12(uf, f);
+  u12_reduce(uf);
+  u12_cyclotomic_sqr(t, uf);
+  u12_mul(uf3, t, uf);
+  res = uf;
+  const u64 nz = BN_X_W3_NZ, ng = BN_X_W3_NEG, th = BN_X_W3_THREE;
+#pragma unroll 1
+  for (int i = 61; i >= 0; --i) {
+    u12_cyclotomic_sqr(res, res);
+    if ((nz >> i) & 1) {
+      const U12& m = ((th >> i) & 1) ? uf3 : uf;
+      if ((ng >> i) & 1) { u12_conj(t, m); u12_mul(res, res, t); }
+      else u12_mul(res, res, m);
+    }
+  }
+  u12_conj(t, res);
+  u12_to_fp12(r, t);
 }
 // pairing.rs:245-492: easy part (:410), hard part (:437, Fuentes-Castaneda chain)
 BN_NOINLINE void final_exponentiation(Fp12& out, const Fp12& fin) {

@@ -131,7 +131,8 @@ __global__ void HEAVY_BOUNDS k_fp6_op(int op, const u64* a, const u64* b, u64* o
   else fp6_inv(r, x);
   store_fp6(out, n, i, 0, r);
 }
-enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROB1 = 3, OP12_FROB2 = 4, OP12_FROB3 = 5, OP12_SPARSE = 6, OP12_CYCSQR = 7 };
+enum { OP12_MUL = 0, OP12_SQR = 1, OP12_INV = 2, OP12_FROB1 = 3, OP12_FROB2 = 4, OP12_FROB3 = 5, OP12_SPARSE = 6, OP12_CYCSQR = 7,
+       OP12_U_MUL = 8, OP12_U_CYCSQR = 9, OP12_EXPZ = 10, OP12_EXPZ_SAT = 11 };
 __global__ void HEAVY_BOUNDS k_fp12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
   size_t i = TID;
   if (i >= n) return;
@@ -145,6 +146,10 @@ __global__ void HEAVY_BOUNDS k_fp12_op(int op, const u64* a, const u64* b, u64* 
     case OP12_FROB2: fp12_frobenius<2>(r, x); break;
     case OP12_FROB3: fp12_frobenius<3>(r, x); break;
     case OP12_CYCSQR: cyclotomic_sqr(r, x); break;
+    case OP12_U_MUL: { load_fp12(y, b, n, i); U12 ux, uy, ur; u12_from_fp12(ux, x); u12_reduce(ux); u12_from_fp12(uy, y); u12_reduce(uy); u12_mul(ur, ux, uy); u12_to_fp12(r, ur); break; }
+    case OP12_U_CYCSQR: { U12 ux, ur; u12_from_fp12(ux, x); u12_reduce(ux); u12_cyclotomic_sqr(ur, ux); u12_to_fp12(r, ur); break; }
+    case OP12_EXPZ: exp_by_neg_z(r, x); break;
+    case OP12_EXPZ_SAT: exp_by_neg_z_sat(r, x); break;
     default: {
       Fp2 l0 = load_fp2(b, n, i, 0), lvw = load_fp2(b, n, i, 8), lvv = load_fp2(b, n, i, 16);
       fp12_sparse_mul(r, x, l0, lvw, lvv);
@@ -816,6 +821,25 @@ __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t
   status[i] = st;
 }
 
+
+// test hook for the carry-free core (bn254_f29.hpp): op 0: to_fp(from_fp(a)) (must be a); 1: product through
+// f29_mul; 2: a*b + b*a through f29_dot2; 3: lazy (a + b) - b + a normalised then * 1 ... all compared with the
+// saturated core by tests/test_gpu_fields.py
+__global__ void __launch_bounds__(BLOCK) k_f29_hook(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp x = load_fp(a, n, i, 0), y = load_fp(b, n, i, 0), r;
+  F29 fx = f29_from_fp(x), fy = f29_from_fp(y);
+  if (op == 0) r = f29_to_fp(fx);
+  else if (op == 1) r = f29_to_fp(f29_mul(fx, fy));
+  else if (op == 2) r = f29_to_fp(f29_dot2(fx, fy, fy, fx));
+  else {
+    F29 t = f29_norm(f29_sub(f29_add(f29_add(fx, fy), fx), fy));     // 2x as a lazy value (L <= 3), normalised
+    r = f29_to_fp(f29_mul(t, f29_sub(fy, fx)));                        // 2x * (y - x)
+  }
+  store_fp(out, n, i, 0, r);
+}
+
 // ------------------------------------------------------------------ layout helpers --------------
 __global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
   size_t t = TID;
@@ -934,6 +958,11 @@ int32_t sylow_hip_fp12_sparse_mul_batch(const uint64_t* f, const uint64_t* ell, 
 int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_CYCSQR, a, nullptr, out, n); LAUNCHED();
 }
+// test hook: raw k_fp12_op selector (8: product on the carry-free core, 9: cyclotomic square on it,
+// 10 / 11: exp_by_neg_z on the carry-free / saturated core)
+int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out && op >= 0 && op <= 11); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
+}
 
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
@@ -1005,6 +1034,8 @@ static int32_t ensure_g2gen_lines(void* stream) {
     k_g2_lines<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, nullptr);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return fail(e_, "k_g2_lines launch");
+    // one-time: later calls may run on other streams, so the table must be complete before we report it ready
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     ready[dev] = true;
   }
   return SYLOW_HIP_OK;
@@ -1090,6 +1121,12 @@ int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_in
 }
 int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
   ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g2_from_bytes<<<GRID(n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
+}
+
+// test hook (see k_f29_hook)
+int32_t sylow_hip_f29_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;
+  k_f29_hook<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));

@@ -131,6 +131,26 @@ class Engine:
     def fp12_inv(self, a): return self._unop("sylow_hip_fp12_inv_batch", 48, a)
     def fp12_frobenius(self, a, e): return self._unop("sylow_hip_fp12_frobenius_batch", 48, a, int(e))
 
+    def f29_hook(self, op, a, b):
+        a, b = _aos(a, 4), _aos(b, 4)
+        n = a.shape[0]
+        da, db = self.to_device_soa(a, 4), self.to_device_soa(b, 4)
+        do = self.empty((4, n))
+        self._call("sylow_hip_f29_hook_batch", int(op), da.ptr, db.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
+    def fp12_hook(self, op, a, b=None):
+        fn = self.lib.sylow_hip_fp12_hook_batch
+        fn.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        fn.restype = ctypes.c_int32
+        a = _aos(a, 48)
+        n = a.shape[0]
+        da = self.to_device_soa(a, 48)
+        db = self.to_device_soa(_aos(b, 48), 48) if b is not None else None
+        do = self.empty((48, n))
+        self._call("sylow_hip_fp12_hook_batch", int(op), da.ptr, self._ptr(db), do.ptr, n)
+        return self.from_device_soa(do)
+
     def fp12_cyclotomic_sqr(self, a):
         fn = self.lib.sylow_hip_fp12_cyclotomic_sqr_batch
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

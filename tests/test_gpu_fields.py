@@ -94,3 +94,47 @@ def test_fp12_algebraic_properties_full_size(engine):
     one = np.zeros((n, 48), dtype=np.uint64)
     one[:, 0] = 1
     assert np.array_equal(engine.fp12_mul(a, ainv), one)
+
+
+def test_f29_core_vs_saturated_core(engine):
+    """The carry-free 9 x 29-bit core (csrc/bn254_f29.hpp) against exact integer arithmetic, edge values included."""
+    rng = Xoshiro(SEED + 5)
+    va = [a for a in EDGE for _ in EDGE] + [rng.fp() for _ in range(4000)]
+    vb = [b for _ in EDGE for b in EDGE] + [rng.fp() for _ in range(4000)]
+    a, b = limbs(va), limbs(vb)
+    va, vb = [x % P for x in va], [x % P for x in vb]
+    assert ints(engine.f29_hook(0, a, b)) == va
+    assert ints(engine.f29_hook(1, a, b)) == [x * y % P for x, y in zip(va, vb)]
+    assert ints(engine.f29_hook(2, a, b)) == [2 * x * y % P for x, y in zip(va, vb)]
+    assert ints(engine.f29_hook(3, a, b)) == [2 * x * (y - x) % P for x, y in zip(va, vb)]
+
+
+def test_f29_tower_vs_saturated_tower(engine, coracle):
+    """Fp12 product, cyclotomic square and f^x on the carry-free core vs the saturated core and the oracle."""
+    n = 1024
+    a12, b12 = fast_rand_fp_array(21, n, 12), fast_rand_fp_array(22, n, 12)
+    assert np.array_equal(engine.fp12_hook(8, a12, b12), coracle.fp12_op("mul", a12, b12))
+    # cyclotomic formulas are defined on any Fp12 input (they just are not a square outside the subgroup): compare as maps
+    assert np.array_equal(engine.fp12_hook(9, a12), coracle.fp12_op("cyclotomic_squared", a12))
+    # elements of the cyclotomic subgroup: pairing values
+    rng = Xoshiro(SEED + 6)
+    G1 = [1, 2]
+    G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED, 0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2,
+          0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA, 0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B]
+    m = 64
+    p_xy, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), m, 0), limbs([rng.fp() for _ in range(m)]))
+    gt = engine.pairing(p_xy, np.repeat(pack(G2, 16), m, 0))
+    assert np.array_equal(engine.fp12_hook(9, gt), engine.fp12_sqr(gt))          # in the subgroup the GS formula IS the square
+    ez, ez_sat = engine.fp12_hook(10, gt), engine.fp12_hook(11, gt)
+    assert np.array_equal(ez, ez_sat)
+    # f^x conjugated: check against plain square-and-multiply through the oracle's product
+    x = 4965661367192848881
+    acc = gt.copy()
+    for bit in bin(x)[3:]:
+        acc = coracle.fp12_op("sqr", acc)
+        if bit == "1":
+            acc = coracle.fp12_op("mul", acc, gt)
+    assert np.array_equal(ez, coracle.fp12_op("conj", acc))
+    # edge: the identity and zero
+    z = np.zeros((2, 48), dtype=np.uint64); z[0, 0] = 1
+    assert np.array_equal(engine.fp12_hook(10, z), z) and np.array_equal(engine.fp12_hook(8, z, z), z)
