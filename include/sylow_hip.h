@@ -105,6 +105,14 @@ int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
 /* Add for &G1Projective (group.rs:528-599) on affine inputs, affine output */
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* Add for &G2Projective, GroupProjective::double for G1 / G2 (group.rs:528-599, 339-386), affine in / out */
+int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
+                               uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* Mul<&Fr> for &Gt (groups/gt.rs:161-187): out_i = gt_i "times" k_i, i.e. gt_i^k_i in Fp12, by the reference's own
+ * 256-step signed-digit square-and-multiply (negative digits multiply by the conjugate).  k: Fr values, [4][n]. */
+int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream);
 /* GroupAffine::from(&GroupProjective) (group.rs:475-495) */
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);

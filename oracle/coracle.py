@@ -237,6 +237,13 @@ def glued_pairing(p_proj, q_proj, offsets):
     return out
 
 
+def gt_pow(g, k):
+    g, k = _u64(g, 48), _u64(k, 4)
+    out = np.empty_like(g)
+    lib().oracle_gt_pow(_p(g), _p(k), _p(out), ctypes.c_size_t(g.shape[0]))
+    return out
+
+
 # ---- hashing / BLS -------------------------------------------------------------------------
 def keccak256(msg: bytes) -> bytes:
     out = ctypes.create_string_buffer(32)

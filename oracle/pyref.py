@@ -795,6 +795,20 @@ def glued_pairing(g1s, g2s):
     return final_exponentiation(glued_miller_loop([g2_precompute(q) for q in a2], a1))
 
 
+def gt_pow(g, k: int):
+    """Mul<&Fr> for &Gt (gt.rs:161-187): NAF square-and-multiply, negative digits use the unitary inverse."""
+    np_, nm_ = compute_naf(k)
+    res = FP12_ONE
+    ng = fp12_unitary_inverse(g)
+    for i in range(255, -1, -1):
+        res = fp12_square(res)
+        if (np_ >> i) & 1:
+            res = fp12_mul(res, g)
+        elif (nm_ >> i) & 1:
+            res = fp12_mul(res, ng)
+    return res
+
+
 # --- SvdW: src/svdw.rs ---------------------------------------------------------------------
 def svdw_constants():
     """svdw.rs:123-153 with a = 0, b = 3, Z = 1 (find_z_svdw, svdw.rs:81-111)."""

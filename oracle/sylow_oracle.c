@@ -905,6 +905,25 @@ API void oracle_glued_pairing(const u64 *p, const u64 *q, const u64 *off, u64 *o
     free(ps); free(cs);
   }
 }
+/* Mul<&Fr> for &Gt (gt.rs:161-187): 256-step NAF square-and-multiply; "-" is the unitary inverse (conjugate) */
+API void oracle_gt_pow(const u64 *g, const u64 *k, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t e = 0; e < n; ++e) {
+    fp12 a = ld12(g + 48 * e), na = fp12_conj(a), res = FP12_ONE_C;
+    const u64 *kk = k + 4 * e;
+    u64 xh[4], x3[4], np[4], nm[4];
+    for (int i = 0; i < 4; ++i) xh[i] = (kk[i] >> 1) | (i < 3 ? kk[i + 1] << 63 : 0);
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)kk[i] + xh[i]; x3[i] = (u64)c; c >>= 64; }
+    for (int i = 0; i < 4; ++i) { u64 cc = xh[i] ^ x3[i]; np[i] = x3[i] & cc; nm[i] = xh[i] & cc; }
+    for (int i = 255; i >= 0; --i) {
+      res = fp12_sqr(res);
+      if ((np[i >> 6] >> (i & 63)) & 1) res = fp12_mul(res, a);
+      else if ((nm[i >> 6] >> (i & 63)) & 1) res = fp12_mul(res, na);
+    }
+    st12(out + 48 * e, res);
+  }
+}
 API void oracle_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]) {
   keccak_ctx c; keccak_init(&c); keccak_update(&c, msg, len); keccak_final(&c, out);
 }

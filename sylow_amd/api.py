@@ -105,6 +105,10 @@ class G1Affine(_Points):
         y = engine().fp_neg(self.xy[:, 4:])
         return G1Affine(np.concatenate([self.xy[:, :4], y], axis=1), self.infinity)
 
+    def double(self):                              # GroupProjective::double (group.rs:339-386)
+        xy, inf = engine().g1_double(self.xy, self.infinity)
+        return G1Affine(xy, inf)
+
 
 G1Projective = G1Affine   # results are compared after normalisation: one batch type serves both names
 
@@ -138,6 +142,14 @@ class G2Affine(_Points):
         y = np.concatenate([engine().fp_neg(self.xy[:, 8:12]), engine().fp_neg(self.xy[:, 12:16])], axis=1)
         return G2Affine(np.concatenate([self.xy[:, :8], y], axis=1), self.infinity)
 
+    def __add__(self, other):
+        xy, inf = engine().g2_add(self.xy, other.xy, self.infinity, other.infinity)
+        return G2Affine(xy, inf)
+
+    def double(self):
+        xy, inf = engine().g2_double(self.xy, self.infinity)
+        return G2Affine(xy, inf)
+
     def precompute(self) -> "G2PreComputed":        # pairing.rs:676
         return G2PreComputed(self)
 
@@ -165,6 +177,14 @@ class Gt:
 
     def __add__(self, other):                      # gt.rs: Add = Fp12 multiplication
         return Gt(engine().fp12_mul(self.v, other.v))
+
+    def __neg__(self):                             # gt.rs:107-114: unitary inverse (conjugate)
+        v = self.v.copy()
+        v[:, 24:] = np.concatenate([engine().fp_neg(self.v[:, 24 + 4 * j:28 + 4 * j]) for j in range(6)], axis=1)
+        return Gt(v)
+
+    def __mul__(self, k):                          # Mul<&Fr> (gt.rs:161-187); k: Fr values [n, 4]
+        return Gt(engine().gt_pow(self.v, k))
 
 
 class MillerLoopResult:

@@ -840,6 +840,86 @@ __global__ void __launch_bounds__(BLOCK) k_f29_hook(int op, const u64* a, const 
   store_fp(out, n, i, 0, r);
 }
 
+
+// ------------------------------------------------------------------ f4: Gt * Fr, G2 add, doublings ---------
+// Mul<&Fr> for &Gt (gt.rs:161-187): the reference's own algorithm -- 256-step signed-digit square-and-multiply
+// on generic Fp12 squares (Gt::double = Fp12::square, gt.rs:268-270), negative digits multiply by the conjugate
+// -- so the value matches even for inputs outside the cyclotomic subgroup.  The scalar is the Fr VALUE.
+__global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp12 a, na, buf[2];
+  load_fp12(a, g, n, i);
+  fp12_conj(na, a);
+  // digits of fp.rs:653-662 on the raw 256-bit scalar (Fr values are < r < p: no reduction involved)
+  u32 k[8], xh[8], x3[8], np[8], nm[8];
+  {
+    Fp kp = load_plain(ks, n, i, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = kp.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xh[j] = (k[j] >> 1) | (j < 7 ? (k[j + 1] << 31) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
+  int cur = 0;
+  fp12_set_one(buf[0]);
+  // wave-uniform schedule: every lane squares and multiplies each step; lanes whose digit is zero multiply by one
+  Fp12 one;
+  fp12_set_one(one);
+#pragma unroll 1
+  for (int b = 255; b >= 0; --b) {
+    fp12_sqr(buf[cur ^ 1], buf[cur]); cur ^= 1;
+    const bool bp = (np[b >> 5] >> (b & 31)) & 1, bm = (nm[b >> 5] >> (b & 31)) & 1;
+    if (__any(bp || bm)) {
+      Fp12 m;
+      const Fp12& src = bp ? a : na;
+      // select per lane: a, conj(a) or one
+      m.c0 = (bp || bm) ? src.c0 : one.c0;
+      m.c1 = (bp || bm) ? src.c1 : one.c1;
+      fp12_mul(buf[cur ^ 1], buf[cur], m); cur ^= 1;
+    }
+  }
+  store_fp12(out, n, i, buf[cur]);
+}
+__global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G2P a{load_fp2(axy, n, i, 0), load_fp2(axy, n, i, 8), (ainf && ainf[i]) ? fp2_zero() : fp2_one()};
+  G2P b{load_fp2(bxy, n, i, 0), load_fp2(bxy, n, i, 8), (binf && binf[i]) ? fp2_zero() : fp2_one()};
+  G2P r;
+  g2_add(r, a, b);
+  Fp2 x, y; bool rinf;
+  g2_to_affine(x, y, rinf, r);
+  store_fp2(oxy, n, i, 0, x); store_fp2(oxy, n, i, 8, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+// GroupProjective::double (group.rs:339-386) on affine inputs
+__global__ void __launch_bounds__(BLOCK) k_g1_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P r = g1_double(a);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void HEAVY_BOUNDS k_g2_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G2P a{load_fp2(axy, n, i, 0), load_fp2(axy, n, i, 8), (ainf && ainf[i]) ? fp2_zero() : fp2_one()};
+  G2P r;
+  g2_double(r, a);
+  Fp2 x, y; bool rinf;
+  g2_to_affine(x, y, rinf, r);
+  store_fp2(oxy, n, i, 0, x); store_fp2(oxy, n, i, 8, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ layout helpers --------------
 __global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const u64* __restrict__ aos, u64* __restrict__ soa, size_t words, size_t n) {
   size_t t = TID;
@@ -1127,6 +1207,20 @@ int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, ui
 int32_t sylow_hip_f29_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;
   k_f29_hook<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
+}
+
+int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK; k_gt_pow<<<GRID(n)>>>(gt, k, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g2_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; k_g1_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; k_g2_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));

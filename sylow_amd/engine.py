@@ -186,6 +186,37 @@ class Engine:
         self._call("sylow_hip_g1_add_batch", da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
         return self.from_device_soa(do), doi.download()
 
+    def g2_add(self, a_xy, b_xy, a_inf=None, b_inf=None):
+        a_xy, b_xy = _aos(a_xy, 16), _aos(b_xy, 16)
+        n = a_xy.shape[0]
+        da, db = self.to_device_soa(a_xy, 16), self.to_device_soa(b_xy, 16)
+        dai, dbi = self._flags(a_inf, n), self._flags(b_inf, n)
+        do, doi = self.empty((16, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_g2_add_batch", da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def _double(self, name, width, a_xy, a_inf):
+        a_xy = _aos(a_xy, width)
+        n = a_xy.shape[0]
+        da, dai = self.to_device_soa(a_xy, width), self._flags(a_inf, n)
+        do, doi = self.empty((width, n)), self.empty((n,), np.uint8)
+        self._call(name, da.ptr, self._ptr(dai), do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def g1_double(self, a_xy, a_inf=None): return self._double("sylow_hip_g1_double_batch", 8, a_xy, a_inf)
+    def g2_double(self, a_xy, a_inf=None): return self._double("sylow_hip_g2_double_batch", 16, a_xy, a_inf)
+
+    def gt_pow(self, gt, k):
+        return self._binop_w("sylow_hip_gt_pow_batch", 48, gt, 4, k)
+
+    def _binop_w(self, name, wa, a, wb, b):
+        a, b = _aos(a, wa), _aos(b, wb)
+        n = a.shape[0]
+        da, db = self.to_device_soa(a, wa), self.to_device_soa(b, wb)
+        do = self.empty((wa, n))
+        self._call(name, da.ptr, db.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
     def _normalize(self, name, win, wout, p):
         p = _aos(p, win)
         n = p.shape[0]
