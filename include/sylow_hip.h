@@ -75,6 +75,16 @@ int32_t sylow_hip_fp_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void*
 int32_t sylow_hip_fp_neg_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 
+/* ---- Fr, the r-torsion scalar field (fields/fp.rs:556-565: the same macro-generated API as Fp, modulus r) -----------
+ * Same contract as the Fp calls: [4][n] canonical limbs in and out, any 256-bit input accepted like Fr::new,
+ * inv(0) = 0.  Used by Lagrange interpolation / polynomial evaluation (examples/threshold_signing.rs:64-70,146-155). */
+int32_t sylow_hip_fr_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_neg_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+
 /* ---- extension tower (test hooks): fields/fp2.rs:285-306,164-171,355-360; fp6.rs:283-367,
  * 415-423; fp12.rs:229-238,536-550,281-286,515-522,426-503 ------------------------------------ */
 int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
@@ -110,6 +120,12 @@ int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const
                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* Weighted aggregation sum_i k_{j,i} * P_{j,i} (examples/threshold_signing.rs:124-143: partial signatures times
+ * Lagrange coefficients), n_jobs independent sums of n_terms terms each.  p_xy [8][n_jobs*n_terms], k [4][n_jobs*n_terms]
+ * (Fr / Fp values), term-major: element (job j, term i) is at index i*n_jobs + j.  out [8][n_jobs] affine + flags.
+ * n_terms = 0 yields the identity, like G1Projective::default(). */
+int32_t sylow_hip_g1_lincomb_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf,
+                                   size_t n_jobs, size_t n_terms, void* stream);
 /* Mul<&Fr> for &Gt (groups/gt.rs:161-187): out_i = gt_i "times" k_i, i.e. gt_i^k_i in Fp12, by the reference's own
  * 256-step signed-digit square-and-multiply (negative digits multiply by the conjugate).  k: Fr values, [4][n]. */
 int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream);

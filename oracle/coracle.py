@@ -92,6 +92,10 @@ def fp_op(op, a, b=None):
     return _field_op(lib().oracle_fp_op, 4, op, a, b)
 
 
+def fr_op(op, a, b=None):
+    return _field_op(lib().oracle_fr_op, 4, op, a, b)
+
+
 def fp2_op(op, a, b=None):
     return _field_op(lib().oracle_fp2_op, 8, op, a, b)
 

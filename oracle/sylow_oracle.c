@@ -924,6 +924,63 @@ API void oracle_gt_pow(const u64 *g, const u64 *k, u64 *out, size_t n) {
     st12(out + 48 * e, res);
   }
 }
+/* ---- Fr (fp.rs:556-565: same macro as Fp, modulus r = fp.rs:60-65).  Deliberately the dumbest possible
+ * algorithm -- 512-bit schoolbook product and bit-serial long division -- so it shares nothing with the GPU's Barrett path. */
+static const u64 RMOD[4] = {0x43E1F593F0000001ull, 0x2833E84879B97091ull, 0xB85045B68181585Dull, 0x30644E72E131A029ull};
+static int geq_r(const u64 a[4]) {
+  for (int i = 3; i >= 0; --i) { if (a[i] > RMOD[i]) return 1; if (a[i] < RMOD[i]) return 0; }
+  return 1;
+}
+static void sub_r(u64 a[4]) {
+  u128 b = 0;
+  for (int i = 0; i < 4; ++i) { u128 t = (u128)a[i] - RMOD[i] - (u64)b; a[i] = (u64)t; b = (t >> 64) & 1; }
+}
+static void fr_reduce(u64 a[4]) { while (geq_r(a)) sub_r(a); }
+static void fr_mulmod(const u64 a[4], const u64 b[4], u64 out[4]) {
+  u64 t[8] = {0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a[i] * b[j] + t[i + j]; t[i + j] = (u64)c; c >>= 64; }
+    t[i + 4] = (u64)c;
+  }
+  u64 rem[4] = {0, 0, 0, 0};
+  for (int bit = 511; bit >= 0; --bit) {
+    u64 top = rem[3] >> 63;
+    for (int i = 3; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+    rem[0] = (rem[0] << 1) | ((t[bit >> 6] >> (bit & 63)) & 1);
+    if (top || geq_r(rem)) sub_r(rem);
+  }
+  memcpy(out, rem, 32);
+}
+/* op: 0 add 1 sub 2 mul 3 sqr 4 inv 5 neg (same numbering as oracle_fp_op) */
+API void oracle_fr_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+  for (size_t e = 0; e < n; ++e) {
+    u64 x[4], y[4] = {0, 0, 0, 0}, r[4];
+    memcpy(x, a + 4 * e, 32); fr_reduce(x);
+    if (b) { memcpy(y, b + 4 * e, 32); fr_reduce(y); }
+    if (op == 5 || op == 1) {               /* neg(y) for sub, neg(x) for neg */
+      u64 *v = (op == 5) ? x : y;
+      if (v[0] | v[1] | v[2] | v[3]) { u128 bw = 0; for (int i = 0; i < 4; ++i) { u128 t = (u128)RMOD[i] - v[i] - (u64)bw; v[i] = (u64)t; bw = (t >> 64) & 1; } }
+    }
+    if (op == 0 || op == 1) {
+      u128 c = 0;
+      for (int i = 0; i < 4; ++i) { c += (u128)x[i] + y[i]; r[i] = (u64)c; c >>= 64; }
+      fr_reduce(r);
+    } else if (op == 2) fr_mulmod(x, y, r);
+    else if (op == 3) fr_mulmod(x, x, r);
+    else if (op == 5) memcpy(r, x, 32);
+    else {                                   /* x^(r-2); inv(0) = 0 */
+      u64 ex[4]; memcpy(ex, RMOD, 32); ex[0] -= 2;
+      u64 acc[4] = {1, 0, 0, 0};
+      for (int i = 255; i >= 0; --i) {
+        fr_mulmod(acc, acc, acc);
+        if ((ex[i >> 6] >> (i & 63)) & 1) fr_mulmod(acc, x, acc);
+      }
+      memcpy(r, acc, 32);
+    }
+    memcpy(out + 4 * e, r, 32);
+  }
+}
 API void oracle_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]) {
   keccak_ctx c; keccak_init(&c); keccak_update(&c, msg, len); keccak_final(&c, out);
 }

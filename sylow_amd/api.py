@@ -204,6 +204,32 @@ class MillerLoopResult:
         return Gt(engine().final_exp(self.v))
 
 
+class Fr:
+    """Batch of scalar-field elements (fp.rs:556-565), canonical limbs [n, 4]; arithmetic runs on the GPU."""
+
+    def __init__(self, v):
+        self.v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+
+    @classmethod
+    def from_ints(cls, values):
+        return cls(fp(values))
+
+    def __len__(self): return self.v.shape[0]
+    def __add__(self, o): return Fr(engine().fr_add(self.v, o.v))
+    def __sub__(self, o): return Fr(engine().fr_sub(self.v, o.v))
+    def __mul__(self, o): return Fr(engine().fr_mul(self.v, o.v))
+    def __neg__(self): return Fr(engine().fr_neg(self.v))
+    def inv(self): return Fr(engine().fr_inv(self.v))
+    def __eq__(self, o): return (self.v == o.v).all(axis=1)
+
+
+def aggregate(points: "G1Affine", weights: "Fr", n_jobs: int, n_terms: int) -> "G1Affine":
+    """sum_i weights[j,i] * points[j,i] per job (examples/threshold_signing.rs:124-143); rows are term-major
+    (row i*n_jobs + j is term i of job j)."""
+    xy, inf = engine().g1_lincomb(points.xy, weights.v, n_jobs, n_terms, points.infinity)
+    return G1Affine(xy, inf)
+
+
 class G2PreComputed:
     """G2Affine::precompute() (pairing.rs:556,676-708): q plus the 87 line-coefficient triples, [n, 87*24] words."""
 

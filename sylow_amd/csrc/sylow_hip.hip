@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "bn254_hash.hpp"
+#include "bn254_fr.hpp"
 
 using namespace bn254;
 
@@ -71,13 +72,18 @@ BN_DEV void store_plain2(u64* __restrict__ base, size_t n, size_t i, const Fp& e
     *reinterpret_cast<ulonglong2*>(base + (size_t)k * n + i) = w;
   }
 }
-template <int OP>
+template <int OP, int FR>
 BN_DEV Fp fp_binop_one(const Fp& x, const Fp& y) {
+  if (FR) {                                            // the scalar field, same macro-generated API (fp.rs:556-565)
+    if (OP == OP_MUL) return fr_mulmod_inline(x, y);
+    Fp xr = fr_reduce_plain(x), yr = fr_reduce_plain(y);
+    return (OP == OP_ADD) ? fr_add(xr, yr) : fr_sub(xr, yr);
+  }
   if (OP == OP_MUL) return fp_mulmod_plain(x, y);      // Barrett takes any 256-bit operands
   Fp xr = fp_reduce_plain(x), yr = fp_reduce_plain(y);
   return (OP == OP_ADD) ? fp_add(xr, yr) : fp_sub(xr, yr);
 }
-template <int OP>
+template <int OP, int FR>
 __global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, size_t n) {
   size_t i = 2 * TID;
   if (i >= n) return;
@@ -86,19 +92,24 @@ __global__ void __launch_bounds__(BLOCK) k_fp_binop(const u64* __restrict__ a, c
     Fp x0, x1, y0, y1;
     load_plain2(x0, x1, a, n, i);
     load_plain2(y0, y1, b, n, i);
-    store_plain2(out, n, i, fp_binop_one<OP>(x0, y0), fp_binop_one<OP>(x1, y1));
+    store_plain2(out, n, i, fp_binop_one<OP, FR>(x0, y0), fp_binop_one<OP, FR>(x1, y1));
   } else {
     for (size_t j = i; j < n && j < i + 2; ++j)
-      store_plain(out, n, j, 0, fp_binop_one<OP>(load_plain(a, n, j, 0), load_plain(b, n, j, 0)));
+      store_plain(out, n, j, 0, fp_binop_one<OP, FR>(load_plain(a, n, j, 0), load_plain(b, n, j, 0)));
   }
 }
-template <int OP>
+template <int OP, int FR>
 BN_DEV Fp fp_unop_one(const Fp& x) {
+  if (FR) {
+    if (OP == OP_SQR) return fr_mulmod_inline(x, x);
+    if (OP == OP_NEG) return fr_neg(fr_reduce_plain(x));
+    return fr_inv(fr_reduce_plain(x));
+  }
   if (OP == OP_SQR) return fp_mulmod_plain(x, x);
   if (OP == OP_NEG) return fp_neg(fp_reduce_plain(x));
   return fp_from_mont(fp_inv(fp_to_mont(x)));
 }
-template <int OP>
+template <int OP, int FR>
 __global__ void __launch_bounds__(BLOCK) k_fp_unop(const u64* __restrict__ a, u64* __restrict__ out, size_t n) {
   size_t i = 2 * TID;
   if (i >= n) return;
@@ -106,9 +117,9 @@ __global__ void __launch_bounds__(BLOCK) k_fp_unop(const u64* __restrict__ a, u6
   if (vec) {
     Fp x0, x1;
     load_plain2(x0, x1, a, n, i);
-    store_plain2(out, n, i, fp_unop_one<OP>(x0), fp_unop_one<OP>(x1));
+    store_plain2(out, n, i, fp_unop_one<OP, FR>(x0), fp_unop_one<OP, FR>(x1));
   } else {
-    for (size_t j = i; j < n && j < i + 2; ++j) store_plain(out, n, j, 0, fp_unop_one<OP>(load_plain(a, n, j, 0)));
+    for (size_t j = i; j < n && j < i + 2; ++j) store_plain(out, n, j, 0, fp_unop_one<OP, FR>(load_plain(a, n, j, 0)));
   }
 }
 
@@ -202,6 +213,27 @@ __global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t*
   g1_to_affine(x, y, rinf, r);
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
   oinf[i] = rinf ? 1 : 0;
+}
+// out_j = sum_i k_{j,i} * P_{j,i}: the aggregation loop of examples/threshold_signing.rs:124-143 (Lagrange-weighted partial
+// signatures), one job per lane, terms walked in order with the reference's own scalar multiplication and complete addition.
+// Term-major layout: element (job j, term i) lives at index i * n_jobs + j, so a wave reads consecutive addresses.
+__global__ void __launch_bounds__(BLOCK) k_g1_lincomb(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n_jobs, size_t n_terms) {
+  size_t j = TID;
+  if (j >= n_jobs) return;
+  const size_t n = n_jobs * n_terms;
+  G1P acc{fp_zero(), fp_one(), fp_zero()};               // G1Projective::default() = identity
+#pragma unroll 1
+  for (size_t t = 0; t < n_terms; ++t) {
+    const size_t i = t * n_jobs + j;
+    G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), (pinf && pinf[i]) ? fp_zero() : fp_one()};
+    u32 k[8];
+    load_scalar(k, ks, n, i);
+    acc = g1_add(acc, g1_scalar_mul(p, k));
+  }
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, acc);
+  store_fp(oxy, n_jobs, j, 0, x); store_fp(oxy, n_jobs, j, 4, y);
+  oinf[j] = rinf ? 1 : 0;
 }
 __global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
@@ -990,18 +1022,20 @@ int32_t sylow_hip_soa_to_aos(const uint64_t* soa, uint64_t* aos, size_t words, s
   k_soa_to_aos<<<GRID(words * n)>>>(soa, aos, words, n); LAUNCHED();
 }
 
-#define FP_BIN(name, OP)                                                                                         \
-  int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) { \
+#define FP_BIN(field, FR, name, OP)                                                                                 \
+  int32_t sylow_hip_##field##_##name##_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) { \
     ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;                                                           \
-    k_fp_binop<OP><<<GRID((n + 1) / 2)>>>(a, b, out, n); LAUNCHED();                                                        \
+    k_fp_binop<OP, FR><<<GRID((n + 1) / 2)>>>(a, b, out, n); LAUNCHED();                                             \
   }
-FP_BIN(add, OP_ADD) FP_BIN(sub, OP_SUB) FP_BIN(mul, OP_MUL)
-#define FP_UN(name, OP)                                                                                  \
-  int32_t sylow_hip_fp_##name##_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {           \
+FP_BIN(fp, 0, add, OP_ADD) FP_BIN(fp, 0, sub, OP_SUB) FP_BIN(fp, 0, mul, OP_MUL)
+FP_BIN(fr, 1, add, OP_ADD) FP_BIN(fr, 1, sub, OP_SUB) FP_BIN(fr, 1, mul, OP_MUL)
+#define FP_UN(field, FR, name, OP)                                                                          \
+  int32_t sylow_hip_##field##_##name##_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {      \
     ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;                                                        \
-    k_fp_unop<OP><<<GRID((n + 1) / 2)>>>(a, out, n); LAUNCHED();                                                    \
+    k_fp_unop<OP, FR><<<GRID((n + 1) / 2)>>>(a, out, n); LAUNCHED();                                         \
   }
-FP_UN(sqr, OP_SQR) FP_UN(neg, OP_NEG) FP_UN(inv, OP_INV)
+FP_UN(fp, 0, sqr, OP_SQR) FP_UN(fp, 0, neg, OP_NEG) FP_UN(fp, 0, inv, OP_INV)
+FP_UN(fr, 1, sqr, OP_SQR) FP_UN(fr, 1, neg, OP_NEG) FP_UN(fr, 1, inv, OP_INV)
 
 int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OP_MUL, a, b, out, n); LAUNCHED();
@@ -1055,6 +1089,10 @@ int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   k_g1_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_lincomb_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n_jobs, size_t n_terms, void* stream) {
+  ARGCHK(out_xy && out_inf && (n_terms == 0 || (p_xy && k))); if (!n_jobs) return SYLOW_HIP_OK;
+  k_g1_lincomb<<<GRID(n_jobs)>>>(p_xy, p_inf, k, out_xy, out_inf, n_jobs, n_terms); LAUNCHED();
 }
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;

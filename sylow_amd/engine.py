@@ -121,6 +121,12 @@ class Engine:
     def fp_sqr(self, a): return self._unop("sylow_hip_fp_sqr_batch", 4, a)
     def fp_neg(self, a): return self._unop("sylow_hip_fp_neg_batch", 4, a)
     def fp_inv(self, a): return self._unop("sylow_hip_fp_inv_batch", 4, a)
+    def fr_add(self, a, b): return self._binop("sylow_hip_fr_add_batch", 4, a, b)
+    def fr_sub(self, a, b): return self._binop("sylow_hip_fr_sub_batch", 4, a, b)
+    def fr_mul(self, a, b): return self._binop("sylow_hip_fr_mul_batch", 4, a, b)
+    def fr_sqr(self, a): return self._unop("sylow_hip_fr_sqr_batch", 4, a)
+    def fr_neg(self, a): return self._unop("sylow_hip_fr_neg_batch", 4, a)
+    def fr_inv(self, a): return self._unop("sylow_hip_fr_inv_batch", 4, a)
     def fp2_mul(self, a, b): return self._binop("sylow_hip_fp2_mul_batch", 8, a, b)
     def fp2_sqr(self, a): return self._unop("sylow_hip_fp2_sqr_batch", 8, a)
     def fp2_inv(self, a): return self._unop("sylow_hip_fp2_inv_batch", 8, a)
@@ -184,6 +190,18 @@ class Engine:
         dai, dbi = self._flags(a_inf, n), self._flags(b_inf, n)
         do, doi = self.empty((8, n)), self.empty((n,), np.uint8)
         self._call("sylow_hip_g1_add_batch", da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def g1_lincomb(self, p_xy, k, n_jobs, n_terms, p_inf=None):
+        """sum_i k[j,i] * P[j,i]; inputs term-major: row i*n_jobs + j is term i of job j."""
+        p_xy, k = _aos(p_xy, 8), _aos(k, 4)
+        n = n_jobs * n_terms
+        assert p_xy.shape[0] == n and k.shape[0] == n
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dk = self.to_device_soa(k, 4) if n else None
+        di = self._flags(p_inf, n) if n else None
+        do, doi = self.empty((8, n_jobs)), self.empty((n_jobs,), np.uint8)
+        self._call("sylow_hip_g1_lincomb_batch", self._ptr(dp), self._ptr(di), self._ptr(dk), do.ptr, doi.ptr, n_jobs, n_terms)
         return self.from_device_soa(do), doi.download()
 
     def g2_add(self, a_xy, b_xy, a_inf=None, b_inf=None):
