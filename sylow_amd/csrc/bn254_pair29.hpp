@@ -1,0 +1,320 @@
+// bn254_pair29.hpp -- the Fp12 layer of the lane-pair pairing on the carry-free 9 x 29-bit core (bn254_f29.hpp).
+//
+// Same lane-pair layout as bn254_pair.hpp (even lane = c0 coordinate, odd lane = c1 coordinate of every Fp2), but each
+// coordinate is an F29 (9 signed 29-bit limbs, Montgomery factor 2^261).  On this layout the kernel is VALU-bound
+// (no scratch traffic left), and the carry-free core needs ~30 % fewer instructions per Fp2 product (one v_mad_i64_i32 per
+// partial product, no v_addc) and 9-instruction lazy additions, so it is used for everything that touches the Fp12
+// accumulator: the squarings and line multiplications of the Miller loop and the whole hard part of the final exponentiation.
+//
+// Bounds discipline (worst case, see bn254_f29.hpp for L and V):
+//   R  "reduced":     limbs 0..7 in [0, 2^29), |value| < 0.51 p
+//   N  "normalized":  limbs 0..7 in [0, 2^29), top limb signed, |value| <= 4 p
+//   D  "difference":  |limbs| < 2^29 (a difference of two N values, or a negated N value), |value| <= 4 p
+//  * product operands (w2_mul) may be R, N or D; w2_sqr needs non-negative limbs (R or N);
+//  * a sum of two/three N values must go through f29_norm before it is a product operand;
+//  * every value STORED by a routine here is R or N -- lazy combinations end in f29_reduce_from (R) or f29_norm (N).
+// With |V| <= 4 on the operands a fused two-product pass returns |V| < 2*16/169 + 1 < 1.2, a pre-added Karatsuba operand
+// has |V| <= 8 and its products |V| < 2*64/169 + 1 < 1.8, so values never approach the |V| <= 40 limit of the core.
+#pragma once
+#include "bn254_f29.hpp"
+#include "bn254_pair.hpp"
+
+namespace bn254 {
+namespace pl {
+
+struct W2 { F29 c; };
+struct W6 { W2 c0, c1, c2; };
+struct W12 { W6 c0, c1; };
+
+BN_DEV F29 xchg9(const F29& a) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = (i32)swap_u32((u32)a.v[i]);
+  return r;
+}
+BN_DEV F29 sel9(bool odd, const F29& if_even, const F29& if_odd) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = odd ? if_odd.v[i] : if_even.v[i];
+  return r;
+}
+BN_DEV F29 f29_reduce(const F29& a) { return f29_reduce_from([&](int i) { return (i64)a.v[i]; }); }
+
+// ---- leaves: 18 scalar ABI arguments (two 9-limb structs would travel through the stack) -----------------------------
+// even lane: a0 b0 - a1 b1;  odd lane: a1 b0 + a0 b1.  Operands R / N / D.  Output N, |V| < (VaVb + Va'Vb')/169 + 1.
+BN_NOINLINE F29 w2_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
+                            i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
+  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
+  const bool odd = lane_odd();
+  const F29 ra = xchg9(sel9(odd, a, f29_neg(a)));      // the odd lane sends -a1, the even lane a0
+  const F29 rb = xchg9(b);
+  return f29_dot2(a, sel9(odd, b, rb), ra, sel9(odd, rb, b));
+}
+// even lane: (a0 + a1)(a0 - a1);  odd lane: a0 * 2 a1.  Operand limbs non-negative (R / N).  Output N.
+BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8) {
+  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+  const bool odd = lane_odd();
+  const F29 o = xchg9(a);
+  return f29_mul(sel9(odd, f29_add(a, o), o), sel9(odd, f29_sub(a, o), f29_dbl(a)));   // L(x) L(y) = 2
+}
+// Fp x Fp on the core (line scaling): operands R / N / D, L(a) L(b) <= 2.5
+BN_NOINLINE F29 f29_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
+                             i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
+  return f29_mul(F29{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, F29{{b0, b1, b2, b3, b4, b5, b6, b7, b8}});
+}
+#define W_ARGS(x) (x).v[0], (x).v[1], (x).v[2], (x).v[3], (x).v[4], (x).v[5], (x).v[6], (x).v[7], (x).v[8]
+BN_DEV W2 w2_mul(const W2& a, const W2& b) { return W2{w2_mul_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
+BN_DEV W2 w2_sqr(const W2& a) { return W2{w2_sqr_leaf(W_ARGS(a.c))}; }
+BN_DEV W2 w2_scale(const W2& a, const F29& k) { return W2{f29_mul_leaf(W_ARGS(a.c), W_ARGS(k))}; }
+
+// ---- lazy linear layer ------------------------------------------------------------------------------------------------
+BN_DEV W2 w2_add(const W2& a, const W2& b) { return W2{f29_add(a.c, b.c)}; }
+BN_DEV W2 w2_sub(const W2& a, const W2& b) { return W2{f29_sub(a.c, b.c)}; }
+BN_DEV W2 w2_neg(const W2& a) { return W2{f29_neg(a.c)}; }
+BN_DEV W2 w2_norm(const W2& a) { return W2{f29_norm(a.c)}; }
+BN_DEV W2 w2_reduce(const W2& a) { return W2{f29_reduce(a.c)}; }
+// reduce(ka a + kb b)
+BN_DEV W2 w2_lin2(const W2& a, int ka, const W2& b, int kb) { return W2{f29_lin2(a.c, ka, b.c, kb)}; }
+// reduce(k xi x + m y): this lane's coordinate of xi x is 9 x -/+ (partner's x)
+BN_DEV W2 w2_xi_lin(const W2& x, int k, const W2& y, int m) {
+  const F29 xo = xchg9(x.c);
+  const i32 s = lane_odd() ? 1 : -1;
+  return W2{f29_reduce_from([&](int i) { return ((i64)x.c.v[i] * 9 + (i64)xo.v[i] * s) * k + (i64)y.c.v[i] * m; })};
+}
+
+// ---- conversions (saturated lane-pair <-> carry-free lane-pair) ---------------------------------------------------
+BN_DEV W2 w2_from_s2(const S2& a) { return W2{f29_reduce(f29_from_fp(a.c))}; }     // R
+BN_DEV S2 w2_to_s2(const W2& a) { return S2{f29_to_fp(a.c)}; }                     // needs |V| < 64
+BN_DEV W2 w2_const(const uint32_t (&c)[2][8]) { return w2_from_s2(s2_const(c)); }
+BN_DEV void w12_from_s12(W12& r, const S12& a) {
+  r.c0.c0 = w2_from_s2(a.c0.c0); r.c0.c1 = w2_from_s2(a.c0.c1); r.c0.c2 = w2_from_s2(a.c0.c2);
+  r.c1.c0 = w2_from_s2(a.c1.c0); r.c1.c1 = w2_from_s2(a.c1.c1); r.c1.c2 = w2_from_s2(a.c1.c2);
+}
+BN_DEV void w12_to_s12(S12& r, const W12& a) {
+  r.c0.c0 = w2_to_s2(a.c0.c0); r.c0.c1 = w2_to_s2(a.c0.c1); r.c0.c2 = w2_to_s2(a.c0.c2);
+  r.c1.c0 = w2_to_s2(a.c1.c0); r.c1.c1 = w2_to_s2(a.c1.c1); r.c1.c2 = w2_to_s2(a.c1.c2);
+}
+
+// ---- Fp6: inputs R / N / D with |V| <= 4, outputs R ---------------------------------------------------------------------
+BN_DEV W6 w6_mul(const W6& a, const W6& b) {
+  const W2 v0 = w2_mul(a.c0, b.c0);
+  const W2 v1 = w2_mul(a.c1, b.c1);
+  const W2 v2 = w2_mul(a.c2, b.c2);
+  const W2 t0 = w2_mul(w2_norm(w2_add(a.c1, a.c2)), w2_norm(w2_add(b.c1, b.c2)));
+  const W2 t1 = w2_mul(w2_norm(w2_add(a.c0, a.c1)), w2_norm(w2_add(b.c0, b.c1)));
+  const W2 t2 = w2_mul(w2_norm(w2_add(a.c0, a.c2)), w2_norm(w2_add(b.c0, b.c2)));
+  W6 r;
+  r.c0 = w2_xi_lin(w2_sub(w2_sub(t0, v1), v2), 1, v0, 1);               // v0 + xi (t0 - v1 - v2)
+  r.c1 = w2_xi_lin(v2, 1, w2_sub(w2_sub(t1, v0), v1), 1);               // (t1 - v0 - v1) + xi v2
+  r.c2 = w2_reduce(w2_add(w2_sub(w2_sub(t2, v0), v2), v1));             // t2 - v0 - v2 + v1
+  return r;
+}
+BN_DEV W6 w6_add_norm(const W6& a, const W6& b) {
+  return W6{w2_norm(w2_add(a.c0, b.c0)), w2_norm(w2_add(a.c1, b.c1)), w2_norm(w2_add(a.c2, b.c2))};
+}
+BN_DEV W6 w6_sub(const W6& a, const W6& b) { return W6{w2_sub(a.c0, b.c0), w2_sub(a.c1, b.c1), w2_sub(a.c2, b.c2)}; }
+
+// ---- Fp12: inputs R / N, outputs R / N --------------------------------------------------------------------------------
+BN_DEV W12 w12_mul(const W12& a, const W12& b) {
+  const W6 t0 = w6_mul(a.c0, b.c0);
+  const W6 t1 = w6_mul(a.c1, b.c1);
+  const W6 t2 = w6_mul(w6_add_norm(a.c0, a.c1), w6_add_norm(b.c0, b.c1));
+  W12 r;
+  r.c1.c0 = w2_lin2(w2_sub(t2.c0, t0.c0), 1, t1.c0, -1);
+  r.c1.c1 = w2_lin2(w2_sub(t2.c1, t0.c1), 1, t1.c1, -1);
+  r.c1.c2 = w2_lin2(w2_sub(t2.c2, t0.c2), 1, t1.c2, -1);
+  r.c0.c0 = w2_xi_lin(t1.c2, 1, t0.c0, 1);                               // t0 + v t1
+  r.c0.c1 = w2_norm(w2_add(t0.c1, t1.c0));                               // two R values: N with |V| < 1.1
+  r.c0.c2 = w2_norm(w2_add(t0.c2, t1.c1));
+  return r;
+}
+// complex squaring (fp12.rs:536-550): c0 = (a0 - a1)(a0 - v a1) + a0 a1 + v a0 a1, c1 = 2 a0 a1
+BN_DEV W12 w12_sqr(const W12& a) {
+  const W6 d = w6_sub(a.c0, a.c1);                                       // D
+  W6 e;                                                                  // a0 - v a1 = (a0.c0 - xi a1.c2, a0.c1 - a1.c0, a0.c2 - a1.c1)
+  e.c0 = w2_xi_lin(a.c1.c2, -1, a.c0.c0, 1);
+  e.c1 = w2_sub(a.c0.c1, a.c1.c0);
+  e.c2 = w2_sub(a.c0.c2, a.c1.c1);
+  const W6 c2 = w6_mul(a.c0, a.c1);
+  const W6 m = w6_mul(d, e);
+  W12 r;
+  r.c1.c0 = w2_norm(w2_add(c2.c0, c2.c0));
+  r.c1.c1 = w2_norm(w2_add(c2.c1, c2.c1));
+  r.c1.c2 = w2_norm(w2_add(c2.c2, c2.c2));
+  r.c0.c0 = w2_xi_lin(c2.c2, 1, w2_add(m.c0, c2.c0), 1);                 // m0 + c2.0 + xi c2.2
+  r.c0.c1 = w2_norm(w2_add(w2_add(m.c1, c2.c1), c2.c0));                 // three R values: N with |V| < 1.6
+  r.c0.c2 = w2_norm(w2_add(w2_add(m.c2, c2.c2), c2.c1));
+  return r;
+}
+// conjugate, N-class output (non-negative limbs: the result may feed a squaring)
+BN_DEV W12 w12_conj(const W12& a) {
+  W12 r;
+  r.c0 = a.c0;
+  r.c1.c0 = w2_norm(w2_neg(a.c1.c0)); r.c1.c1 = w2_norm(w2_neg(a.c1.c1)); r.c1.c2 = w2_norm(w2_neg(a.c1.c2));
+  return r;
+}
+// this lane's coordinate negated on odd lanes only (Fp2 conjugation), N-class
+BN_DEV W2 w2_conj(const W2& a) { return W2{sel9(lane_odd(), a.c, f29_norm(f29_neg(a.c)))}; }
+template <int E>
+BN_DEV W6 w6_frobenius(const W6& a) {
+  constexpr bool oddE = (E & 1) != 0;
+  const uint32_t (&k1)[2][8] = (E == 1) ? C_FROB6_C1_1 : (E == 2) ? C_FROB6_C1_2 : C_FROB6_C1_3;
+  const uint32_t (&k2)[2][8] = (E == 1) ? C_FROB6_C2_1 : (E == 2) ? C_FROB6_C2_2 : C_FROB6_C2_3;
+  W6 r;
+  r.c0 = oddE ? w2_conj(a.c0) : a.c0;
+  r.c1 = w2_mul(oddE ? w2_conj(a.c1) : a.c1, w2_const(k1));
+  r.c2 = w2_mul(oddE ? w2_conj(a.c2) : a.c2, w2_const(k2));
+  return r;
+}
+template <int E>
+BN_DEV W12 w12_frobenius(const W12& a) {
+  const uint32_t (&k)[2][8] = (E == 1) ? C_FROB12_C1_1 : (E == 2) ? C_FROB12_C1_2 : C_FROB12_C1_3;
+  const W2 kk = w2_const(k);
+  const W6 x1 = w6_frobenius<E>(a.c1);
+  return W12{w6_frobenius<E>(a.c0), W6{w2_mul(x1.c0, kk), w2_mul(x1.c1, kk), w2_mul(x1.c2, kk)}};
+}
+// fp12.rs:426-503 (mul_by_024): x0 = ell_0, x2 = ell_vv, x4 = ell_vw, all R / N.  f R / N.  Output R.
+BN_DEV W12 w12_sparse_mul(const W12& f, const W2& x0, const W2& x4, const W2& x2) {
+  const W2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
+  const W2 d0 = w2_mul(z0, x0);
+  const W2 d2 = w2_mul(z2, x2);
+  const W2 d4 = w2_mul(z4, x4);
+  const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p10 = w2_mul(z1, x0);
+  const W2 p34 = w2_mul(z3, x4), p30 = w2_mul(z3, x0), p52 = w2_mul(z5, x2);
+  const W2 x02 = w2_norm(w2_add(x0, x2)), x24 = w2_norm(w2_add(x2, x4)), x04 = w2_norm(w2_add(x0, x4));
+  const W2 q02 = w2_mul(w2_norm(w2_add(z0, z2)), x02);
+  const W2 q24 = w2_mul(w2_norm(w2_add(z2, z4)), x24);
+  const W2 q04 = w2_mul(w2_norm(w2_add(z0, z4)), x04);
+  const W2 qs = w2_mul(w2_norm(w2_add(w2_add(z1, z3), z5)), w2_norm(w2_add(x02, x4)));
+  W12 o;
+  o.c0.c0 = w2_xi_lin(w2_add(p12, d4), 1, d0, 1);                                            // xi (z1 x2 + d4) + d0
+  o.c0.c1 = w2_xi_lin(w2_add(p54, d2), 1, p10, 1);                                           // xi (z5 x4 + d2) + z1 x0
+  o.c0.c2 = w2_reduce(w2_add(w2_sub(w2_sub(q02, d0), d2), p34));                             // (z0+z2)(x0+x2) - d0 - d2 + z3 x4
+  o.c1.c0 = w2_xi_lin(w2_sub(w2_sub(q24, d2), d4), 1, p30, 1);                               // xi ((z2+z4)(x2+x4) - d2 - d4) + z3 x0
+  o.c1.c1 = w2_xi_lin(p52, 1, w2_sub(w2_sub(q04, d0), d4), 1);                               // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
+  {                                                                                          // (z1+z3+z5)(x0+x2+x4) - all six cross products
+    const W2 sa = w2_add(w2_add(p12, p54), p10), sb = w2_add(w2_add(p34, p30), p52);         // each < 3 * 2^29: fits int32
+    o.c1.c2 = W2{f29_reduce_from([&](int i) { return (i64)qs.c.v[i] - sa.c.v[i] - sb.c.v[i]; })};
+  }
+  return o;
+}
+// pairing.rs:274-350 (Granger-Scott), input R / N with |V| <= 1.2, output R
+BN_DEV void w_fp4_square(W2& c0, W2& c1, const W2& a, const W2& b) {
+  const W2 t0 = w2_sqr(a);
+  const W2 t1 = w2_sqr(b);
+  c0 = w2_xi_lin(t1, 1, t0, 1);
+  c1 = w2_sub(w2_sub(w2_sqr(w2_norm(w2_add(a, b))), t0), t1);          // lazy: limbs in (-2^30, 2^29)
+}
+BN_DEV W12 w12_cyclotomic_sqr(const W12& f) {
+  const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  W2 t0, t1, t2, t3;
+  W12 r;
+  w_fp4_square(t0, t1, z0, z1);
+  r.c0.c0 = w2_lin2(t0, 3, z0, -2);
+  r.c1.c1 = w2_lin2(t1, 3, z1, 2);
+  w_fp4_square(t0, t1, z2, z3);
+  w_fp4_square(t2, t3, z4, z5);
+  r.c0.c1 = w2_lin2(t0, 3, z4, -2);
+  r.c1.c2 = w2_lin2(t1, 3, z5, 2);
+  r.c1.c0 = w2_xi_lin(t3, 3, z2, 2);
+  r.c0.c2 = w2_lin2(t2, 3, z3, -2);
+  return r;
+}
+
+// ---- Miller loop: G2 point arithmetic on the saturated lane-pair core, accumulator on the carry-free core ----------
+BN_DEV W12 w12_line(const W12& f, const S2& l0, const S2& l1, const S2& l2, const F29& px, const F29& py) {
+  // sparse_mul(c0, c1 * P.y, c2 * P.x) (pairing.rs:598); f29_from_fp yields N-class digits with V <= 32, the products
+  // with the reduced px / py are N with |V| < 1.1
+  const W2 x0 = w2_from_s2(l0);
+  const W2 x4 = w2_scale(W2{f29_from_fp(l1.c)}, py);
+  const W2 x2 = w2_scale(W2{f29_from_fp(l2.c)}, px);
+  return w12_sparse_mul(f, x0, x4, x2);
+}
+BN_NOINLINE void miller_loop29(S12& fout, const Fp& pxs, const Fp& pys, const S2& qx, const S2& qy) {
+  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
+  W12 f;
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  G2S r{qx, qy, s2_one()};
+  const S2 nqy = s2_neg(qy);
+  S2 l0, l1, l2;
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step(r, l0, l1, l2);
+    f = w12_sqr(f);
+    f = w12_line(f, l0, l1, l2, px, py);
+    if ((nz >> (63 - i)) & 1) {
+      const bool neg = (ng >> (63 - i)) & 1;
+      g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
+      f = w12_line(f, l0, l1, l2, px, py);
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qx, qy);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  q2y = s2_neg(q2y);
+  g2_addition_step(r, q1x, q1y, l0, l1, l2);
+  f = w12_line(f, l0, l1, l2, px, py);
+  g2_addition_step(r, q2x, q2y, l0, l1, l2);
+  f = w12_line(f, l0, l1, l2, px, py);
+  w12_to_s12(fout, f);
+}
+
+// ---- final exponentiation: easy part saturated (one inversion), hard part carry-free ------------------------------
+BN_NOINLINE void w12_mul_nl(W12& r, const W12& a, const W12& b) { r = w12_mul(a, b); }
+BN_NOINLINE void w12_cyclotomic_sqr_nl(W12& r, const W12& a) { r = w12_cyclotomic_sqr(a); }
+template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) { r = w12_frobenius<E>(a); }
+BN_NOINLINE void exp_by_neg_z29(W12& r, const W12& f) {
+  const W12 f3 = w12_mul(w12_cyclotomic_sqr(f), f);
+  W12 res = f;
+  const u64 nz = 0x4908924444891211ull, ng = 0x0108000400880210ull, th = 0x0108804404880200ull;
+#pragma unroll 1
+  for (int i = 61; i >= 0; --i) {
+    res = w12_cyclotomic_sqr(res);
+    if ((nz >> i) & 1) {
+      W12 m = ((th >> i) & 1) ? f3 : f;
+      if ((ng >> i) & 1) m = w12_conj(m);
+      res = w12_mul(res, m);
+    }
+  }
+  r = w12_conj(res);
+}
+BN_NOINLINE void final_exponentiation29(S12& out, const S12& fin) {
+  W12 in, t, a, b, d, e, g;
+  {
+    S12 sa = s12_conj(fin), sb = s12_inv(fin), st, su;
+    s12_mul_nl(st, sa, sb);
+    s12_frobenius_nl<2>(sa, st);
+    s12_mul_nl(su, sa, st);
+    w12_from_s12(in, su);
+  }
+  exp_by_neg_z29(a, in);
+  w12_cyclotomic_sqr_nl(b, a);
+  w12_cyclotomic_sqr_nl(t, b);
+  w12_mul_nl(d, t, b);
+  exp_by_neg_z29(e, d);
+  w12_cyclotomic_sqr_nl(t, e);
+  exp_by_neg_z29(g, t);
+  d = w12_conj(d);
+  g = w12_conj(g);
+  w12_mul_nl(t, g, e);
+  w12_mul_nl(a, t, d);
+  w12_mul_nl(d, a, b);
+  w12_mul_nl(t, a, e);
+  w12_mul_nl(e, in, t);
+  w12_frobenius_nl<1>(t, d);
+  w12_mul_nl(b, t, e);
+  w12_frobenius_nl<2>(t, a);
+  w12_mul_nl(e, t, b);
+  t = w12_conj(in);
+  w12_mul_nl(a, t, d);
+  w12_frobenius_nl<3>(t, a);
+  w12_mul_nl(g, t, e);
+  w12_to_s12(out, g);
+}
+
+}  // namespace pl
+}  // namespace bn254

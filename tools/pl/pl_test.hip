@@ -4,7 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include "../../sylow_amd/csrc/bn254_pairing.hpp"
-#include "../../sylow_amd/csrc/bn254_pair.hpp"
+#include "../../sylow_amd/csrc/bn254_pair29.hpp"
 using namespace bn254;
 #define TID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
 BN_DEV Fp load_plain(const u64* __restrict__ base, size_t n, size_t i, int w0) {
@@ -54,6 +54,50 @@ __global__ void __launch_bounds__(256, 2) k_pl_op(int op, const u64* a, const u6
     x = r;
   }
   store_s12(out, n, i, odd, r);
+}
+__global__ void __launch_bounds__(256, 2) k_pw_op(int op, const u64* a, const u64* b, u64* out, size_t n, int iters) {
+  size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  pl::S12 sx, sy, sr;
+  load_s12(sx, a, n, i, odd);
+  if (b) load_s12(sy, b, n, i, odd);
+  if (op == OP_FINAL) {
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) { pl::final_exponentiation29(sr, sx); sx = sr; }
+  } else {
+    pl::W12 x, y, r;
+    pl::w12_from_s12(x, sx);
+    if (b) pl::w12_from_s12(y, sy);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+      switch (op) {
+        case OP_MUL: r = pl::w12_mul(x, y); break;
+        case OP_SQR: r = pl::w12_sqr(x); break;
+        case OP_FROB1: r = pl::w12_frobenius<1>(x); break;
+        case OP_FROB2: r = pl::w12_frobenius<2>(x); break;
+        case OP_FROB3: r = pl::w12_frobenius<3>(x); break;
+        case OP_SPARSE: r = pl::w12_sparse_mul(x, y.c0.c0, y.c0.c1, y.c0.c2); break;
+        case OP_CYCSQR: r = pl::w12_cyclotomic_sqr(x); break;
+        default: pl::exp_by_neg_z29(r, x); break;
+      }
+      x = r;
+    }
+    pl::w12_to_s12(sr, r);
+  }
+  store_s12(out, n, i, odd, sr);
+}
+__global__ void __launch_bounds__(256, 2) k_pw_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n) {
+  size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+  pl::S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+  pl::S12 f, g;
+  pl::miller_loop29(f, px, py, qx, qy);
+  if (fout) store_s12(fout, n, i, odd, f);
+  pl::final_exponentiation29(g, f);
+  store_s12(gout, n, i, odd, g);
 }
 BN_DEV void load_fp12(Fp12& r, const u64* base, size_t n, size_t i) {
   Fp* f = reinterpret_cast<Fp*>(&r);
@@ -129,13 +173,15 @@ static float timed(void (*launch)(void*), void* ctx, int reps) {
 struct OpCtx { int pair, op; const u64 *a, *b; u64* out; size_t n; int iters; };
 static void launch_op(void* p) {
   OpCtx* c = (OpCtx*)p;
-  if (c->pair) k_pl_op<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
+  if (c->pair == 2) k_pw_op<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
+  else if (c->pair) k_pl_op<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
   else k_sl_op<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
 }
 struct PairCtx { int pair; const u64 *p, *q; u64 *g, *f; size_t n; };
 static void launch_pairing(void* p) {
   PairCtx* c = (PairCtx*)p;
-  if (c->pair) k_pl_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
+  if (c->pair == 2) k_pw_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
+  else if (c->pair) k_pl_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
   else k_sl_pairing<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
 }
 extern "C" {

@@ -34,17 +34,30 @@ def parity():
            "frob1": C.fp12_op("frobenius", a, arg=1), "frob2": C.fp12_op("frobenius", a, arg=2), "frob3": C.fp12_op("frobenius", a, arg=3),
            "sparse": C.fp12_sparse_mul(a, b[:, :24])}
     for op, e in exp.items():
-        got, _ = run_op(1, op, a, b if op in ("mul", "sparse") else None)
-        print(f"pair {op:7s} parity:", np.array_equal(got, e)); assert np.array_equal(got, e), op
+        for mode in (1, 2):
+            if mode == 2 and op == "inv": continue
+            got, _ = run_op(mode, op, a, b if op in ("mul", "sparse") else None)
+            print(f"mode {mode} {op:7s} parity:", np.array_equal(got, e)); assert np.array_equal(got, e), op
     # cyclotomic ops need subgroup members: easy part of random values via the oracle
     cyc = C.fp12_op("mul", C.fp12_op("frobenius", C.fp12_op("mul", C.fp12_op("conj", a[2:]), C.fp12_op("inv", a[2:])), arg=2),
                     C.fp12_op("mul", C.fp12_op("conj", a[2:]), C.fp12_op("inv", a[2:])))
-    got, _ = run_op(1, "cycsqr", cyc)
-    assert np.array_equal(got, C.fp12_op("sqr", cyc)); print("pair cycsqr  parity: True")
-    got, _ = run_op(1, "expz", cyc); ref, _ = run_op(0, "expz", cyc)
-    assert np.array_equal(got, ref); print("pair expz == single-lane expz: True")
-    got, _ = run_op(1, "final", a[2:])
-    assert np.array_equal(got, C.final_exponentiation(a[2:])); print("pair final_exponentiation parity: True")
+    ref, _ = run_op(0, "expz", cyc)
+    for mode in (1, 2):
+        got, _ = run_op(mode, "cycsqr", cyc)
+        assert np.array_equal(got, C.fp12_op("sqr", cyc)); print(f"mode {mode} cycsqr  parity: True")
+        got, _ = run_op(mode, "cycsqr", cyc, iters=40); e = cyc
+        for _ in range(40): e = C.fp12_op("sqr", e)
+        assert np.array_equal(got, e); print(f"mode {mode} cycsqr x40 parity: True")
+        got, _ = run_op(mode, "expz", cyc)
+        assert np.array_equal(got, ref); print(f"mode {mode} expz == single-lane expz: True")
+        got, _ = run_op(mode, "final", a[2:])
+        assert np.array_equal(got, C.final_exponentiation(a[2:])); print(f"mode {mode} final_exponentiation parity: True")
+        got, _ = run_op(mode, "mul", a, b, iters=25); e = a
+        for _ in range(25): e = C.fp12_op("mul", e, b)
+        assert np.array_equal(got, e); print(f"mode {mode} mul x25 parity: True")
+        got, _ = run_op(mode, "sqr", a, iters=25); e = a
+        for _ in range(25): e = C.fp12_op("sqr", e)
+        assert np.array_equal(got, e); print(f"mode {mode} sqr x25 parity: True")
 
 def pairing_inputs(n):
     ks = C.to_limbs([rng.fp() % R.R_ORDER for _ in range(2 * n)])
@@ -56,12 +69,13 @@ def pairing_parity():
     n = 33
     p, q = pairing_inputs(n)
     dp, dq = eng.to_device_soa(p, 8), eng.to_device_soa(q, 16)
-    dg, df = eng.empty((48, n)), eng.empty((48, n))
-    assert lib.pl_pairing(1, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 1) >= 0
-    f, g = eng.from_device_soa(df), eng.from_device_soa(dg)
-    print("pair miller raw parity:", np.array_equal(f, C.miller_loop(p, q)))
-    print("pair pairing Gt parity:", np.array_equal(g, C.final_exponentiation(C.miller_loop(p, q))))
-    assert np.array_equal(f, C.miller_loop(p, q)) and np.array_equal(g, C.final_exponentiation(C.miller_loop(p, q)))
+    for mode in (1, 2):
+        dg, df = eng.empty((48, n)), eng.empty((48, n))
+        assert lib.pl_pairing(mode, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 1) >= 0
+        f, g = eng.from_device_soa(df), eng.from_device_soa(dg)
+        print(f"mode {mode} miller raw parity:", np.array_equal(f, C.miller_loop(p, q)))
+        print(f"mode {mode} pairing Gt parity:", np.array_equal(g, C.final_exponentiation(C.miller_loop(p, q))))
+        assert np.array_equal(f, C.miller_loop(p, q)) and np.array_equal(g, C.final_exponentiation(C.miller_loop(p, q)))
 
 def bench():
     n = 1 << 18
@@ -69,18 +83,18 @@ def bench():
     a = np.tile(a, (n // 64, 1)); b = np.tile(b, (n // 64, 1))
     for op, iters in (("mul", 64), ("sqr", 64), ("sparse", 64), ("cycsqr", 64)):
         r = []
-        for pair in (0, 1):
+        for pair in (0, 1, 2):
             _, ms = run_op(pair, op, a, b if op in ("mul", "sparse") else None, iters=iters, reps=3)
             r.append(ms)
-        print(f"{op:7s} x{iters}: single-lane {r[0]:8.3f} ms   lane-pair {r[1]:8.3f} ms   ratio {r[0] / r[1]:.3f}")
+        print(f"{op:7s} x{iters}: single-lane {r[0]:8.3f} ms   lane-pair {r[1]:8.3f} ms   lane-pair/29 {r[2]:8.3f} ms")
     n = 1 << 20
     p, q = pairing_inputs(64)
     p = np.tile(p, (n // 64, 1)); q = np.tile(q, (n // 64, 1))
     dp, dq = eng.to_device_soa(p, 8), eng.to_device_soa(q, 16)
     dg = eng.empty((48, n))
-    for pair in (0, 1):
+    for pair in (0, 1, 2):
         ms = lib.pl_pairing(pair, dp.ptr, dq.ptr, dg.ptr, None, n, 3)
-        print(f"pairing n=2^20 {'lane-pair ' if pair else 'single-lane'}: {ms:8.2f} ms  -> {n / ms / 1e3:.3f} M pairings/s")
+        print(f"pairing n=2^20 mode {pair}: {ms:8.2f} ms  -> {n / ms / 1e3:.3f} M pairings/s")
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["parity", "pairing", "bench"]
