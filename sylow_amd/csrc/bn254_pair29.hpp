@@ -221,6 +221,99 @@ BN_DEV W12 w12_cyclotomic_sqr(const W12& f) {
   return r;
 }
 
+// ---- G2 doubling / addition steps on the carry-free core --------------------------------------------------------------
+// value / 2 mod p for an N-class value: add p when odd, renormalise and shift (|V| <= (|V(a)| + 1) / 2), N-class result
+BN_DEV F29 f29_halve(const F29& a) {
+  i32 p[9]; f29_p(p);
+  const i32 m = -(a.v[0] & 1);                 // all-ones when odd
+  i32 lo[9];
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    i32 t = a.v[i] + (p[i] & m) + c;
+    lo[i] = t & BN_M29;
+    c = t >> 29;
+  }
+  lo[8] = a.v[8] + (p[8] & m) + c;
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (lo[i] >> 1) | ((lo[i + 1] & 1) << 28);
+  r.v[8] = lo[8] >> 1;
+  return r;
+}
+BN_DEV W2 w2_halve(const W2& a) { return W2{f29_halve(a.c)}; }
+BN_DEV W2 w2_triple(const W2& a) { return W2{f29_add(f29_add(a.c, a.c), a.c)}; }   // lazy, limbs < 3 * 2^29 for N input
+struct G2W { W2 x, y, z; };      // coordinates R / N with |V| <= 2
+// pairing.rs:798-818.  Line coefficients: l0 R, l1 D, l2 N.
+BN_DEV void g2_doubling_step29(G2W& r, W2& l0, W2& l1, W2& l2, const W2& twist_b) {
+  const W2 a = w2_halve(w2_mul(r.x, r.y));                              // N
+  l2 = w2_norm(w2_triple(w2_sqr(r.x)));                                  // 3 X^2, N, |V| < 3.4
+  const W2 b = w2_sqr(r.y);
+  const W2 c = w2_sqr(r.z);
+  const W2 h = w2_norm(w2_sub(w2_sqr(w2_norm(w2_add(r.y, r.z))), w2_add(b, c)));   // (Y+Z)^2 - (b+c), N, |V| < 3.4
+  const W2 e = w2_mul(twist_b, w2_norm(w2_triple(c)));                   // b' * 3c, N
+  l1 = w2_neg(h);                                                        // D
+  r.z = w2_mul(b, h);
+  l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);                                 // xi (e - b), R
+  const W2 f = w2_norm(w2_triple(e));                                    // 3e, N, |V| < 3.4
+  r.x = w2_mul(a, w2_sub(b, f));                                         // a (b - f): D operand
+  const W2 g = w2_halve(w2_norm(w2_add(b, f)));                          // (b + f) / 2, N
+  r.y = w2_lin2(w2_sqr(g), 1, w2_sqr(e), -3);                            // g^2 - 3 e^2, R
+}
+// pairing.rs:756-772, Q = (bx, by) affine, R-class.  Line coefficients: l0 R, l1 D, l2 D.
+BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2) {
+  const W2 d = w2_sub(r.x, w2_mul(r.z, bx));                             // D
+  const W2 e = w2_sub(r.y, w2_mul(r.z, by));                             // D
+  l0 = w2_xi_lin(w2_sub(w2_mul(e, bx), w2_mul(d, by)), 1, bx, 0);        // xi (e bx - d by), R
+  l1 = d;
+  l2 = w2_neg(e);
+  const W2 dn = w2_norm(d), en = w2_norm(e);                             // N (squarings need non-negative limbs)
+  const W2 f = w2_sqr(dn);
+  const W2 h = w2_mul(dn, f);
+  const W2 i = w2_mul(r.x, f);
+  const W2 j = w2_norm(w2_sub(w2_add(w2_mul(r.z, w2_sqr(en)), h), w2_add(i, i)));   // z e^2 + h - 2i, N, |V| < 5
+  r.z = w2_mul(r.z, h);
+  r.x = w2_mul(dn, j);
+  r.y = w2_norm(w2_sub(w2_mul(en, w2_sub(i, j)), w2_mul(h, r.y)));       // e (i - j) - h y, N
+}
+BN_DEV W12 w12_line29(const W12& f, const W2& l0, const W2& l1, const W2& l2, const F29& px, const F29& py) {
+  return w12_sparse_mul(f, l0, w2_scale(l1, py), w2_scale(l2, px));
+}
+// whole Miller loop on the carry-free core (points and accumulator)
+BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys) {
+  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
+  const W2 twist_b = w2_const(C_TWIST_B);
+  W12 f;
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  G2W r{qx, qy, w2_from_s2(s2_one())};
+  W2 l0, l1, l2;
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step29(r, l0, l1, l2, twist_b);
+    f = w12_sqr(f);
+    f = w12_line29(f, l0, l1, l2, px, py);
+    if ((nz >> (63 - i)) & 1) {
+      const bool neg = (ng >> (63 - i)) & 1;
+      g2_addition_step29(r, qx, neg ? nqy : qy, l0, l1, l2);
+      f = w12_line29(f, l0, l1, l2, px, py);
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qxs, qys);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  q2y = s2_neg(q2y);
+  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  f = w12_line29(f, l0, l1, l2, px, py);
+  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(q2y), l0, l1, l2);
+  f = w12_line29(f, l0, l1, l2, px, py);
+  w12_to_s12(fout, f);
+}
+
 // ---- Miller loop: G2 point arithmetic on the saturated lane-pair core, accumulator on the carry-free core ----------
 BN_DEV W12 w12_line(const W12& f, const S2& l0, const S2& l1, const S2& l2, const F29& px, const F29& py) {
   // sparse_mul(c0, c1 * P.y, c2 * P.x) (pairing.rs:598); f29_from_fp yields N-class digits with V <= 32, the products

@@ -87,17 +87,16 @@ __global__ void __launch_bounds__(256, 2) k_pw_op(int op, const u64* a, const u6
   }
   store_s12(out, n, i, odd, sr);
 }
-__global__ void __launch_bounds__(256, 2) k_pw_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n) {
+__global__ void __launch_bounds__(256, 2) k_pw_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n, int stage) {
   size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   if (i >= n) return;
   Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
   pl::S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
   pl::S12 f, g;
-  pl::miller_loop29(f, px, py, qx, qy);
-  if (fout) store_s12(fout, n, i, odd, f);
-  pl::final_exponentiation29(g, f);
-  store_s12(gout, n, i, odd, g);
+  if (stage != 2) pl::miller_loop29(f, px, py, qx, qy); else load_s12(f, fout, n, i, odd);
+  if (fout && stage != 2) store_s12(fout, n, i, odd, f);
+  if (stage != 1) { pl::final_exponentiation29(g, f); store_s12(gout, n, i, odd, g); }
 }
 BN_DEV void load_fp12(Fp12& r, const u64* base, size_t n, size_t i) {
   Fp* f = reinterpret_cast<Fp*>(&r);
@@ -131,28 +130,37 @@ __global__ void __launch_bounds__(256, 2) k_sl_op(int op, const u64* a, const u6
   store_fp12(out, n, i, r);
 }
 // pairing: P [8][n], Q [16][n] -> Gt [48][n]
-__global__ void __launch_bounds__(256, 2) k_pl_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n) {
+__global__ void __launch_bounds__(256, 2) k_pl_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n, int stage) {
   size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   if (i >= n) return;
   Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
   pl::S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
   pl::S12 f, g;
-  pl::miller_loop(f, px, py, qx, qy);
-  if (fout) store_s12(fout, n, i, odd, f);
-  pl::final_exponentiation(g, f);
-  store_s12(gout, n, i, odd, g);
+  if (stage != 2) pl::miller_loop(f, px, py, qx, qy); else load_s12(f, fout, n, i, odd);
+  if (fout && stage != 2) store_s12(fout, n, i, odd, f);
+  if (stage != 1) { pl::final_exponentiation(g, f); store_s12(gout, n, i, odd, g); }
 }
-__global__ void __launch_bounds__(256, 2) k_sl_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n) {
+__global__ void __launch_bounds__(256, 2) k_pg_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n, int stage) {
+  size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+  pl::S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+  pl::S12 f, g;
+  if (stage != 2) pl::miller_loop29g(f, px, py, qx, qy); else load_s12(f, fout, n, i, odd);
+  if (fout && stage != 2) store_s12(fout, n, i, odd, f);
+  if (stage != 1) { pl::final_exponentiation29(g, f); store_s12(gout, n, i, odd, g); }
+}
+__global__ void __launch_bounds__(256, 2) k_sl_pairing(const u64* pxy, const u64* qxy, u64* gout, u64* fout, size_t n, int stage) {
   size_t i = TID;
   if (i >= n) return;
   Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
   Fp2 qx{load_fp(qxy, n, i, 0), load_fp(qxy, n, i, 4)}, qy{load_fp(qxy, n, i, 8), load_fp(qxy, n, i, 12)};
   Fp12 f, g;
-  miller_loop(f, px, py, qx, qy);
-  if (fout) store_fp12(fout, n, i, f);
-  final_exponentiation(g, f);
-  store_fp12(gout, n, i, g);
+  if (stage != 2) miller_loop(f, px, py, qx, qy); else load_fp12(f, fout, n, i);
+  if (fout && stage != 2) store_fp12(fout, n, i, f);
+  if (stage != 1) { final_exponentiation(g, f); store_fp12(gout, n, i, g); }
 }
 
 static float timed(void (*launch)(void*), void* ctx, int reps) {
@@ -177,12 +185,13 @@ static void launch_op(void* p) {
   else if (c->pair) k_pl_op<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
   else k_sl_op<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256)>>>(c->op, c->a, c->b, c->out, c->n, c->iters);
 }
-struct PairCtx { int pair; const u64 *p, *q; u64 *g, *f; size_t n; };
+struct PairCtx { int pair; const u64 *p, *q; u64 *g, *f; size_t n; int stage; };
 static void launch_pairing(void* p) {
   PairCtx* c = (PairCtx*)p;
-  if (c->pair == 2) k_pw_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
-  else if (c->pair) k_pl_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
-  else k_sl_pairing<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n);
+  if (c->pair == 3) k_pg_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n, c->stage);
+  else if (c->pair == 2) k_pw_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n, c->stage);
+  else if (c->pair) k_pl_pairing<<<dim3((unsigned)((2 * c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n, c->stage);
+  else k_sl_pairing<<<dim3((unsigned)((c->n + 255) / 256)), dim3(256)>>>(c->p, c->q, c->g, c->f, c->n, c->stage);
 }
 extern "C" {
 // returns average ms per launch (reps timed launches after one warm-up), < 0 on error
@@ -190,8 +199,8 @@ float pl_op(int pair, int op, const u64* a, const u64* b, u64* out, size_t n, in
   OpCtx c{pair, op, a, b, out, n, iters};
   return timed(launch_op, &c, reps);
 }
-float pl_pairing(int pair, const u64* p, const u64* q, u64* g, u64* f, size_t n, int reps) {
-  PairCtx c{pair, p, q, g, f, n};
+float pl_pairing(int pair, const u64* p, const u64* q, u64* g, u64* f, size_t n, int reps, int stage) {
+  PairCtx c{pair, p, q, g, f, n, stage};
   return timed(launch_pairing, &c, reps);
 }
 }

@@ -6,9 +6,9 @@ OUT=gpurun_out/prof_pl
 rm -rf $OUT; mkdir -p $OUT
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/pl/run_pl.py bench > $OUT/$name.log 2>&1; }
 run sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
-run stall SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_INSTS_LDS
-run fetch FETCH_SIZE
-run write WRITE_SIZE
+
+
+
 python3 - <<PY
 import csv, collections, glob, json
 out=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(lambda: collections.defaultdict(int))

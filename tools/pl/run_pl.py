@@ -11,7 +11,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "tools", "pl", "libpl_test.so"))
 lib.pl_op.restype = ctypes.c_float
 lib.pl_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
 lib.pl_pairing.restype = ctypes.c_float
-lib.pl_pairing.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+lib.pl_pairing.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
 eng = Engine()
 rng = Xoshiro(SEED + 777)
 OPS = {"mul": 0, "sqr": 1, "inv": 2, "frob1": 3, "frob2": 4, "frob3": 5, "sparse": 6, "cycsqr": 7, "expz": 8, "final": 9}
@@ -69,9 +69,9 @@ def pairing_parity():
     n = 33
     p, q = pairing_inputs(n)
     dp, dq = eng.to_device_soa(p, 8), eng.to_device_soa(q, 16)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         dg, df = eng.empty((48, n)), eng.empty((48, n))
-        assert lib.pl_pairing(mode, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 1) >= 0
+        assert lib.pl_pairing(mode, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 1, 0) >= 0
         f, g = eng.from_device_soa(df), eng.from_device_soa(dg)
         print(f"mode {mode} miller raw parity:", np.array_equal(f, C.miller_loop(p, q)))
         print(f"mode {mode} pairing Gt parity:", np.array_equal(g, C.final_exponentiation(C.miller_loop(p, q))))
@@ -91,10 +91,12 @@ def bench():
     p, q = pairing_inputs(64)
     p = np.tile(p, (n // 64, 1)); q = np.tile(q, (n // 64, 1))
     dp, dq = eng.to_device_soa(p, 8), eng.to_device_soa(q, 16)
-    dg = eng.empty((48, n))
-    for pair in (0, 1, 2):
-        ms = lib.pl_pairing(pair, dp.ptr, dq.ptr, dg.ptr, None, n, 3)
-        print(f"pairing n=2^20 mode {pair}: {ms:8.2f} ms  -> {n / ms / 1e3:.3f} M pairings/s")
+    dg, df = eng.empty((48, n)), eng.empty((48, n))
+    for pair in (0, 1, 2, 3):
+        ms = lib.pl_pairing(pair, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 3, 0)
+        m1 = lib.pl_pairing(pair, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 3, 1)
+        m2 = lib.pl_pairing(pair, dp.ptr, dq.ptr, dg.ptr, df.ptr, n, 3, 2)
+        print(f"pairing n=2^20 mode {pair}: {ms:8.2f} ms  -> {n / ms / 1e3:.3f} M pairings/s   (miller {m1:7.2f} ms, final exp {m2:7.2f} ms)")
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["parity", "pairing", "bench"]
