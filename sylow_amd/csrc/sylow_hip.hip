@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "bn254_hash.hpp"
@@ -633,6 +634,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
 }
 
 
+#include "pair_kernels.hpp"
+
 // ------------------------------------------------------------------ EVM alt_bn128 adapter -------
 // Byte-level batches of the three precompile shapes of examples/reth_bn128.rs:99-217 (EIP-196/197):
 // 32-byte big-endian field elements (Fp::from_be_bytes rejects >= p, fp.rs:686-719), (0,0) encodes the
@@ -981,6 +984,7 @@ static int32_t fail(hipError_t e, const char* what) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(e_, #x); } while (0)
 #define ARGCHK(c) do { if (!(c)) { snprintf(g_err, sizeof(g_err), "bad argument: %s", #c); return SYLOW_HIP_E_ARG; } } while (0)
 #define GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream
+static bool single_lane();
 #define LAUNCHED() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "kernel launch"); return SYLOW_HIP_OK; } while (0)
 
 extern "C" {
@@ -1108,22 +1112,26 @@ int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q
 }
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
-  k_miller_loop<<<GRID(n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
+  if (single_lane()) { k_miller_loop<<<GRID(n)>>>(p_xy, q_xy, f_out, n); LAUNCHED(); }
+  plk::k_miller_loop<<<GRID(2 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
 }
 int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
-  k_final_exp<<<GRID(n)>>>(f, gt_out, n); LAUNCHED();
+  if (single_lane()) { k_final_exp<<<GRID(n)>>>(f, gt_out, n); LAUNCHED(); }
+  plk::k_final_exp<<<GRID(2 * n)>>>(f, gt_out, n); LAUNCHED();
 }
 int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && gt_out); if (!n) return SYLOW_HIP_OK;
-  k_pairing<<<GRID(n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
+  if (single_lane()) { k_pairing<<<GRID(n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED(); }
+  plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
 }
 
 int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
-  k_multi_pairing<<<GRID(n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED();
+  if (single_lane()) { k_multi_pairing<<<GRID(n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED(); }
+  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED();
 }
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
 static void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
@@ -1141,6 +1149,33 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
   ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; dst_arg(dp, nullptr, 0);
   k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
+}
+// The pairing-based entry points run on lane pairs (pair_kernels.hpp).  SYLOW_HIP_SINGLE_LANE=1 selects the one-element-per-lane
+// kernels instead: the slower twin kept for A/B measurements and as a second implementation for the parity tests.
+static bool single_lane() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SYLOW_HIP_SINGLE_LANE"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+static int32_t ensure_g2gen_lines29(void* stream) {
+  static bool ready[64] = {false};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { snprintf(g_err, sizeof(g_err), "device index out of range"); return SYLOW_HIP_E_ARG; }
+  if (!ready[dev]) {
+    plk::k_g2_lines29<<<1, 64, 0, (hipStream_t)stream>>>(nullptr, 0, 0, nullptr);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return fail(e_, "k_g2_lines29 launch");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    ready[dev] = true;
+  }
+  return SYLOW_HIP_OK;
+}
+static int32_t gen_table29(const bn254::i32** out) {
+  void* p = nullptr;
+  HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(plk::g_g2gen_lines29)));
+  *out = (const bn254::i32*)p;
+  return SYLOW_HIP_OK;
 }
 // one-time (per device) construction of the G2-generator line table used by the fused verifier
 static int32_t ensure_g2gen_lines(void* stream) {
@@ -1161,31 +1196,59 @@ static int32_t ensure_g2gen_lines(void* stream) {
 int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                    const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  int32_t rc = ensure_g2gen_lines(stream);
-  if (rc != SYLOW_HIP_OK) return rc;
   DstPrime dp; dst_arg(dp, nullptr, 0);
-  k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+  if (single_lane()) {
+    int32_t rc = ensure_g2gen_lines(stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    k_bls_verify<<<GRID(n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+  }
+  int32_t rc = ensure_g2gen_lines29(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  const bn254::i32* gen = nullptr;
+  if ((rc = gen_table29(&gen)) != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify<<<GRID(2 * n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
 }
 
 int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                          const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  int32_t rc = ensure_g2gen_lines(stream);
-  if (rc != SYLOW_HIP_OK) return rc;
   DstPrime dp; dst_arg(dp, nullptr, 0);
-  k_bls_verify_fused<false><<<GRID(n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+  if (single_lane()) {
+    int32_t rc = ensure_g2gen_lines(stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    k_bls_verify_fused<false><<<GRID(n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n); LAUNCHED();
+  }
+  int32_t rc = ensure_g2gen_lines29(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  const bn254::i32* gen = nullptr;
+  if ((rc = gen_table29(&gen)) != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify_fused<false><<<GRID(2 * n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
 }
 int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  int32_t rc = ensure_g2gen_lines(stream);
-  if (rc != SYLOW_HIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  u32* table = nullptr;
-  HIPCHK(hipMallocAsync((void**)&table, 87 * 48 * sizeof(u32), st));
-  k_g2_lines<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);          // the key is a 1-element SoA array
   DstPrime dp; dst_arg(dp, nullptr, 0);
-  k_bls_verify_fused<true><<<GRID(n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n);
+  if (single_lane()) {
+    int32_t rc = ensure_g2gen_lines(stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    u32* table = nullptr;
+    HIPCHK(hipMallocAsync((void**)&table, 87 * 48 * sizeof(u32), st));
+    k_g2_lines<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);          // the key is a 1-element SoA array
+    k_bls_verify_fused<true><<<GRID(n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n);
+    hipError_t e_ = hipGetLastError();
+    HIPCHK(hipFreeAsync(table, st));
+    if (e_ != hipSuccess) return fail(e_, "kernel launch");
+    return SYLOW_HIP_OK;
+  }
+  int32_t rc = ensure_g2gen_lines29(stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  const bn254::i32* gen = nullptr;
+  if ((rc = gen_table29(&gen)) != SYLOW_HIP_OK) return rc;
+  bn254::i32* table = nullptr;
+  HIPCHK(hipMallocAsync((void**)&table, plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st));
+  plk::k_g2_lines29<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
+  plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n);
   hipError_t e_ = hipGetLastError();
   HIPCHK(hipFreeAsync(table, st));
   if (e_ != hipSuccess) return fail(e_, "kernel launch");
@@ -1220,7 +1283,8 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   uint8_t* pst = qinf + np;
   uint8_t* isone = pst + np;
   if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
-  k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
+  if (single_lane()) k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
+  else plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
   k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
   hipError_t e_ = hipGetLastError();
   HIPCHK(hipFreeAsync(ws, st));
