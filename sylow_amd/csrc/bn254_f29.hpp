@@ -228,6 +228,77 @@ BN_DEV F29 f29_reduce_from(LIMB limb) {
   return r;
 }
 
+// ---- squaring and fixed-exponent powers ----------------------------------------------------------------------------------
+// a^2 / R': the 36 cross products are taken once against the doubled operand (45 multiply-adds instead of 81), same
+// column bound as f29_mul.  Input N-class (L <= 1), output normalized.
+BN_DEV F29 f29_sqr(const F29& a) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  i32 a2[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a2[i] = a.v[i] * 2;
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    i64 x = acc, y = 0;
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; 2 * i < k; ++i) { if ((i - lo) & 1) y += (i64)a.v[i] * a2[k - i]; else x += (i64)a.v[i] * a2[k - i]; }
+    if ((k & 1) == 0) y += (i64)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+    }
+    acc = x + y;
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      acc += (i64)m[k] * p[0];
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+// a^e for a 256-bit exponent given as 8 wave-uniform words: 4-bit fixed windows over the carry-free core (254 squarings of
+// 126 multiply-adds + at most 64 products + 14 for the table, against 381 saturated Montgomery products of 256 multiply-add
+// / add-carry pairs each).  0^e = 0, so inv(0) = 0 as in the reference (fp.rs:418-433, test fp.rs:1126-1132).
+BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5, u32 e6, u32 e7) {
+  const u32 e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
+  const F29 af = f29_from_fp(a);
+  const F29 x = f29_reduce_from([&](int i) { return (i64)af.v[i]; });
+  F29 tab[16];
+  tab[1] = x;
+#pragma unroll 1
+  for (int i = 2; i < 16; ++i) tab[i] = f29_mul(tab[i - 1], x);
+  F29 r = x;
+  bool started = false;
+#pragma unroll 1
+  for (int w = 7; w >= 0; --w) {
+    const u32 word = e[w];
+#pragma unroll 1
+    for (int nib = 7; nib >= 0; --nib) {
+      if (started) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) r = f29_sqr(r);
+      }
+      const u32 idx = (word >> (4 * nib)) & 15u;
+      if (idx) {
+        r = started ? f29_mul(r, tab[idx]) : tab[idx];
+        started = true;
+      }
+    }
+  }
+  if (!started) {                                  // e == 0: the Montgomery one
+    const F29 one = f29_from_fp(fp_one());
+    r = f29_reduce_from([&](int i) { return (i64)one.v[i]; });
+  }
+  return f29_to_fp(r);
+}
+
 // ---- Fp2 on the carry-free core ---------------------------------------------------------------------------------------
 struct U2 { F29 c0, c1; };
 BN_DEV U2 u2_add(const U2& a, const U2& b) { return U2{f29_add(a.c0, b.c0), f29_add(a.c1, b.c1)}; }

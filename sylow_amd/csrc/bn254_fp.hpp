@@ -447,26 +447,9 @@ BN_DEV Fp fp_small(int k) {
   return r;
 }
 
-// a^e for a fixed 256-bit exponent given as 8 wave-uniform u32 words, MSB-first square-and-multiply.
-// Out-of-line: it is called from the inversion / sqrt / Legendre paths and is a rolled loop.
-BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5, u32 e6, u32 e7) {
-  const u32 e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
-  Fp r = fp_one();
-  bool started = false;
-#pragma unroll 1
-  for (int w = 7; w >= 0; --w) {
-    u32 word = e[w];
-#pragma unroll 1
-    for (int bit = 31; bit >= 0; --bit) {
-      if (started) r = fp_mul(r, r);
-      if ((word >> bit) & 1) {
-        r = started ? fp_mul(r, a) : a;
-        started = true;
-      }
-    }
-  }
-  return r;
-}
+// a^e for a fixed 256-bit exponent given as 8 wave-uniform u32 words (inversion / sqrt / Legendre paths).
+// Defined in bn254_f29.hpp: the chain runs on the carry-free core (dedicated squaring, 4-bit windows).
+BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5, u32 e6, u32 e7);
 // a^(p-2): inv(0) = 0 like the reference (fp.rs:418-433, test fp.rs:1126-1132)
 BN_DEV Fp fp_inv(const Fp& a) {
   return fp_pow_words(a, BN_P0 - 2, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
