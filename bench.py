@@ -30,11 +30,18 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ISSUE_PEAK_GINSTR = 580.0             # measured VOP3 wave-instr/s ceiling, profiles/r01_issue_rate_ubench.txt
 PAIRING_BYTES = 576                   # 64 (G1 affine) + 128 (G2 affine) + 384 (Gt)  -- SURVEY.md §8(d)
 VERIFY_BYTES = 225                    # pk 128 + sig 64 + 32-byte msg + flag
-# rocprofv3 PMC facts about k_pairing (profiles/r01_pairing_v4/pmc_k_pairing.json, n = 2^20 = 16384 waves);
-# bench.py cannot collect PMC counters itself, so the per-launch constants measured there are reused here
-# and scale with n.  Refresh them with tools/prof_pairing.sh whenever the kernel changes.
-PAIRING_VALU_INSTR_PER_WAVE = 1.0627981312e11 / 16384          # SQ_INSTS_VALU per wavefront (64 pairings)
-PAIRING_HBM_BYTES_PER_WAVE = (2 * 226712579.0625 + 365548158.625) * 1024 / 16384   # 2*FETCH_SIZE + WRITE_SIZE (KiB), gfx950 correction
+# rocprofv3 PMC facts about the dominant kernel (plk::k_pairing): bench.py cannot collect PMC counters itself, so the
+# per-pairing constants measured by tools/prof_pairing.sh (separate --pmc passes, n = 2^20) are read from the committed summary
+# profiles/pmc_current.json and scale with n.  Refresh with tools/prof_pairing.sh whenever the kernel changes.
+def _load_pmc():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
+PMC = _load_pmc()
 
 G1 = [1, 2]
 G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
@@ -239,22 +246,25 @@ def main():
             "metric": "BN254 optimal-ate pairings/s", "value": value, "unit": "pairings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (8x32-bit Montgomery, exact integer)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i32/u32 limbs (9x29-bit carry-free core + 8x32-bit Montgomery, exact integer)", "data": "synthetic",
             "config": {"workload": f"pairing_batch: 2^{args.log2n} independent e(a_i*G1, b_i*G2) per GPU per step "
                                    "(BASELINE.json configs[2] shape at the metric's batch=2^20), affine SoA inputs resident in HBM",
                        "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": PAIRING_HBM_BYTES_PER_WAVE * (n / 64),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pairing_v4): "
-                                         "per-lane scratch frames of Fp12 temporaries, not algorithmic re-reads",
-                         "kernel": "k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (PMC["hbm_bytes_per_pairing"] * n) if PMC else None,
+                         "traffic_note": ("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + PMC["source"] + "): "
+                                          "what is left beyond the algorithmic bytes is the stack frame of the final exponentiation's "
+                                          "straight-line part; the Miller loop and the f^x loops run out of registers") if PMC else None,
+                         "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
         }
-        if PAIRING_VALU_INSTR_PER_WAVE:
-            ginstr = PAIRING_VALU_INSTR_PER_WAVE * (n / 64) / (kern_ms * 1e-3) / 1e9
+        if PMC:
+            ginstr = PMC["valu_instr_per_pairing"] * n / (kern_ms * 1e-3) / 1e9
             out["issue_roofline"] = {"bound": "valu-issue", "achieved": ginstr, "peak": ISSUE_PEAK_GINSTR,
                                      "unit": "G wave-instr/s", "frac": ginstr / ISSUE_PEAK_GINSTR,
-                                     "note": "the roof that actually binds a pairing (integer carry chains): SQ_INSTS_VALU per launch / "
-                                             "kernel time vs the measured VOP3 issue ceiling (profiles/r01_issue_rate_ubench.txt)"}
+                                     "note": "the roof that actually binds a pairing (integer multiply-add chains): SQ_INSTS_VALU per "
+                                             "launch / kernel time vs the measured VOP3 issue ceiling (profiles/r01_issue_rate_ubench.txt: "
+                                             "~580 G wave-instr/s for VOP3, 477-520 for pure v_mad_*64 streams, ~900 for VOP2 adds)"}
         if aux:
             out["aux"] = aux
         if not args.no_cpu:

@@ -21,8 +21,12 @@ for f in sorted(glob.glob('$OUT/*/p_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         if 'k_pairing' in r['Kernel_Name']: agg[r['Counter_Name']]+=float(r['Counter_Value'])
     out.update(agg)
-out['note']='k_pairing, one launch, n=2^20 (16384 waves). FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3 (gfx950: FETCH_SIZE under-reports wide streaming reads 2x, MI355X_MICROARCH.md)'
+out['note']='plk::k_pairing (lane pairs), one launch, n=2^20 (32768 waves). FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3 (gfx950: FETCH_SIZE under-reports wide streaming reads 2x, MI355X_MICROARCH.md)'
 json.dump(out, open('$OUT/pmc_k_pairing.json','w'), indent=1)
+n = 1 << 20
+json.dump({"source": "profiles/r01_pairing_$TAG".replace("r01_pairing_r01_", "r01_pairing_"), "n": n,
+           "valu_instr_per_pairing": out["SQ_INSTS_VALU"] / n,
+           "hbm_bytes_per_pairing": (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024 / n}, open('$OUT/pmc_current.json', 'w'), indent=1)
 print(json.dumps(out))
 PY
 cat $OUT/trace/p_kernel_stats.csv | head -4
