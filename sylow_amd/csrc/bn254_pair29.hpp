@@ -408,15 +408,31 @@ BN_NOINLINE void miller_loop29(S12& fout, const Fp& pxs, const Fp& pys, const S2
 BN_NOINLINE void w12_mul_nl(W12& r, const W12& a, const W12& b) { r = w12_mul(a, b); }
 BN_NOINLINE void w12_cyclotomic_sqr_nl(W12& r, const W12& a) { r = w12_cyclotomic_sqr(a); }
 template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) { r = w12_frobenius<E>(a); }
+// pairing.rs:366-392: f^x then conjugate, f in the cyclotomic subgroup (f^-1 = conj f).  Width-4 signed-digit form of
+// x = 4965661367192848881: 14 non-zero digits in {+-1, +-3, +-5, +-7} -> 62 cyclotomic squarings + 13 products + 3 for the
+// table {f, f^3, f^5, f^7} (the reference's 256-step square-and-multiply reaches the same field element with 27 products).
+//   digit i != 0: BN_X_W4_NZ;  negative: _NEG;  (|d| - 1) / 2 = table index: bits _I0, _I1
+#define BN_X_W4_NZ 0x4108844442110211ull
+#define BN_X_W4_NEG 0x0008004400010010ull
+#define BN_X_W4_I0 0x0008800400110000ull
+#define BN_X_W4_I1 0x0100044002110200ull
 BN_NOINLINE void exp_by_neg_z29(W12& r, const W12& f) {
-  const W12 f3 = w12_mul(w12_cyclotomic_sqr(f), f);
-  W12 res = f;
-  const u64 nz = 0x4908924444891211ull, ng = 0x0108000400880210ull, th = 0x0108804404880200ull;
+  W12 tab[4];
+  tab[0] = f;
+  {
+    W12 f2;
+    w12_cyclotomic_sqr_nl(f2, f);
+    w12_mul_nl(tab[1], f2, f);
+    w12_mul_nl(tab[2], tab[1], f2);
+    w12_mul_nl(tab[3], tab[2], f2);
+  }
+  W12 res = f;                                    // top digit (bit 62) is +1
+  const u64 nz = BN_X_W4_NZ, ng = BN_X_W4_NEG, i0 = BN_X_W4_I0, i1 = BN_X_W4_I1;
 #pragma unroll 1
   for (int i = 61; i >= 0; --i) {
     res = w12_cyclotomic_sqr(res);
     if ((nz >> i) & 1) {
-      W12 m = ((th >> i) & 1) ? f3 : f;
+      W12 m = tab[((i0 >> i) & 1) | (((i1 >> i) & 1) << 1)];
       if ((ng >> i) & 1) m = w12_conj(m);
       res = w12_mul(res, m);
     }
