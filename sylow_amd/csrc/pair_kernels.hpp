@@ -168,6 +168,118 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   }
 }
 
+// ------------------------------------------------------------------ G2 group law on lane pairs -------------------------------
+// The complete RCB'15 formulas of bn254_pairing.hpp (proj_double / proj_add, generic over the coordinate field like
+// group.rs) instantiated over the lane-pair Fp2: a projective G2 point is 24 VGPRs per lane instead of 48.
+struct OpsS2 {
+  typedef S2 F;
+  static BN_DEV F add(const F& a, const F& b) { return s2_add(a, b); }
+  static BN_DEV F sub(const F& a, const F& b) { return s2_sub(a, b); }
+  static BN_DEV F neg(const F& a) { return s2_neg(a); }
+  static BN_DEV F mul(const F& a, const F& b) { return s2_mul(a, b); }
+  static BN_DEV F zero() { return s2_zero(); }
+  static BN_DEV F one() { return s2_one(); }
+  static BN_DEV bool is_zero(const F& a) { return s2_is_zero(a); }
+  static BN_DEV F select(const F& a, const F& b, bool c) { return s2_select(a, b, c); }
+  static BN_DEV F mul_b3(const F& a) { return s2_mul(a, s2_const(C_TWIST_B3)); }
+};
+typedef Proj<S2> G2Q;
+BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsS2>(p); }
+BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsS2>(p, q); }
+BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
+  out = scalar_mul_window<OpsS2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
+                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; });
+}
+// group.rs:475-495
+BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
+  const S2 zi = s2_inv(p.z);
+  inf = s2_is_zero(zi);
+  x = s2_select(s2_mul(p.x, zi), s2_zero(), inf);
+  y = s2_select(s2_mul(p.y, zi), s2_one(), inf);
+}
+BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-297
+  return s2_eq(s2_sub(s2_sqr(y), s2_mul(s2_sqr(x), x)), s2_const(C_TWIST_B));
+}
+// g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
+BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
+  const G2Q q{x, y, s2_one()};
+  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
+  G2Q a;
+  g2q_scalar_mul(a, q, bx);
+  // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
+  auto psi = [](G2Q& r, const G2Q& p) {
+    r.x = s2_mul(s2_const(C_EPS_EXP0), s2_conj(p.x));
+    r.y = s2_mul(s2_const(C_EPS_EXP1), s2_conj(p.y));
+    r.z = s2_conj(p.z);
+  };
+  G2Q b, c, l, r;
+  psi(b, a);
+  g2q_add(a, a, q);
+  psi(c, b);
+  g2q_add(l, c, b);
+  g2q_add(l, l, a);
+  psi(r, c);
+  g2q_double(r, r);
+  const G2Q nl = proj_neg<OpsS2>(l);
+  g2q_add(r, r, nl);
+  return s2_is_zero(r.z);
+}
+BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
+  return G2Q{load_s2(xy, n, i, 0, odd), load_s2(xy, n, i, 8, odd), (inf && inf[i]) ? s2_zero() : s2_one()};
+}
+BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {
+  S2 x, y; bool rinf;
+  g2q_to_affine(x, y, rinf, r);
+  store_s2(oxy, n, i, 0, odd, x); store_s2(oxy, n, i, 8, odd, y);
+  if (!odd) oinf[i] = rinf ? 1 : 0;
+}
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G2Q r;
+  g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k);
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  G2Q r;
+  g2q_add(r, load_g2q(axy, ainf, n, i, odd), load_g2q(bxy, binf, n, i, odd));
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  G2Q r;
+  g2q_double(r, load_g2q(axy, ainf, n, i, odd));
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const G2Q p{load_s2(pxyz, n, i, 0, odd), load_s2(pxyz, n, i, 8, odd), load_s2(pxyz, n, i, 16, odd)};
+  store_g2q_affine(oxy, oinf, n, i, odd, p);
+}
+// g2.rs:460-525 on an affine input
+__global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* qinf, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  if (!(qinf && qinf[i])) {                       // Z == 0 passes both tests (g2.rs:469,510)
+    const S2 x = load_s2(qxy, n, i, 0, odd), y = load_s2(qxy, n, i, 8, odd);
+    if (!g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    else if (!g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+  }
+  if (!odd) status[i] = st;
+}
+
 // ------------------------------------------------------------------ hash to G1 on a lane pair ---------------------------
 // g1.rs:307-331: map(u0) + map(u1).  The even lane maps u0, the odd lane u1 (the two SvdW maps are independent), the points
 // are exchanged and both lanes finish with the same complete addition and affine normalisation.

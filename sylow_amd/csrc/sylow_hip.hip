@@ -684,29 +684,6 @@ BN_DEV void evm_write_g1(uint8_t* b, const G1P& p) {
   write_be_fp(b, inf ? zero : fp_from_mont(x));
   write_be_fp(b + 32, inf ? zero : fp_from_mont(y));
 }
-// subgroup test shared with k_g2_subgroup_check (g2.rs:488-513); q on the twist, affine
-BN_NOINLINE bool g2_in_subgroup(const Fp2& x, const Fp2& y) {
-  G2P q{x, y, fp2_one()};
-  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
-  G2P a;
-  g2_scalar_mul(a, q, bx);
-  auto psi = [](G2P& r, const G2P& p) {
-    r.x = fp2_mul(fp2_const(C_EPS_EXP0), fp2_conj(p.x));
-    r.y = fp2_mul(fp2_const(C_EPS_EXP1), fp2_conj(p.y));
-    r.z = fp2_conj(p.z);
-  };
-  G2P b, c, l, r;
-  psi(b, a);
-  g2_add(a, a, q);
-  psi(c, b);
-  g2_add(l, c, b);
-  g2_add(l, l, a);
-  psi(r, c);
-  g2_double(r, r);
-  G2P nl = proj_neg<OpsFp2>(l);
-  g2_add(r, r, nl);
-  return fp2_is_zero(r.z);
-}
 __global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
   size_t i = TID;
   if (i >= n) return;
@@ -734,9 +711,11 @@ __global__ void __launch_bounds__(BLOCK) k_evm_ecmul(const uint8_t* in, uint8_t*
   cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);  // r
   evm_write_g1(out + 64 * i, g1_scalar_mul(a, k));
 }
-// one lane per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes
+// one LANE PAIR per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes.  Both lanes decode
+// the six field elements; the G2 checks (twist equation, subgroup) run on the lane-pair Fp2 (pair_kernels.hpp).
 __global__ void HEAVY_BOUNDS k_evm_decode_pairs(const uint8_t* in, size_t n_pairs, u64* pxy, uint8_t* pinf, u64* qxy, uint8_t* qinf, uint8_t* pst) {
-  size_t i = TID;
+  const size_t t = TID, i = t >> 1;
+  const bool odd = (t & 1) != 0;
   if (i >= n_pairs) return;
   const uint8_t* b = in + 192 * i;
   Fp f[6];
@@ -752,11 +731,13 @@ __global__ void HEAVY_BOUNDS k_evm_decode_pairs(const uint8_t* in, size_t n_pair
     if (!ainf && !g1_on_curve_affine(fp_to_mont(f[0]), fp_to_mont(f[1]))) st = SYLOW_HIP_ST_NOT_ON_CURVE;
     binf = fp_is_zero(f[2]) && fp_is_zero(f[3]) && fp_is_zero(f[4]) && fp_is_zero(f[5]);
     if (!st && !binf) {
-      Fp2 x{fp_to_mont(f[3]), fp_to_mont(f[2])}, y{fp_to_mont(f[5]), fp_to_mont(f[4])};   // (bax, bay), (bbx, bby)
-      if (!g2_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
-      else if (!g2_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+      // (bax, bay), (bbx, bby): x = f[3] + f[2] u, y = f[5] + f[4] u; this lane's coordinate
+      const pl::S2 x{fp_to_mont(pl::sel(odd, f[3], f[2]))}, y{fp_to_mont(pl::sel(odd, f[5], f[4]))};
+      if (!plk::g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+      else if (!plk::g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
     }
   }
+  if (odd) return;
   bool dead = st != SYLOW_HIP_ST_OK;
   Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
   // identities (and invalid pairs, whose job is rejected anyway) are stored in the canonical (0, 1) encoding
@@ -827,8 +808,10 @@ __global__ void __launch_bounds__(BLOCK) k_g2_to_bytes(const u64* xy, const uint
   write_be_fp(o, xc1); write_be_fp(o + 32, xc0); write_be_fp(o + 64, yc1); write_be_fp(o + 96, yc0);
   if (z) o[0] |= 0x80;
 }
+// one LANE PAIR per 128-byte encoding (both lanes decode, the curve / subgroup checks run on the lane-pair Fp2)
 __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
-  size_t i = TID;
+  const size_t t = TID, i = t >> 1;
+  const bool odd = (t & 1) != 0;
   if (i >= n) return;
   uint8_t b[128];
   for (int k = 0; k < 128; ++k) b[k] = in[128 * i + k];
@@ -845,10 +828,11 @@ __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t
   if (!ok) st = SYLOW_HIP_ST_DECODE_ERROR;
   else if (flag) st = is01 ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_DECODE_ERROR;
   else {
-    Fp2 x{fp_to_mont(xc0), fp_to_mont(xc1)}, y{fp_to_mont(yc0), fp_to_mont(yc1)};
-    if (!g2_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
-    else if (!g2_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+    const pl::S2 x{fp_to_mont(pl::sel(odd, xc0, xc1))}, y{fp_to_mont(pl::sel(odd, yc0, yc1))};
+    if (!plk::g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    else if (!plk::g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
   }
+  if (odd) return;
   bool z = flag || st != SYLOW_HIP_ST_OK;
   store_plain(xy, n, i, 0, z ? zero : xc0); store_plain(xy, n, i, 4, z ? zero : xc1);
   store_plain(xy, n, i, 8, z ? one : yc0); store_plain(xy, n, i, 12, z ? zero : yc1);
@@ -1088,7 +1072,8 @@ int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
 }
 int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  k_g2_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+  if (single_lane()) { k_g2_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED(); }
+  plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
@@ -1104,11 +1089,13 @@ int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, ui
 }
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  k_g2_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+  if (single_lane()) { k_g2_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED(); }
+  plk::k_g2_normalize<<<GRID(2 * n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream) {
   ARGCHK(q_xy && status); if (!n) return SYLOW_HIP_OK;
-  k_g2_subgroup_check<<<GRID(n)>>>(q_xy, q_inf, status, n); LAUNCHED();
+  if (single_lane()) { k_g2_subgroup_check<<<GRID(n)>>>(q_xy, q_inf, status, n); LAUNCHED(); }
+  plk::k_g2_subgroup_check<<<GRID(2 * n)>>>(q_xy, q_inf, status, n); LAUNCHED();
 }
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
@@ -1282,7 +1269,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   uint8_t* qinf = pinf + np;
   uint8_t* pst = qinf + np;
   uint8_t* isone = pst + np;
-  if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
+  if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((2 * n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
   if (single_lane()) k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
   else plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
   k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
@@ -1302,7 +1289,7 @@ int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_in
   ARGCHK(p_xy && out); if (!n) return SYLOW_HIP_OK; k_g2_to_bytes<<<GRID(n)>>>(p_xy, p_inf, out, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
-  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g2_from_bytes<<<GRID(n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
+  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g2_from_bytes<<<GRID(2 * n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
 }
 
 // test hook (see k_f29_hook)
@@ -1316,13 +1303,14 @@ int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* 
 }
 int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  k_g2_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+  if (single_lane()) { k_g2_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED(); }
+  plk::k_g2_add<<<GRID(2 * n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; k_g1_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
-  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; k_g2_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
+  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; if (single_lane()) { k_g2_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED(); } plk::k_g2_double<<<GRID(2 * n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream) {
   ARGCHK(out_dev && (flags || !n));
