@@ -228,6 +228,14 @@ BN_DEV F29 f29_reduce_from(LIMB limb) {
   return r;
 }
 
+// ---- out-of-line product leaf: 18 scalar ABI arguments (two 9-limb structs would travel through the stack) -------------
+// operands R / N / D class, L(a) L(b) <= 2.5; output normalized
+BN_NOINLINE F29 f29_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
+                             i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
+  return f29_mul(F29{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, F29{{b0, b1, b2, b3, b4, b5, b6, b7, b8}});
+}
+#define W_ARGS(x) (x).v[0], (x).v[1], (x).v[2], (x).v[3], (x).v[4], (x).v[5], (x).v[6], (x).v[7], (x).v[8]
+
 // ---- squaring and fixed-exponent powers ----------------------------------------------------------------------------------
 // a^2 / R': the 36 cross products are taken once against the doubled operand (45 multiply-adds instead of 81), same
 // column bound as f29_mul.  Input N-class (L <= 1), output normalized.

@@ -105,12 +105,6 @@ BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 
   const F29 o = xchg9(a);
   return f29_mul(sel9(odd, f29_add(a, o), o), sel9(odd, f29_sub(a, o), f29_dbl(a)));   // L(x) L(y) = 2
 }
-// Fp x Fp on the core (line scaling): operands R / N / D, L(a) L(b) <= 2.5
-BN_NOINLINE F29 f29_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
-                             i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
-  return f29_mul(F29{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, F29{{b0, b1, b2, b3, b4, b5, b6, b7, b8}});
-}
-#define W_ARGS(x) (x).v[0], (x).v[1], (x).v[2], (x).v[3], (x).v[4], (x).v[5], (x).v[6], (x).v[7], (x).v[8]
 BN_DEV W2 w2_mul(const W2& a, const W2& b) { return W2{w2_mul_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
 BN_DEV W2 w2_sqr(const W2& a) { return W2{w2_sqr_leaf(W_ARGS(a.c))}; }
 BN_DEV W2 w2_scale(const W2& a, const F29& k) { return W2{f29_mul_leaf(W_ARGS(a.c), W_ARGS(k))}; }

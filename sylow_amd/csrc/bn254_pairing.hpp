@@ -163,8 +163,42 @@ BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const
   }
   return res;
 }
+// G1 group law on the carry-free core (bn254_f29.hpp): the same complete formulas over F29 coordinates.  Class invariant:
+// every coordinate is N-class (limbs in [0, 2^29), top limb signed) -- additions are carry-normalised (34 instructions
+// against 25 for a saturated modular add) and products are one v_mad_i64_i32 per partial product (233 instructions against
+// 439 issue slots).  Value bounds (|V| = |value| / p): products return |V| < VaVb/169 + 1, the x9 of mul_b3 ends in a
+// reduce pass (|V| < 0.51), so with inputs |V| <= 7 proj_double returns |V| <= 2.1 and proj_add (inputs <= 2.1) returns
+// |V| <= 2.1 -- far inside the |V| <= 40 limit of the core.  Zero tests go through the canonical form.
+struct OpsF29 {
+  typedef F29 F;
+  static BN_DEV F add(const F& a, const F& b) { return f29_norm(f29_add(a, b)); }
+  static BN_DEV F sub(const F& a, const F& b) { return f29_norm(f29_sub(a, b)); }
+  static BN_DEV F neg(const F& a) { return f29_norm(f29_neg(a)); }
+  static BN_DEV F mul(const F& a, const F& b) { return f29_mul_leaf(W_ARGS(a), W_ARGS(b)); }
+  static BN_DEV F zero() { return F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
+  // 2^261 mod p, the Montgomery one of the core
+  static BN_DEV F one() { return F29{{0x157ccc21, 0x141c2758, 0x185230d3, 0x014c0419, 0x0aa36fb9, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836}}; }
+  static BN_DEV bool is_zero(const F& a) { return fp_is_zero(f29_to_fp(a)); }
+  static BN_DEV F select(const F& a, const F& b, bool c) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.v[i] = c ? b.v[i] : a.v[i];
+    return r;
+  }
+  static BN_DEV F mul_b3(const F& a) { return f29_reduce_from([&](int i) { return (i64)a.v[i] * 9; }); }   // 3 b = 9
+};
+typedef Proj<F29> G1W;
+BN_DEV F29 f29_from_fp_reduced(const Fp& a) {
+  const F29 t = f29_from_fp(a);
+  return f29_reduce_from([&](int i) { return (i64)t.v[i]; });
+}
+// k * P with the wave-uniform window schedule above, on the carry-free core; the saturated projective result is a
+// representative of the same point (only affine-normalised values cross the boundary)
 BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
-  return scalar_mul_window<OpsFp>(p, k, [](const G1P& a) { return g1_double(a); }, [](const G1P& a, const G1P& b) { return g1_add(a, b); });
+  const G1W pw{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
+  const G1W r = scalar_mul_window<OpsF29>(pw, k, [](const G1W& a) { return proj_double<OpsF29>(a); },
+                                          [](const G1W& a, const G1W& b) { return proj_add<OpsF29>(a, b); });
+  return G1P{f29_to_fp(r.x), f29_to_fp(r.y), f29_to_fp(r.z)};
 }
 BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
   out = scalar_mul_window<OpsFp2>(p, k, [](const G2P& a) { G2P r; g2_double(r, a); return r; },

@@ -170,47 +170,50 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 
 // ------------------------------------------------------------------ G2 group law on lane pairs -------------------------------
 // The complete RCB'15 formulas of bn254_pairing.hpp (proj_double / proj_add, generic over the coordinate field like
-// group.rs) instantiated over the lane-pair Fp2: a projective G2 point is 24 VGPRs per lane instead of 48.
-struct OpsS2 {
-  typedef S2 F;
-  static BN_DEV F add(const F& a, const F& b) { return s2_add(a, b); }
-  static BN_DEV F sub(const F& a, const F& b) { return s2_sub(a, b); }
-  static BN_DEV F neg(const F& a) { return s2_neg(a); }
-  static BN_DEV F mul(const F& a, const F& b) { return s2_mul(a, b); }
-  static BN_DEV F zero() { return s2_zero(); }
-  static BN_DEV F one() { return s2_one(); }
-  static BN_DEV bool is_zero(const F& a) { return s2_is_zero(a); }
-  static BN_DEV F select(const F& a, const F& b, bool c) { return s2_select(a, b, c); }
-  static BN_DEV F mul_b3(const F& a) { return s2_mul(a, s2_const(C_TWIST_B3)); }
+// group.rs) instantiated over the lane-pair Fp2 on the carry-free core: a projective G2 point is 27 VGPRs per lane.
+// Class invariant and value bounds as for OpsF29 (bn254_pairing.hpp): coordinates N-class, additions carry-normalised,
+// products |V| < 2 VaVb/169 + 1; with inputs |V| <= 7 proj_double returns |V| <= 2.3, proj_add (inputs <= 2.3) <= 2.3.
+struct OpsW2 {
+  typedef W2 F;
+  static BN_DEV F add(const F& a, const F& b) { return w2_norm(w2_add(a, b)); }
+  static BN_DEV F sub(const F& a, const F& b) { return w2_norm(w2_sub(a, b)); }
+  static BN_DEV F neg(const F& a) { return w2_norm(w2_neg(a)); }
+  static BN_DEV F mul(const F& a, const F& b) { return w2_mul(a, b); }
+  static BN_DEV F zero() { return W2{OpsF29::zero()}; }
+  static BN_DEV F one() { return W2{sel9(lane_odd(), OpsF29::one(), OpsF29::zero())}; }
+  static BN_DEV bool is_zero(const F& a) { return s2_is_zero(w2_to_s2(a)); }
+  static BN_DEV F select(const F& a, const F& b, bool c) { return w2_select(a, b, c); }
+  static BN_DEV F mul_b3(const F& a) { return w2_mul(a, w2_const(C_TWIST_B3)); }
 };
-typedef Proj<S2> G2Q;
-BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsS2>(p); }
-BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsS2>(p, q); }
+typedef Proj<W2> G2Q;
+BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
+BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
 BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
-  out = scalar_mul_window<OpsS2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
+  out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
                                  [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; });
 }
-// group.rs:475-495
+// group.rs:475-495 (through the saturated core: one Fp2 inversion)
 BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
-  const S2 zi = s2_inv(p.z);
+  const S2 zi = s2_inv(w2_to_s2(p.z));
   inf = s2_is_zero(zi);
-  x = s2_select(s2_mul(p.x, zi), s2_zero(), inf);
-  y = s2_select(s2_mul(p.y, zi), s2_one(), inf);
+  x = s2_select(s2_mul(w2_to_s2(p.x), zi), s2_zero(), inf);
+  y = s2_select(s2_mul(w2_to_s2(p.y), zi), s2_one(), inf);
 }
 BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-297
   return s2_eq(s2_sub(s2_sqr(y), s2_mul(s2_sqr(x), x)), s2_const(C_TWIST_B));
 }
 // g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
 BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
-  const G2Q q{x, y, s2_one()};
+  const G2Q q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()};
   const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
   G2Q a;
   g2q_scalar_mul(a, q, bx);
   // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
-  auto psi = [](G2Q& r, const G2Q& p) {
-    r.x = s2_mul(s2_const(C_EPS_EXP0), s2_conj(p.x));
-    r.y = s2_mul(s2_const(C_EPS_EXP1), s2_conj(p.y));
-    r.z = s2_conj(p.z);
+  const W2 e0 = w2_const(C_EPS_EXP0), e1 = w2_const(C_EPS_EXP1);
+  auto psi = [&](G2Q& r, const G2Q& p) {
+    r.x = w2_mul(e0, w2_conj(p.x));
+    r.y = w2_mul(e1, w2_conj(p.y));
+    r.z = w2_conj(p.z);
   };
   G2Q b, c, l, r;
   psi(b, a);
@@ -220,12 +223,12 @@ BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
   g2q_add(l, l, a);
   psi(r, c);
   g2q_double(r, r);
-  const G2Q nl = proj_neg<OpsS2>(l);
+  const G2Q nl = proj_neg<OpsW2>(l);
   g2q_add(r, r, nl);
-  return s2_is_zero(r.z);
+  return OpsW2::is_zero(r.z);
 }
 BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
-  return G2Q{load_s2(xy, n, i, 0, odd), load_s2(xy, n, i, 8, odd), (inf && inf[i]) ? s2_zero() : s2_one()};
+  return G2Q{w2_from_s2(load_s2(xy, n, i, 0, odd)), w2_from_s2(load_s2(xy, n, i, 8, odd)), (inf && inf[i]) ? OpsW2::zero() : OpsW2::one()};
 }
 BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {
   S2 x, y; bool rinf;
@@ -263,7 +266,7 @@ __global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* 
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   if (i >= n) return;
-  const G2Q p{load_s2(pxyz, n, i, 0, odd), load_s2(pxyz, n, i, 8, odd), load_s2(pxyz, n, i, 16, odd)};
+  const G2Q p{w2_from_s2(load_s2(pxyz, n, i, 0, odd)), w2_from_s2(load_s2(pxyz, n, i, 8, odd)), w2_from_s2(load_s2(pxyz, n, i, 16, odd))};
   store_g2q_affine(oxy, oinf, n, i, odd, p);
 }
 // g2.rs:460-525 on an affine input

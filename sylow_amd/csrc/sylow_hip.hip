@@ -177,7 +177,7 @@ BN_DEV void load_scalar(u32 (&k)[8], const u64* base, size_t n, size_t i) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) k[j] = s.v[j];
 }
-__global__ void __launch_bounds__(BLOCK) k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+__global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
   bool inf = pinf && pinf[i];
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t*
 // out_j = sum_i k_{j,i} * P_{j,i}: the aggregation loop of examples/threshold_signing.rs:124-143 (Lagrange-weighted partial
 // signatures), one job per lane, terms walked in order with the reference's own scalar multiplication and complete addition.
 // Term-major layout: element (job j, term i) lives at index i * n_jobs + j, so a wave reads consecutive addresses.
-__global__ void __launch_bounds__(BLOCK) k_g1_lincomb(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n_jobs, size_t n_terms) {
+__global__ void HEAVY_BOUNDS k_g1_lincomb(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n_jobs, size_t n_terms) {
   size_t j = TID;
   if (j >= n_jobs) return;
   const size_t n = n_jobs * n_terms;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const
   if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
 }
 // lib.rs:179-187
-__global__ void __launch_bounds__(BLOCK) k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
+__global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
   G1P h;
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t*
   if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
   evm_write_g1(out + 64 * i, g1_add(a, b));
 }
-__global__ void __launch_bounds__(BLOCK) k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+__global__ void HEAVY_BOUNDS k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
   size_t i = TID;
   if (i >= n) return;
   G1P a;
