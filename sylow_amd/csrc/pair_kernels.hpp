@@ -61,6 +61,42 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
   store_s12(gout, n, i, odd, g);
 }
 
+// test hook: the lane-pair Fp12 layer one operation at a time (ops 16.. of sylow_hip_fp12_hook_batch); `b` carries the second
+// operand, or the three line coefficients (ell_0, ell_vw, ell_vv) in its first 24 words for the sparse product
+enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 = 20, OPW_FROB2 = 21, OPW_FROB3 = 22, OPW_EXPZ = 23,
+       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28, OPW_LAST = 28 };
+__global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  S12 sx, sy, sr;
+  load_s12(sx, a, n, i, odd);
+  if (b) load_s12(sy, b, n, i, odd);
+  if (op >= OPW_S_MUL && op <= OPW_S_CYCSQR) {       // saturated lane-pair layer (bn254_pair.hpp)
+    if (op == OPW_S_MUL) sr = s12_mul(sx, sy);
+    else if (op == OPW_S_SQR) sr = s12_sqr(sx);
+    else if (op == OPW_S_INV) sr = s12_inv(sx);
+    else sr = cyclotomic_sqr(sx);
+  } else {
+    W12 x, y, r;
+    w12_from_s12(x, sx);
+    if (b) w12_from_s12(y, sy);
+    switch (op) {
+      case OPW_MUL: w12_mul_nl(r, x, y); break;
+      case OPW_SQR: r = w12_sqr(x); break;
+      case OPW_SPARSE: r = w12_sparse_mul(x, y.c0.c0, y.c0.c1, y.c0.c2); break;
+      case OPW_CYCSQR: w12_cyclotomic_sqr_nl(r, x); break;
+      case OPW_FROB1: w12_frobenius_nl<1>(r, x); break;
+      case OPW_FROB2: w12_frobenius_nl<2>(r, x); break;
+      case OPW_FROB3: w12_frobenius_nl<3>(r, x); break;
+      case OPW_CONJ: r = w12_conj(x); break;
+      default: exp_by_neg_z29(r, x); break;
+    }
+    w12_to_s12(sr, r);
+  }
+  store_s12(out, n, i, odd, sr);
+}
+
 // ------------------------------------------------------------------ glued pairing ----------------------------------------
 // Same wave-uniform schedule as the single-lane k_multi_pairing (sylow_hip.hip): chunks of KMAX pairs share the squarings of
 // one accumulator, a lane pair whose job has fewer pairs multiplies by the unit line.  Pair states live in the stack frame

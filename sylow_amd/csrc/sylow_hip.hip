@@ -1061,9 +1061,11 @@ int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, si
   ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_CYCSQR, a, nullptr, out, n); LAUNCHED();
 }
 // test hook: raw k_fp12_op selector (8: product on the carry-free core, 9: cyclotomic square on it,
-// 10 / 11: exp_by_neg_z on the carry-free / saturated core)
+// 10 / 11: exp_by_neg_z on the carry-free / saturated core); 16..28: the lane-pair Fp12 layer (plk::k_w12_op)
 int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(a && out && op >= 0 && op <= 11); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
+  ARGCHK(a && out && op >= 0 && (op <= 11 || (op >= 16 && op <= plk::OPW_LAST))); if (!n) return SYLOW_HIP_OK;
+  if (op >= 16) { plk::k_w12_op<<<GRID(2 * n)>>>(op, a, b, out, n); LAUNCHED(); }
+  k_fp12_op<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
 }
 
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
