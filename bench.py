@@ -193,7 +193,7 @@ def main():
     # ---- untimed aux leg: batched BLS verify + aggregate AND over ranks (RCCL MIN) ----------------
     aux = {}
     if not args.no_aux:
-        nv = min(n, 1 << 18)
+        nv = min(n, 1 << 20)                      # BASELINE.json configs[3]: BLS verifies at batch 2^20
         rng = np.random.default_rng(7 + rank)
         msgs_np = rng.integers(0, 256, size=(nv, 32), dtype=np.uint8)
         off = (np.arange(nv + 1, dtype=np.uint64) * np.uint64(32))

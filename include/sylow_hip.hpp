@@ -129,6 +129,42 @@ inline std::vector<G2Affine> mul(const std::vector<G2Affine>& p, const std::vect
   check(sylow_hip_g2_scalar_mul_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
   return from_device_soa<G2Affine>(dout, n);
 }
+// Mul<&Fr> for &Gt (groups/gt.rs:161-187), elementwise: gt[i] "times" k[i]
+inline std::vector<Gt> mul(const std::vector<Gt>& gt, const std::vector<Fp>& k) {
+  if (gt.size() != k.size()) throw Error("Gt * Fr: length mismatch");
+  const size_t n = gt.size();
+  auto dg = to_device_soa(gt); auto dk = to_device_soa(k);
+  DeviceBuffer dout(n * sizeof(Gt) + 8);
+  check(sylow_hip_gt_pow_batch(dg.as<uint64_t>(), dk.as<uint64_t>(), dout.as<uint64_t>(), n, nullptr), "sylow_hip_gt_pow_batch");
+  return from_device_soa<Gt>(dout, n);
+}
+// Fr arithmetic (fields/fp.rs:556-565), elementwise on canonical values carried in the Fp container
+namespace fr {
+inline std::vector<Fp> binop(int32_t (*fn)(const uint64_t*, const uint64_t*, uint64_t*, size_t, void*), const std::vector<Fp>& a, const std::vector<Fp>& b) {
+  if (a.size() != b.size()) throw Error("Fr: length mismatch");
+  auto da = to_device_soa(a); auto db = to_device_soa(b);
+  DeviceBuffer dout(a.size() * sizeof(Fp) + 8);
+  check(fn(da.as<uint64_t>(), db.as<uint64_t>(), dout.as<uint64_t>(), a.size(), nullptr), "fr binop");
+  return from_device_soa<Fp>(dout, a.size());
+}
+inline std::vector<Fp> add(const std::vector<Fp>& a, const std::vector<Fp>& b) { return binop(sylow_hip_fr_add_batch, a, b); }
+inline std::vector<Fp> sub(const std::vector<Fp>& a, const std::vector<Fp>& b) { return binop(sylow_hip_fr_sub_batch, a, b); }
+inline std::vector<Fp> mul(const std::vector<Fp>& a, const std::vector<Fp>& b) { return binop(sylow_hip_fr_mul_batch, a, b); }
+inline std::vector<Fp> inv(const std::vector<Fp>& a) {
+  auto da = to_device_soa(a);
+  DeviceBuffer dout(a.size() * sizeof(Fp) + 8);
+  check(sylow_hip_fr_inv_batch(da.as<uint64_t>(), dout.as<uint64_t>(), a.size(), nullptr), "sylow_hip_fr_inv_batch");
+  return from_device_soa<Fp>(dout, a.size());
+}
+}  // namespace fr
+// sum_i k[j][i] * P[j][i] per job (examples/threshold_signing.rs:124-143); rows term-major: row i*n_jobs + j
+inline std::vector<G1Affine> aggregate(const std::vector<G1Affine>& p, const std::vector<Fp>& k, size_t n_jobs, size_t n_terms) {
+  if (p.size() != n_jobs * n_terms || k.size() != p.size()) throw Error("aggregate: shape mismatch");
+  auto dp = to_device_soa(p); auto dk = to_device_soa(k);
+  DeviceBuffer dout(n_jobs * sizeof(G1Affine) + 8), dinf(n_jobs + 8);
+  check(sylow_hip_g1_lincomb_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n_jobs, n_terms, nullptr), "sylow_hip_g1_lincomb_batch");
+  return from_device_soa<G1Affine>(dout, n_jobs);
+}
 struct Messages {                                    // concatenated bytes + offsets on the device
   DeviceBuffer bytes, offsets; size_t n;
   explicit Messages(const std::vector<std::vector<uint8_t>>& msgs) : bytes(total(msgs) + 8), offsets((msgs.size() + 1) * 8), n(msgs.size()) {

@@ -35,6 +35,17 @@ int main() {
     Gt prod = glued_pairing({g1_generator(), g1_generator()}, {g2_generator(), g2_generator()});
     auto sq = pairing({G1Affine{Fp{{1, 0, 0, 0}}, Fp{{2, 0, 0, 0}}}}, {mul(std::vector<G2Affine>(1, g2_generator()), {Fp{{2, 0, 0, 0}}})[0]});
     std::printf("GLUED %d\n", prod == sq[0] ? 1 : 0);
+    // gt::tests::test_bilinearity shape: e(P, Q) * s == e(s P, Q); Fr: s * s^-1 == 1; aggregate: 2 P + 3 P == 5 P
+    auto es = mul(rhs, {sk[0]});                              // e(G1, 5 G2) * 5
+    auto e25 = pairing(mul(std::vector<G1Affine>(1, g1_generator()), {Fp{{25, 0, 0, 0}}}), {g2_generator()});
+    std::printf("GTPOW %d\n", es[0] == e25[0] ? 1 : 0);
+    auto one = fr::mul({sk[1]}, fr::inv({sk[1]}));
+    std::printf("FRINV %d\n", (one[0].w[0] == 1 && !one[0].w[1] && !one[0].w[2] && !one[0].w[3]) ? 1 : 0);
+    auto agg = aggregate({g1_generator(), g1_generator()}, {Fp{{2, 0, 0, 0}}, Fp{{3, 0, 0, 0}}}, 1, 2);
+    auto five = mul(std::vector<G1Affine>(1, g1_generator()), {sk[0]});
+    bool same = true;
+    for (int i = 0; i < 4; ++i) same = same && agg[0].x.w[i] == five[0].x.w[i] && agg[0].y.w[i] == five[0].y.w[i];
+    std::printf("AGG %d\n", same ? 1 : 0);
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());

@@ -35,6 +35,7 @@ def test_cpp_host_layer_runs(kats, coracle):
     assert [int(x, 16) for x in lines["GT"].split()] == [int(x, 16) for x in kats["gt_generator"]["value"]]
     assert lines["VERIFY"] == "1111 1101"
     assert lines["BILINEAR"] == "1" and lines["GLUED"] == "1"
+    assert lines["GTPOW"] == "1" and lines["FRINV"] == "1" and lines["AGG"] == "1"
     sk0 = np.array([[5, 0, 0, 0]], dtype=np.uint64)
     sig_ref, _ = coracle.g1_to_affine(coracle.sign(sk0, [bytes([0, 0, 0, 20])]))
     want = [sum(int(sig_ref[0, 4 * i + k]) << (64 * k) for k in range(4)) for i in range(2)]
