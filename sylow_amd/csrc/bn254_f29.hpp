@@ -307,6 +307,104 @@ BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5
   return f29_to_fp(r);
 }
 
+// ---- modular inversion: Bernstein-Yang safegcd on 30-bit signed limbs ------------------------------------------------------
+// (delta, f, g) -> divstep^600 in 20 batches of 30: each batch derives a 2x2 transition matrix t from the low 30 bits of f, g
+// (branch-free: conditional negate / add through masks), then applies it to (f, g) exactly (/ 2^30) and to (d, e) modulo p
+// (adding the multiple of p that makes the low 30 bits vanish).  g reaches 0, f = +-1, d = +-x^-1.  Start delta = 1/2
+// (zeta = -1), for which 590 divsteps suffice for 256-bit inputs.  tools/safegcd_model.py is the bit-level Python model that
+// checks every invariant asserted in the comments below and prints the constants.
+// In: X = x R canonical (the saturated Montgomery form).  Out: x^-1 R = X^-1 R^2 = montmul(X^-1, R^3).  X = 0 -> 0.
+BN_NOINLINE Fp fp_inv_safegcd(Fp a) {
+  const i32 P30[9] = {0x187cfd47, 0x3082305b, 0x071ca8d3, 0x205aa45a, 0x01585d97, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x00003064};
+  const u32 PINV30 = 0x1b799c77u;          // p^-1 mod 2^30
+  const i32 M30 = 0x3fffffff;
+  i32 f[9], g[9], d[9], e[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+    u32 lo = a.v[w] >> sh;
+    u32 hi = (sh > 2 && w + 1 < 8) ? (a.v[w + 1] << (32 - sh)) : 0u;
+    g[i] = (i32)((lo | hi) & (u32)M30);
+    f[i] = P30[i];
+    d[i] = 0;
+    e[i] = (i == 0) ? 1 : 0;
+  }
+  i32 zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 20; ++it) {
+    // 30 divsteps on the low limbs -> t = [[u, v], [q, r]] (entries in (-2^30, 2^30])
+    u32 u = 1, v = 0, q = 0, r = 1, ff = (u32)f[0], gg = (u32)g[0];
+#pragma unroll 5
+    for (int st = 0; st < 30; ++st) {
+      u32 c1 = (u32)(zeta >> 31);
+      const u32 c2 = 0u - (gg & 1u);
+      const u32 x = (ff ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+      gg += x & c2; q += y & c2; r += z & c2;
+      c1 &= c2;
+      zeta = (i32)(((u32)zeta ^ c1) - 1u);
+      ff += gg & c1; u += q & c1; v += r & c1;
+      gg >>= 1; u <<= 1; v <<= 1;
+    }
+    const i32 tu = (i32)u, tv = (i32)v, tq = (i32)q, tr = (i32)r;
+    // (d, e) <- t (d, e) / 2^30 mod p; d, e stay in (-2p, p)
+    {
+      const i32 sd = d[8] >> 31, se = e[8] >> 31;
+      i32 md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+      i64 cd = (i64)tu * d[0] + (i64)tv * e[0], ce = (i64)tq * d[0] + (i64)tr * e[0];
+      md -= (i32)((PINV30 * (u32)cd + (u32)md) & (u32)M30);
+      me -= (i32)((PINV30 * (u32)ce + (u32)me) & (u32)M30);
+      cd += (i64)P30[0] * md; ce += (i64)P30[0] * me;
+      cd >>= 30; ce >>= 30;                      // low 30 bits are zero by construction
+#pragma unroll
+      for (int i = 1; i < 9; ++i) {
+        cd += (i64)tu * d[i] + (i64)tv * e[i] + (i64)P30[i] * md;
+        ce += (i64)tq * d[i] + (i64)tr * e[i] + (i64)P30[i] * me;
+        d[i - 1] = (i32)cd & M30; cd >>= 30;
+        e[i - 1] = (i32)ce & M30; ce >>= 30;
+      }
+      d[8] = (i32)cd; e[8] = (i32)ce;
+    }
+    // (f, g) <- t (f, g) / 2^30, exact
+    {
+      i64 cf = (i64)tu * f[0] + (i64)tv * g[0], cg = (i64)tq * f[0] + (i64)tr * g[0];
+      cf >>= 30; cg >>= 30;
+#pragma unroll
+      for (int i = 1; i < 9; ++i) {
+        cf += (i64)tu * f[i] + (i64)tv * g[i];
+        cg += (i64)tq * f[i] + (i64)tr * g[i];
+        f[i - 1] = (i32)cf & M30; cf >>= 30;
+        g[i - 1] = (i32)cg & M30; cg >>= 30;
+      }
+      f[8] = (i32)cf; g[8] = (i32)cg;
+    }
+  }
+  // d = sign(f) x^-1 in (-2p, p): add p if negative, negate if f < 0, carry, add p again if still negative
+  {
+    const i32 add1 = d[8] >> 31, neg = f[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = ((d[i] + (P30[i] & add1)) ^ neg) - neg;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+    const i32 add2 = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] += P30[i] & add2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+  }
+  // 9 x 30 -> 8 x 32
+  Fp y;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) y.v[w] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+    if (w < 8) y.v[w] |= (u32)d[i] << sh;
+    if (sh > 2 && w + 1 < 8) y.v[w + 1] |= (u32)d[i] >> (32 - sh);
+  }
+  // X^-1 -> X^-1 R^2 (one Montgomery product with R^3 mod p)
+  return fp_mul(y, fp_from_limbs(0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u, 0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u));
+}
+
 // ---- Fp2 on the carry-free core ---------------------------------------------------------------------------------------
 struct U2 { F29 c0, c1; };
 BN_DEV U2 u2_add(const U2& a, const U2& b) { return U2{f29_add(a.c0, b.c0), f29_add(a.c1, b.c1)}; }

@@ -450,8 +450,13 @@ BN_DEV Fp fp_small(int k) {
 // a^e for a fixed 256-bit exponent given as 8 wave-uniform u32 words (inversion / sqrt / Legendre paths).
 // Defined in bn254_f29.hpp: the chain runs on the carry-free core (dedicated squaring, 4-bit windows).
 BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5, u32 e6, u32 e7);
-// a^(p-2): inv(0) = 0 like the reference (fp.rs:418-433, test fp.rs:1126-1132)
-BN_DEV Fp fp_inv(const Fp& a) {
+// a^-1, inv(0) = 0 like the reference (fp.rs:418-433, test fp.rs:1126-1132).  The reference inverts with crypto-bigint's
+// Bernstein-Yang safegcd; so does this (bn254_f29.hpp: 600 branch-free divsteps on 30-bit limbs -- every lane runs the same
+// instruction stream whatever its input, which is exactly what a wavefront wants) instead of the Fermat power a^(p-2).
+BN_NOINLINE Fp fp_inv_safegcd(Fp a);
+BN_DEV Fp fp_inv(const Fp& a) { return fp_inv_safegcd(a); }
+// the Fermat twin, kept for the tests
+BN_DEV Fp fp_inv_fermat(const Fp& a) {
   return fp_pow_words(a, BN_P0 - 2, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
 }
 // a^((p-1)/2)  (Legendre; fp.rs:625-631)
@@ -461,6 +466,12 @@ BN_DEV Fp fp_pow_pm1_half(const Fp& a) {
 // a^((p+1)/4)  (sqrt candidate; fp.rs:611-616)
 BN_DEV Fp fp_pow_pp1_quarter(const Fp& a) {
   return fp_pow_words(a, 0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu);
+}
+
+// a^((p-3)/4): one chain serves both the Legendre symbol (a * t^2 = a^((p-1)/2)) and the square-root candidate
+// (a * t = a^((p+1)/4)) of the same element
+BN_DEV Fp fp_pow_pm3_quarter(const Fp& a) {
+  return fp_pow_words(a, 0xb61f3f51u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu);
 }
 
 }  // namespace bn254

@@ -159,17 +159,29 @@ BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
   Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
   Fp x1 = fp_sub(c2, tv4);
   Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
-  bool e1 = fp_is_square(gx1);
+  // is_square(gx) (fp.rs:625-631: gx^((p-1)/2) in {0, 1}) and sqrt(gx) (fp.rs:611-616: gx^((p+1)/4)) share one chain per
+  // candidate: t = gx^((p-3)/4), Legendre = gx t^2, root = gx t.  Same values as the two separate powers of the reference.
+  const Fp t1 = fp_pow_pm3_quarter(gx1);
+  const Fp r1 = fp_mul(gx1, t1);
+  const Fp l1 = fp_mul(r1, t1);
+  bool e1 = fp_is_zero(l1) || fp_eq(l1, one);
   Fp x2 = fp_add(c2, tv4);
   Fp gx2 = fp_add(fp_mul(fp_mul(x2, x2), x2), b);
-  bool e2 = fp_is_square(gx2) && !e1;
+  const Fp t2 = fp_pow_pm3_quarter(gx2);
+  const Fp r2 = fp_mul(gx2, t2);
+  const Fp l2 = fp_mul(r2, t2);
+  bool e2 = (fp_is_zero(l2) || fp_eq(l2, one)) && !e1;
   Fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
   x3 = fp_mul(fp_mul(x3, x3), c4);
   x3 = fp_add(x3, z);
+  Fp gx3 = fp_add(fp_mul(fp_mul(x3, x3), x3), b);
+  const Fp r3 = fp_mul(gx3, fp_pow_pm3_quarter(gx3));
   Fp x = fp_select(x3, x1, e1);
   x = fp_select(x, x2, e2);
-  Fp gx = fp_add(fp_mul(fp_mul(x, x), x), b);
-  Fp y = fp_pow_pp1_quarter(gx);
+  Fp gx = fp_select(gx3, gx1, e1);
+  gx = fp_select(gx, gx2, e2);
+  Fp y = fp_select(r3, r1, e1);
+  y = fp_select(y, r2, e2);
   bool ok = fp_eq(fp_mul(y, y), gx);
   bool e3 = fp_sgn0(u) == fp_sgn0(y);
   y = fp_select(fp_neg(y), y, e3);

@@ -852,6 +852,9 @@ __global__ void __launch_bounds__(BLOCK) k_f29_hook(int op, const u64* a, const 
   if (op == 0) r = f29_to_fp(fx);
   else if (op == 1) r = f29_to_fp(f29_mul(fx, fy));
   else if (op == 2) r = f29_to_fp(f29_dot2(fx, fy, fy, fx));
+  else if (op == 4) r = fp_inv(x);                       // safegcd
+  else if (op == 5) r = fp_inv_fermat(x);                // x^(p-2) on the carry-free exponentiation chain
+  else if (op == 6) r = f29_to_fp(f29_sqr(f29_reduce_from([&](int k) { return (i64)fx.v[k]; })));
   else {
     F29 t = f29_norm(f29_sub(f29_add(f29_add(fx, fy), fx), fy));     // 2x as a lazy value (L <= 3), normalised
     r = f29_to_fp(f29_mul(t, f29_sub(fy, fx)));                        // 2x * (y - x)

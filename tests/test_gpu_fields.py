@@ -107,6 +107,10 @@ def test_f29_core_vs_saturated_core(engine):
     assert ints(engine.f29_hook(1, a, b)) == [x * y % P for x, y in zip(va, vb)]
     assert ints(engine.f29_hook(2, a, b)) == [2 * x * y % P for x, y in zip(va, vb)]
     assert ints(engine.f29_hook(3, a, b)) == [2 * x * (y - x) % P for x, y in zip(va, vb)]
+    assert ints(engine.f29_hook(6, a, b)) == [x * x % P for x in va]                 # dedicated squaring
+    # inversion: Bernstein-Yang safegcd (op 4) and the Fermat chain (op 5) agree with each other and with pow(x, p-2, p); inv(0) = 0
+    inv = [pow(x, P - 2, P) for x in va]
+    assert ints(engine.f29_hook(4, a, b)) == inv and ints(engine.f29_hook(5, a, b)) == inv
 
 
 def test_f29_tower_vs_saturated_tower(engine, coracle):
