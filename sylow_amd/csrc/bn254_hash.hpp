@@ -140,9 +140,45 @@ __device__ inline Fp fp_from_be48(const uint8_t* b) {
   return fp_add(h, fp_to_mont(lo));
 }
 
-BN_DEV bool fp_is_square(const Fp& a) {                    // fp.rs:625-631
-  Fp r = fp_pow_pm1_half(a);
-  return fp_is_zero(r) || fp_eq(r, fp_one());
+// is_square (fp.rs:625-631: a^((p-1)/2) in {0, 1}) as a Jacobi symbol: the binary algorithm with a FIXED trip count and no
+// data-dependent branches (every lane of the wavefront runs the same 508 steps), ~60 cheap instructions per step against
+// the ~320-product power.  Invariant: n odd, 0 <= a; each step either halves an even a (sign flips when n = 3, 5 mod 8) or,
+// for odd a, orders the pair (quadratic reciprocity: flip when both are 3 mod 4), subtracts and halves.  bits(a) + bits(n)
+// drops every step, so 2 * 254 steps always reach a = 0 with n = gcd.  The Montgomery factor R = (2^128)^2 is a square, so
+// the symbol of the Montgomery representative is the symbol of the value.  (0 / p) = 0 counts as a square, like the reference.
+BN_NOINLINE bool fp_is_square(Fp x) {
+  u32 a[8], n[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = x.v[i];
+  u32 t = 0;
+#pragma unroll 2
+  for (int it = 0; it < 508; ++it) {
+    const u32 odd = 0u - (a[0] & 1u);
+    // d = a - n, lt = (a < n)
+    u32 d[8];
+    u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const u64 w = (u64)a[i] - n[i] - br; d[i] = (u32)w; br = (w >> 32) & 1u; }
+    const u32 lt = 0u - (u32)br;
+    const u32 sw = odd & lt;                       // odd a below n: continue with (n - a, a)
+    t ^= sw & (a[0] >> 1) & (n[0] >> 1);          // both 3 mod 4
+    // |d| when swapping: (d ^ sw) - sw
+    u64 c = sw & 1u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      c += (u64)(d[i] ^ sw);
+      const u32 nd = (u32)c;
+      c >>= 32;
+      n[i] = sw ? a[i] : n[i];
+      a[i] = odd ? nd : a[i];
+    }
+    t ^= (n[0] >> 1) ^ (n[0] >> 2);               // halving an even value: (2 / n); irrelevant once a = 0 (then n = 1 or the symbol is 0)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[7] >>= 1;
+  }
+  const bool n_is_one = (n[0] == 1u) && ((n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]) == 0u);
+  return !(n_is_one && (t & 1u));
 }
 BN_DEV u32 fp_sgn0(const Fp& a) { return fp_from_mont(a).v[0] & 1; }   // fp.rs:636-644
 
@@ -159,29 +195,17 @@ BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
   Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
   Fp x1 = fp_sub(c2, tv4);
   Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
-  // is_square(gx) (fp.rs:625-631: gx^((p-1)/2) in {0, 1}) and sqrt(gx) (fp.rs:611-616: gx^((p+1)/4)) share one chain per
-  // candidate: t = gx^((p-3)/4), Legendre = gx t^2, root = gx t.  Same values as the two separate powers of the reference.
-  const Fp t1 = fp_pow_pm3_quarter(gx1);
-  const Fp r1 = fp_mul(gx1, t1);
-  const Fp l1 = fp_mul(r1, t1);
-  bool e1 = fp_is_zero(l1) || fp_eq(l1, one);
+  const bool e1 = fp_is_square(gx1);
   Fp x2 = fp_add(c2, tv4);
   Fp gx2 = fp_add(fp_mul(fp_mul(x2, x2), x2), b);
-  const Fp t2 = fp_pow_pm3_quarter(gx2);
-  const Fp r2 = fp_mul(gx2, t2);
-  const Fp l2 = fp_mul(r2, t2);
-  bool e2 = (fp_is_zero(l2) || fp_eq(l2, one)) && !e1;
+  const bool e2 = fp_is_square(gx2) && !e1;
   Fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
   x3 = fp_mul(fp_mul(x3, x3), c4);
   x3 = fp_add(x3, z);
-  Fp gx3 = fp_add(fp_mul(fp_mul(x3, x3), x3), b);
-  const Fp r3 = fp_mul(gx3, fp_pow_pm3_quarter(gx3));
   Fp x = fp_select(x3, x1, e1);
   x = fp_select(x, x2, e2);
-  Fp gx = fp_select(gx3, gx1, e1);
-  gx = fp_select(gx, gx2, e2);
-  Fp y = fp_select(r3, r1, e1);
-  y = fp_select(y, r2, e2);
+  Fp gx = fp_add(fp_mul(fp_mul(x, x), x), b);
+  Fp y = fp_mul(gx, fp_pow_pm3_quarter(gx));     // gx^((p+1)/4), the reference's square-root candidate (fp.rs:611-616)
   bool ok = fp_eq(fp_mul(y, y), gx);
   bool e3 = fp_sgn0(u) == fp_sgn0(y);
   y = fp_select(fp_neg(y), y, e3);
