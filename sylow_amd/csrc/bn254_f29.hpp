@@ -1,4 +1,4 @@
-// Carry-free field core for the final-exponentiation hot loop: Fp elements as 9 signed limbs of 29 bits
+// Carry-free field core: Fp elements as 9 signed limbs of 29 bits
 // (value = sum v[i] 2^(29 i)), Montgomery factor R' = 2^261.
 //
 // Why: in the saturated 8 x 32 form every partial product costs a v_mad_u64_u32 AND a v_addc (the mad has no
@@ -65,10 +65,10 @@ BN_DEV F29 f29_norm(const F29& a) {
 
 // ---- Montgomery product, R' = 2^261 ----------------------------------------------------------------------
 // Column sums are split over two accumulators (merged once per column) so that consecutive multiply-adds are
-// independent.  Measured notes (A/B on one box, k_final_exp at n = 2^20): this loop executes 27 % fewer VALU
-// instructions than the saturated one but only runs 4.5 % faster -- it is multiply-add dense (54 % v_mad_*64)
-// and the chip clocks it at 2.07 GHz instead of 2.26 GHz (GRBM_GUI_ACTIVE / time): power-, not issue-limited.
-// Column-interleaving the two passes of an Fp2 product, or replacing the 64-bit shifts by v_alignbit, did not help.
+// independent (a dependent v_mad_*64 chain issues at 4.75 instead of 4.19 cycles at 2 waves/SIMD).
+// History: on the one-element-per-lane kernels this core executed 27 % fewer VALU instructions in the f^x loops but ran only
+// 4.5 % faster -- those kernels were bound by scratch traffic (an Fp12 on this core is 108 VGPRs), not by issue; on lane
+// pairs (bn254_pair29.hpp) the kernel is issue-bound and the instruction saving shows up in full.
 // requires L(a) L(b) <= 2.5; output normalized
 BN_DEV F29 f29_mul(const F29& a, const F29& b) {
   i32 p[9]; f29_p(p);

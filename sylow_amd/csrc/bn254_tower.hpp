@@ -2,6 +2,8 @@
 // Batched replacement for sylow's src/fields/{extensions,fp2,fp6,fp12}.rs.  All values are exact
 // residues, so Karatsuba here vs. the reference's schoolbook forms is bit-identical.
 //
+// This is the ONE-ELEMENT-PER-LANE tower: the twin of the lane-pair implementation (bn254_pair.hpp / bn254_pair29.hpp, which
+// the pairing kernels use by default) and the layer behind the Fp2/Fp6/Fp12 batch entry points.
 // Code-size / register policy: the out-of-line leaf is fp_mul(Fp, Fp) (16 ABI argument registers,
 // ~50-VGPR footprint); the Fp2 layer is inlined; Fp6/Fp12 products, the sparse line multiplication and
 // the cyclotomic square are out-of-line mid-level routines taking references, so Fp12-sized values
