@@ -192,13 +192,140 @@ BN_DEV F29 f29_from_fp_reduced(const Fp& a) {
   const F29 t = f29_from_fp(a);
   return f29_reduce_from([&](int i) { return (i64)t.v[i]; });
 }
-// k * P with the wave-uniform window schedule above, on the carry-free core; the saturated projective result is a
-// representative of the same point (only affine-normalised values cross the boundary)
+// ---- GLV: k P = k1 P + k2 phi(P) with phi(x, y) = (beta x, y) = lambda P on G1 (beta^3 = 1 in Fp, lambda^3 = 1 mod r) ----
+// Every point of E(Fp) has order r (cofactor 1), so k acts through k mod r, and k mod r = k1 + k2 lambda with |k1|, |k2| < 2^128:
+// (k1, k2) = (k, 0) - c1 (a1, b1) - c2 (a2, b2) for the reduced lattice basis below and c_i = floor(k g_i / 2^256).
+// Halves the doublings of the window schedule (128 + 66 additions instead of 256 + 64).  tools/glv_model.py derives the
+// constants from the curve and replays this arithmetic limb-exactly on 20 000 scalars.
+//   a1 = 0x89d3256894d213e3, b1 = 0x6f4d8248eeb859fd0be4e1541221250b, a2 = 0x6f4d8248eeb859fc8211bbeb7d4f1128, b2 = -a1
+// low `NR` limbs of a (NA limbs) times b (NB limbs)
+template <int NA, int NB, int NR>
+BN_DEV void mp_mul_lo(u32 (&out)[NR], const u32 (&a)[NA], const u32 (&b)[NB]) {
+  u64 acc = 0, carry = 0;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    acc = carry; carry = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = k - i;
+      if (j < 0 || j >= NB) continue;
+      const u64 pr = (u64)a[i] * b[j];
+      acc += pr & 0xffffffffu;
+      carry += pr >> 32;
+    }
+    out[k] = (u32)acc;
+    carry += acc >> 32;
+  }
+}
+// |k1|, |k2| (4 limbs each) and their signs for k < p
+BN_DEV void glv_decompose(u32 (&m1)[4], bool& n1, u32 (&m2)[4], bool& n2, const u32 (&kin)[8]) {
+  u32 k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = kin[i];
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);   // k mod r (k < p < 2r)
+  const u32 g1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};                                  // floor(2^256 |b2| / r)
+  const u32 g2[5] = {0x00ff6565u, 0x5398fd03u, 0xa773d2d2u, 0x4ccef014u, 0x00000002u};        // floor(2^256 b1 / r)
+  const u32 a1[2] = {0x94d213e3u, 0x89d32568u};
+  const u32 b1[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+  const u32 a2[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};
+  u32 t1[11], t2[13];
+  mp_mul_lo<8, 3, 11>(t1, k, g1);
+  mp_mul_lo<8, 5, 13>(t2, k, g2);
+  const u32 c1[3] = {t1[8], t1[9], t1[10]};
+  const u32 c2[5] = {t2[8], t2[9], t2[10], t2[11], t2[12]};
+  u32 c1a1[5], c2a2[5], c2b2[5], c1b1[5];
+  mp_mul_lo<3, 2, 5>(c1a1, c1, a1);
+  mp_mul_lo<5, 4, 5>(c2a2, c2, a2);
+  mp_mul_lo<5, 2, 5>(c2b2, c2, a1);          // |b2| = a1
+  mp_mul_lo<3, 4, 5>(c1b1, c1, b1);
+  // k1 = k - c1 a1 - c2 a2, k2 = c2 |b2| - c1 b1, both modulo 2^160 (|k_i| < 2^128)
+  u32 v1[5], v2[5];
+  {
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { c += (i64)k[i] - c1a1[i] - c2a2[i]; v1[i] = (u32)c; c >>= 32; }
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { c += (i64)c2b2[i] - c1b1[i]; v2[i] = (u32)c; c >>= 32; }
+  }
+  auto mag = [](u32 (&m)[4], bool& neg, const u32 (&v)[5]) {
+    neg = (v[4] >> 31) != 0;
+    const u32 s = neg ? 0xffffffffu : 0u;
+    u64 c = s & 1u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c += (u64)(v[i] ^ s); m[i] = (u32)c; c >>= 32; }
+  };
+  mag(m1, n1, v1);
+  mag(m2, n2, v2);
+}
+// signed 4-bit digits of a 128-bit magnitude: m = sum d_i 16^i, d_i in [-8, 7], 33 digits (the last one is the carry)
+BN_DEV void glv_digits(signed char (&dig)[33], const u32 (&m)[4]) {
+  int carry = 0;
+#pragma unroll 1
+  for (int i = 0; i < 32; ++i) {
+    int d = (int)((m[i >> 3] >> (4 * (i & 7))) & 15) + carry;
+    carry = d >= 8;
+    dig[i] = (signed char)(d - (carry << 4));
+  }
+  dig[32] = (signed char)carry;
+}
+// k * P for the batch kernels, on the carry-free core: GLV split, then the wave-uniform signed-window schedule on both halves
+// at once -- every lane does 4 doublings and two complete additions per window (table entry 0 is the identity), 33 windows,
+// one table of 1P..8P; the phi-image of a table entry is a single multiplication of its X by beta.  The saturated projective
+// result is a representative of the same point (only affine-normalised values cross the boundary).
 BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
-  const G1W pw{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
-  const G1W r = scalar_mul_window<OpsF29>(pw, k, [](const G1W& a) { return proj_double<OpsF29>(a); },
-                                          [](const G1W& a, const G1W& b) { return proj_add<OpsF29>(a, b); });
-  return G1P{f29_to_fp(r.x), f29_to_fp(r.y), f29_to_fp(r.z)};
+  u32 m1[4], m2[4];
+  bool n1, n2;
+  glv_decompose(m1, n1, m2, n2, k);
+  signed char d1[33], d2[33];
+  glv_digits(d1, m1);
+  glv_digits(d2, m2);
+  // beta 2^261 mod p
+  const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};
+  auto dbl = [](const G1W& a) { return proj_double<OpsF29>(a); };
+  auto add = [](const G1W& a, const G1W& b) { return proj_add<OpsF29>(a, b); };
+  G1W T[9];
+  T[0] = proj_zero<OpsF29>();
+  T[1] = G1W{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
+  {
+    // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0): the complete formulas keep Z = 0 only
+    // for the canonical representative once two additions follow each other without a doubling in between
+    const bool pinf = OpsF29::is_zero(T[1].z);
+    T[1].x = OpsF29::select(T[1].x, OpsF29::zero(), pinf);
+    T[1].y = OpsF29::select(T[1].y, OpsF29::one(), pinf);
+    T[1].z = OpsF29::select(T[1].z, OpsF29::zero(), pinf);
+  }
+  if (n1) T[1].y = OpsF29::neg(T[1].y);                 // the table holds multiples of sign(k1) P
+  T[2] = dbl(T[1]);
+  T[3] = add(T[2], T[1]);
+  T[4] = dbl(T[2]);
+  T[5] = add(T[4], T[1]);
+  T[6] = dbl(T[3]);
+  T[7] = add(T[6], T[1]);
+  T[8] = dbl(T[4]);
+  const bool flip2 = n1 != n2;                            // phi(table) carries sign(k1); k2 wants sign(k2)
+  G1W res = proj_zero<OpsF29>();
+#pragma unroll 1
+  for (int i = 32; i >= 0; --i) {
+    if (i != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) res = dbl(res);
+    }
+    {
+      const int d = d1[i], m = d < 0 ? -d : d;
+      G1W q = T[m];
+      q.y = OpsF29::select(q.y, OpsF29::neg(q.y), d < 0);
+      res = add(res, q);
+    }
+    {
+      const int d = d2[i], m = d < 0 ? -d : d;
+      G1W q = T[m];
+      q.x = OpsF29::mul(q.x, beta);
+      q.y = OpsF29::select(q.y, OpsF29::neg(q.y), (d < 0) != flip2);
+      res = add(res, q);
+    }
+  }
+  return G1P{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)};
 }
 BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
   out = scalar_mul_window<OpsFp2>(p, k, [](const G2P& a) { G2P r; g2_double(r, a); return r; },
