@@ -51,6 +51,30 @@ def test_g1_scalar_mul_vs_oracle(engine, coracle):
     assert z_inf[0] == 1
 
 
+def test_g1_scalar_mul_glv_edge_scalars(engine, coracle):
+    """Scalars that stress the GLV split k = k1 + k2 lambda (bn254_pairing.hpp): multiples and neighbours of lambda, of the
+    lattice vectors, powers of two around 2^127 / 2^128, values >= r, on random points and on the identity."""
+    rng = Xoshiro(SEED + 25)
+    r = R.R_ORDER
+    lam = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    a1, b1 = 9931322734385697763, 147946756881789319010696353538189108491
+    a2 = 147946756881789319000765030803803410728
+    base = [0, 1, lam, r - lam, lam * lam % r, a1, b1, a2, (a1 + b1 * lam) % r, 1 << 127, 1 << 128, (1 << 128) - 1, (1 << 126) + 1,
+            r - 1, r, r + 1, P - 1, (r + lam) % P, (3 * lam) % r, (lam << 3) % r]
+    ks = []
+    for v in base:
+        ks += [v % P, (v + 1) % P, (v - 1) % P]
+    ks += [(x * lam + y) % r for x in (1, 2, 7, (1 << 127) - 1) for y in (0, 1, (1 << 127) - 1)]
+    n = len(ks)
+    pts_k = limbs([rng.fp() for _ in range(n)])
+    pts, _ = engine.g1_scalar_mul(np.tile(pack(G1, 8), (n, 1)), pts_k)
+    inf = np.zeros(n, np.uint8); inf[5] = 1; inf[17] = 1
+    k = limbs(ks)
+    got_xy, got_inf = engine.g1_scalar_mul(pts, k, p_inf=inf)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.g1_scalar_mul(g1_proj(pts, inf), k))
+    assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_xy, exp_xy)
+
+
 def test_g2_scalar_mul_vs_oracle(engine, coracle):
     rng = Xoshiro(SEED + 21)
     n = 192
