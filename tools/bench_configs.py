@@ -66,4 +66,21 @@ eng._call("sylow_hip_g2_scalar_mul_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr
 ok = eng.empty((nv,), np.uint8)
 t = timed(lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, h.ptr, None, ok.ptr, nv), 2)
 res["bls_verify_2^18"] = {"per_s": nv / t, "all_ok": int(ok.download().all())}
+# C5 end to end: the byte-level ecPairing entry point (decode + curve / subgroup checks + glued pairing), 2^16 jobs of
+# two pairs e(a P, Q) e(-a P, Q) == 1; EIP-197 encodings built from device-generated points
+nj = 1 << 16
+pj, qj = eng.from_device_soa(p)[:nj], eng.from_device_soa(q)[:nj]
+def be(col):  # [n,4] LE limbs -> [n,32] big-endian bytes
+    return col[:, ::-1].astype(">u8").view(np.uint8).reshape(len(col), 32)
+PV = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+ny = np.array([[(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)] for v in
+               [PV - sum(int(pj[i, 4 + k]) << (64 * k) for k in range(4)) for i in range(nj)]], dtype=np.uint64)
+g2b = np.concatenate([be(qj[:, 4:8]), be(qj[:, 0:4]), be(qj[:, 12:16]), be(qj[:, 8:12])], axis=1)       # x.c1 x.c0 y.c1 y.c0
+pair_a = np.concatenate([be(pj[:, 0:4]), be(pj[:, 4:8]), g2b], axis=1)
+pair_b = np.concatenate([be(pj[:, 0:4]), be(ny), g2b], axis=1)
+blob = np.concatenate([pair_a, pair_b], axis=1).reshape(-1)
+d_in = eng.to_device(blob); d_off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(2))
+d_res, d_st = eng.empty((nj,), np.uint8), eng.empty((nj,), np.uint8)
+t = timed(lambda: eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, 2 * nj, d_res.ptr, d_st.ptr), 2)
+res["evm_ecpairing_bytes_2^16_k2"] = {"jobs_per_s": nj / t, "all_true": int(d_res.download().all()), "all_status_ok": int((d_st.download() == 0).all())}
 print(json.dumps(res, indent=1))
