@@ -156,6 +156,13 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
 int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
                                       uint64_t* gt_out, uint8_t* is_one, void* stream);
+/* glued_pairing over the WHOLE batch as one product (pairing.rs:1029-1037 applied to n_pairs pairs; the batch-verification
+ * shape of examples/verify_multiple_messages_same_signer.rs:41-60 and threshold_signing.rs:92-121): gt_out [48][1] =
+ * final_exponentiation(prod_i miller(P_i, Q_i)), is_one[0] = (that == Gt::identity()).  The pairs are spread over the whole
+ * GPU (chunks with shared squarings, a product tree, one final exponentiation); the value is the one the reference's
+ * sequential glued loop yields.  skip_infinity as for multi_pairing_batch.  n_pairs = 0 gives the identity. */
+int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                        size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream);
 
 /* ---- hash-to-curve and BLS: src/hasher.rs, src/svdw.rs, src/groups/g1.rs:307-331, src/lib.rs --- */
 /* G1Projective::hash_to_curve with XMDExpander<Keccak256>(dst, 128), COUNT=2, L=48.

@@ -250,8 +250,9 @@ def glued_pairing(g1s: G1Affine, g2s: G2Affine, offsets=None, evm_infinity: bool
     """glued_pairing(&[G1Projective], &[G2Projective]) -> Gt (pairing.rs:1029-1037).  Without `offsets` the
     whole batch is ONE product (the reference's shape); with offsets, job j multiplies pairs
     [offsets[j], offsets[j+1])."""
-    if offsets is None:
-        offsets = [0, len(g1s)]
+    if offsets is None:            # one product over the whole batch: spread over the GPU, one final exponentiation
+        gt, _ = engine().pairing_product(g1s.xy, g2s.xy, g1s.infinity, g2s.infinity, skip_infinity=evm_infinity)
+        return Gt(gt)
     gt, _ = engine().multi_pairing(g1s.xy, g2s.xy, offsets, g1s.infinity, g2s.infinity, skip_infinity=evm_infinity)
     return Gt(gt)
 

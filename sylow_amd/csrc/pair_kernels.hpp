@@ -106,7 +106,7 @@ constexpr int KMAXW = 4;
 
 __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                              const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
-                                             u64* gout, uint8_t* is_one) {
+                                             u64* gout, uint8_t* is_one, int raw_miller) {
   const size_t t = TID, job = t >> 1;
   const int odd = (int)(t & 1);
   const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
@@ -196,12 +196,55 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   }
   S12 fin, g;
   w12_to_s12(fin, acc);
-  final_exponentiation29(g, fin);
+  if (raw_miller) g = fin;                     // partial Miller product for the batch-wide reduction below
+  else final_exponentiation29(g, fin);
   if (active) {
     if (gout) store_s12(gout, n_jobs, job, odd, g);
     const bool one = s12_is_one(g);
     if (is_one && !odd) is_one[job] = one ? 1 : 0;
   }
+}
+
+// ------------------------------------------------------------------ one product over a whole batch ---------------------------
+// glued_pairing over n pairs as ONE Gt (examples/verify_multiple_messages_same_signer.rs:41-60: 2n pairs, one final
+// exponentiation, == identity).  The shared-squaring Miller value of a set of pairs is exactly the product of the per-pair Miller
+// values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KMAXW pairs per lane pair (k_multi_pairing with
+// raw_miller = 1), the chunk values are multiplied together by a log-depth tree of Fp12 products, and one lane pair runs the
+// final exponentiation.
+__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs) {
+  const size_t j = TID;
+  if (j > n_jobs) return;
+  const size_t v = j * (size_t)KMAXW;
+  off[j] = v < n_pairs ? v : n_pairs;
+}
+// out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out
+__global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* out, size_t n_out) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n_out) return;
+  S12 a;
+  load_s12(a, in, n_in, 2 * i, odd);
+  if (2 * i + 1 < n_in) {
+    S12 b;
+    load_s12(b, in, n_in, 2 * i + 1, odd);
+    W12 x, y, r;
+    w12_from_s12(x, a);
+    w12_from_s12(y, b);
+    w12_mul_nl(r, x, y);
+    w12_to_s12(a, r);
+  }
+  store_s12(out, n_out, i, odd, a);
+}
+__global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one) {
+  const size_t t = TID;
+  const int odd = (int)(t & 1);
+  if (t >= 2) return;
+  S12 f, g;
+  if (n_in) load_s12(f, fin, n_in, 0, odd); else f = s12_one();      // empty product = identity (pairing.rs:1218-1219)
+  final_exponentiation29(g, f);
+  if (gout) store_s12(gout, 1, 0, odd, g);
+  const bool one = s12_is_one(g);
+  if (is_one && !odd) is_one[0] = one ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ G2 group law on lane pairs -------------------------------

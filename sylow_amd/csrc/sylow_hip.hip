@@ -972,6 +972,7 @@ static int32_t fail(hipError_t e, const char* what) {
 #define ARGCHK(c) do { if (!(c)) { snprintf(g_err, sizeof(g_err), "bad argument: %s", #c); return SYLOW_HIP_E_ARG; } } while (0)
 #define GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream
 static bool single_lane();
+static int32_t workspace(void** out, size_t bytes, hipStream_t st);
 #define LAUNCHED() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "kernel launch"); return SYLOW_HIP_OK; } while (0)
 
 extern "C" {
@@ -1123,7 +1124,34 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (single_lane()) { k_multi_pairing<<<GRID(n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED(); }
-  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED();
+  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
+}
+int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                        size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK((gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy)));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n_jobs = (n_pairs + plk::KMAXW - 1) / plk::KMAXW;
+  if (n_jobs == 0) {
+    plk::k_final_exp_flag<<<1, 64, 0, st>>>(nullptr, 0, gt_out, is_one); LAUNCHED();
+  }
+  // workspace: chunk offsets + two ping-pong buffers of Fp12 values
+  const size_t n_off = (n_jobs + 2) & ~(size_t)1, n_a = 48 * n_jobs, n_b = 48 * ((n_jobs + 1) / 2);
+  void* base = nullptr;
+  int32_t rc = workspace(&base, (n_off + n_a + n_b) * sizeof(u64), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  u64 *off = (u64*)base, *bufa = off + n_off, *bufb = bufa + n_a;
+  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs);
+  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  u64 *cur = bufa, *nxt = bufb;
+  size_t m = n_jobs;
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    plk::k_fp12_tree_level<<<GRID(2 * h)>>>(cur, m, nxt, h);
+    u64* tmp = cur; cur = nxt; nxt = tmp;
+    m = h;
+  }
+  plk::k_final_exp_flag<<<1, 64, 0, st>>>(cur, 1, gt_out, is_one);
+  LAUNCHED();
 }
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
 static void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
@@ -1141,6 +1169,28 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
   ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; dst_arg(dp, nullptr, 0);
   k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
+}
+// Per-device scratch workspace for the few entry points that need temporaries (line table of one key, product tree).
+// Grow-only, plain hipMalloc (the stream-ordered allocator on the legacy default stream produced intermittently wrong
+// products here -- measured, see tools/dbg_prod.py -- so it is not used).  Calls that use the workspace are serialised
+// against each other: a call on another stream first waits for the previous user's stream.
+static int32_t workspace(void** out, size_t bytes, hipStream_t st) {
+  struct Ws { void* p; size_t cap; hipStream_t last; bool used; };
+  static Ws ws[64] = {};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { snprintf(g_err, sizeof(g_err), "device index out of range"); return SYLOW_HIP_E_ARG; }
+  Ws& w = ws[dev];
+  if (w.used && w.last != st) HIPCHK(hipStreamSynchronize(w.last));
+  if (bytes > w.cap) {
+    if (w.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(w.p)); w.p = nullptr; w.cap = 0; }
+    const size_t cap = bytes + (bytes >> 2) + 4096;
+    HIPCHK(hipMalloc(&w.p, cap));
+    w.cap = cap;
+  }
+  w.last = st; w.used = true;
+  *out = w.p;
+  return SYLOW_HIP_OK;
 }
 // The pairing-based entry points run on lane pairs (pair_kernels.hpp).  SYLOW_HIP_SINGLE_LANE=1 selects the one-element-per-lane
 // kernels instead: the slower twin kept for A/B measurements and as a second implementation for the parity tests.
@@ -1224,27 +1274,23 @@ int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint
   if (single_lane()) {
     int32_t rc = ensure_g2gen_lines(stream);
     if (rc != SYLOW_HIP_OK) return rc;
-    u32* table = nullptr;
-    HIPCHK(hipMallocAsync((void**)&table, 87 * 48 * sizeof(u32), st));
+    void* wsp = nullptr;
+    if ((rc = workspace(&wsp, 87 * 48 * sizeof(u32), st)) != SYLOW_HIP_OK) return rc;
+    u32* table = (u32*)wsp;
     k_g2_lines<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);          // the key is a 1-element SoA array
     k_bls_verify_fused<true><<<GRID(n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, ok, n);
-    hipError_t e_ = hipGetLastError();
-    HIPCHK(hipFreeAsync(table, st));
-    if (e_ != hipSuccess) return fail(e_, "kernel launch");
-    return SYLOW_HIP_OK;
+    LAUNCHED();
   }
   int32_t rc = ensure_g2gen_lines29(stream);
   if (rc != SYLOW_HIP_OK) return rc;
   const bn254::i32* gen = nullptr;
   if ((rc = gen_table29(&gen)) != SYLOW_HIP_OK) return rc;
-  bn254::i32* table = nullptr;
-  HIPCHK(hipMallocAsync((void**)&table, plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st));
+  void* wsp = nullptr;
+  if ((rc = workspace(&wsp, plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st)) != SYLOW_HIP_OK) return rc;
+  bn254::i32* table = (bn254::i32*)wsp;
   plk::k_g2_lines29<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
   plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n);
-  hipError_t e_ = hipGetLastError();
-  HIPCHK(hipFreeAsync(table, st));
-  if (e_ != hipSuccess) return fail(e_, "kernel launch");
-  return SYLOW_HIP_OK;
+  LAUNCHED();
 }
 int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
   ARGCHK(q_xy && coeffs); if (!n) return SYLOW_HIP_OK;
@@ -1264,10 +1310,12 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   ARGCHK(pair_offsets && result && status && (in || !n_pairs)); if (!n_jobs) return SYLOW_HIP_OK;
   hipStream_t st = (hipStream_t)stream;
   const size_t np = n_pairs ? n_pairs : 1;
-  // stream-ordered workspace: decoded SoA points, flags, per-pair status, per-job product flag
-  uint8_t* ws = nullptr;
+  // workspace: decoded SoA points, flags, per-pair status, per-job product flag
   const size_t bytes = np * (8 + 16) * 8 + 3 * np + n_jobs + 64;
-  HIPCHK(hipMallocAsync((void**)&ws, bytes, st));
+  void* wsp = nullptr;
+  int32_t rc = workspace(&wsp, bytes, st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  uint8_t* ws = (uint8_t*)wsp;
   u64* pxy = (u64*)ws;
   u64* qxy = pxy + 8 * np;
   uint8_t* pinf = (uint8_t*)(qxy + 16 * np);
@@ -1276,12 +1324,9 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   uint8_t* isone = pst + np;
   if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((2 * n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
   if (single_lane()) k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
-  else plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
+  else plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
   k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
-  hipError_t e_ = hipGetLastError();
-  HIPCHK(hipFreeAsync(ws, st));
-  if (e_ != hipSuccess) return fail(e_, "kernel launch");
-  return SYLOW_HIP_OK;
+  LAUNCHED();
 }
 
 int32_t sylow_hip_g1_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {

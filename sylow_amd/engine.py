@@ -291,6 +291,18 @@ class Engine:
         gt = self.from_device_soa(dgt)[:nj] if want_gt else None
         return gt, dis.download()[:nj]
 
+    def pairing_product(self, p_xy, q_xy, p_inf=None, q_inf=None, skip_infinity=False):
+        """prod_i e(P_i, Q_i) as ONE Gt, computed in parallel over the batch; returns (gt [1, 48], is_one)."""
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dq = self.to_device_soa(q_xy, 16) if n else None
+        dpi, dqi = (self._flags(p_inf, n), self._flags(q_inf, n)) if n else (None, None)
+        dgt, dis = self.empty((48, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_pairing_product_batch", self._ptr(dp), self._ptr(dpi), self._ptr(dq), self._ptr(dqi), n,
+                   1 if skip_infinity else 0, dgt.ptr, dis.ptr)
+        return self.from_device_soa(dgt), bool(dis.download()[0])
+
     # ---- wire formats ----------------------------------------------------------------------
     def _to_bytes(self, name, width, nbytes, xy, inf):
         xy = _aos(xy, width)

@@ -111,3 +111,65 @@ def test_infinity_semantics(engine, coracle):
     assert np.array_equal(gt, base)
     gt, is_one = engine.multi_pairing(p2[:2], q2[:2], [0, 2], p_inf=np.array([1, 1], dtype=np.uint8), q_inf=qinf[:2], skip_infinity=True)
     assert is_one.tolist() == [1]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 4, 5, 37, 301])
+def test_batch_wide_product_vs_oracle(engine, coracle, n):
+    """sylow_hip_pairing_product_batch: the whole batch as ONE glued product (chunked Miller loops, product tree, one final
+    exponentiation) equals the reference's sequential glued_pairing over the same pairs."""
+    rng = Xoshiro(SEED + 60 + n)
+    one = np.zeros((1, 48), dtype=np.uint64); one[0, 0] = 1
+    if n == 0:
+        gt, is_one = engine.pairing_product(np.zeros((0, 8), np.uint64), np.zeros((0, 16), np.uint64))
+        assert is_one and np.array_equal(gt, one)
+        return
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    gt, is_one = engine.pairing_product(p, q)
+    exp = coracle.glued_pairing(proj1(p), proj2(q), np.array([0, n], dtype=np.uint64))
+    assert np.array_equal(gt, exp) and not is_one
+    if n >= 4:
+        # skip mode drops flagged pairs (EIP-197); replay mode with a G2 identity zeroes the product (SURVEY.md N5)
+        pinf = np.zeros(n, np.uint8); qinf = np.zeros(n, np.uint8); pinf[1] = 1; qinf[3] = 1
+        keep = [i for i in range(n) if i not in (1, 3)]
+        gt_s, _ = engine.pairing_product(p, q, p_inf=pinf, q_inf=qinf, skip_infinity=True)
+        exp_s = coracle.glued_pairing(proj1(p[keep]), proj2(q[keep]), np.array([0, len(keep)], dtype=np.uint64))
+        assert np.array_equal(gt_s, exp_s)
+        q0 = q.copy(); q0[3] = pack([0, 0, 1, 0], 16)[0]
+        gt_r, _ = engine.pairing_product(p, q0, q_inf=qinf)
+        exp_r = coracle.glued_pairing(proj1(p), proj2(q0, qinf), np.array([0, n], dtype=np.uint64))
+        assert np.array_equal(gt_r, exp_r)
+
+
+def test_batch_wide_same_signer_verification(engine, coracle):
+    """examples/verify_multiple_messages_same_signer.rs:41-60 at batch size 64: the 2n pairs (sig_i, G2gen), (-H_i, pk) as one
+    product == identity; one forged signature flips the aggregate."""
+    rng = Xoshiro(SEED + 70)
+    n = 64
+    sk = limbs([rng.fp() % R.R_ORDER] * n)
+    msgs = [bytes([i, 7, 7]) for i in range(n)]
+    h_xy, _ = engine.hash_to_g1(msgs)
+    sig, _ = engine.g1_scalar_mul(h_xy, sk)
+    pk, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    neg_h = h_xy.copy()
+    neg_h[:, 4:] = engine.fp_neg(h_xy[:, 4:])
+    p = np.empty((2 * n, 8), np.uint64); p[0::2] = sig; p[1::2] = neg_h
+    q = np.empty((2 * n, 16), np.uint64); q[0::2] = np.repeat(pack(G2, 16), n, 0); q[1::2] = pk
+    _, ok = engine.pairing_product(p, q)
+    assert ok
+    p[10] = sig[11]
+    _, ok = engine.pairing_product(p, q)
+    assert not ok
+
+
+def test_batch_wide_product_is_deterministic(engine, coracle):
+    """Regression: the stream-ordered allocator on the default stream once made ~7 % of these calls return a wrong product
+    (tools/dbg_prod.py); the entry point now uses a per-device grow-only workspace."""
+    rng = Xoshiro(SEED + 75)
+    n = 96
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    exp = coracle.glued_pairing(proj1(p), proj2(q), np.array([0, n], dtype=np.uint64))
+    for _ in range(25):
+        gt, _ = engine.pairing_product(p, q)
+        assert np.array_equal(gt, exp)

@@ -66,6 +66,10 @@ eng._call("sylow_hip_g2_scalar_mul_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr
 ok = eng.empty((nv,), np.uint8)
 t = timed(lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, h.ptr, None, ok.ptr, nv), 2)
 res["bls_verify_2^18"] = {"per_s": nv / t, "all_ok": int(ok.download().all())}
+# batch-wide glued product (the aggregate batch-verification shape): 2^20 pairs -> one Gt
+gt1, is1 = eng.empty((48, 1)), eng.empty((1,), np.uint8)
+t = timed(lambda: eng._call("sylow_hip_pairing_product_batch", p.ptr, None, q.ptr, None, n, 0, gt1.ptr, is1.ptr), 2)
+res["pairing_product_2^20"] = {"pairs_per_s": n / t}
 # C5 end to end: the byte-level ecPairing entry point (decode + curve / subgroup checks + glued pairing), 2^16 jobs of
 # two pairs e(a P, Q) e(-a P, Q) == 1; EIP-197 encodings built from device-generated points
 nj = 1 << 16
