@@ -106,11 +106,10 @@ inline Gt glued_pairing(const std::vector<G1Affine>& g1s, const std::vector<G2Af
   std::vector<G1Affine> a(g1s.begin(), g1s.begin() + k);
   std::vector<G2Affine> b(g2s.begin(), g2s.begin() + k);
   auto dp = to_device_soa(a); auto dq = to_device_soa(b);
-  uint64_t off[2] = {0, k};
-  DeviceBuffer doff(16), dgt(sizeof(Gt));
-  check(sylow_hip_memcpy_h2d(doff.as<void>(), off, 16, nullptr), "h2d");
-  check(sylow_hip_multi_pairing_batch(dp.as<uint64_t>(), nullptr, dq.as<uint64_t>(), nullptr, doff.as<uint64_t>(), 1, k, 0,
-                                      dgt.as<uint64_t>(), nullptr, nullptr), "sylow_hip_multi_pairing_batch");
+  DeviceBuffer dgt(sizeof(Gt));
+  // the whole batch as one product, spread over the GPU (chunked Miller loops, product tree, one final exponentiation)
+  check(sylow_hip_pairing_product_batch(dp.as<uint64_t>(), nullptr, dq.as<uint64_t>(), nullptr, k, 0, dgt.as<uint64_t>(), nullptr, nullptr),
+        "sylow_hip_pairing_product_batch");
   return from_device_soa<Gt>(dgt, 1)[0];
 }
 // Mul<&Fp> for G1 / G2 (group.rs:639-667), elementwise
