@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 
 #include "bn254_hash.hpp"
@@ -1177,6 +1178,8 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
 static int32_t workspace(void** out, size_t bytes, hipStream_t st) {
   struct Ws { void* p; size_t cap; hipStream_t last; bool used; };
   static Ws ws[64] = {};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);     // bookkeeping only: two host threads must still not run workspace users concurrently
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { snprintf(g_err, sizeof(g_err), "device index out of range"); return SYLOW_HIP_E_ARG; }
