@@ -205,6 +205,59 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   }
 }
 
+// ------------------------------------------------------------------ Gt * Fr ---------------------------------------------------
+// Mul<&Fr> for &Gt (gt.rs:161-187): the reference's 256-step signed-digit square-and-multiply on generic Fp12 squares and
+// products (exact for any input), negative digits multiply by the conjugate.  Wave-uniform: every step squares; a step
+// multiplies when any lane of the wavefront has a non-zero digit, lanes with a zero digit multiply by one.
+__global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = i < n;
+  const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
+  S12 sa;
+  load_s12(sa, g, n, ii, odd);
+  W12 a, na, one, res;
+  w12_from_s12(a, sa);
+  na = w12_conj(a);
+  {
+    S12 so = s12_one();
+    w12_from_s12(one, so);
+  }
+  res = one;
+  // digits of fp.rs:653-662 on the raw 256-bit scalar
+  u32 k[8], xh[8], x3[8], np[8], nm[8];
+  {
+    const Fp kp = load_plain(ks, n, ii, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = kp.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xh[j] = (k[j] >> 1) | (j < 7 ? (k[j + 1] << 31) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
+#pragma unroll 1
+  for (int b = 255; b >= 0; --b) {
+    res = w12_sqr(res);
+    const bool bp = (np[b >> 5] >> (b & 31)) & 1, bm = (nm[b >> 5] >> (b & 31)) & 1;
+    if (__any(bp || bm)) {
+      W12 m;
+      W2* mc[6] = {&m.c0.c0, &m.c0.c1, &m.c0.c2, &m.c1.c0, &m.c1.c1, &m.c1.c2};
+      const W2* ac[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+      const W2* nc[6] = {&na.c0.c0, &na.c0.c1, &na.c0.c2, &na.c1.c0, &na.c1.c1, &na.c1.c2};
+      const W2* oc[6] = {&one.c0.c0, &one.c0.c1, &one.c0.c2, &one.c1.c0, &one.c1.c1, &one.c1.c2};
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *mc[q] = w2_select(w2_select(*oc[q], *nc[q], bm), *ac[q], bp);
+      w12_mul_nl(res, res, m);
+    }
+  }
+  S12 sr;
+  w12_to_s12(sr, res);
+  if (active) store_s12(out, n, i, odd, sr);
+}
+
 // ------------------------------------------------------------------ one product over a whole batch ---------------------------
 // glued_pairing over n pairs as ONE Gt (examples/verify_multiple_messages_same_signer.rs:41-60: 2n pairs, one final
 // exponentiation, == identity).  The shared-squaring Miller value of a set of pairs is exactly the product of the per-pair Miller

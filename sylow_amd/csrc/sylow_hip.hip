@@ -1352,7 +1352,9 @@ int32_t sylow_hip_f29_hook_batch(int32_t op, const uint64_t* a, const uint64_t* 
 }
 
 int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK; k_gt_pow<<<GRID(n)>>>(gt, k, out, n); LAUNCHED();
+  ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK;
+  if (single_lane()) { k_gt_pow<<<GRID(n)>>>(gt, k, out, n); LAUNCHED(); }
+  plk::k_gt_pow<<<GRID(2 * n)>>>(gt, k, out, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
