@@ -102,8 +102,10 @@ __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* o
 // one accumulator, a lane pair whose job has fewer pairs multiplies by the unit line.  Pair states live in the stack frame
 // (they are touched once per loop iteration); the accumulator and the working point stay in registers.
 struct PairStateW { G2W r; W2 qx, qy; S2 qxs, qys; F29 px, py; bool qinf, live; };
-constexpr int KMAXW = 4;
+constexpr int KMAXW = 4;        // ecPairing / glued jobs (a few pairs each)
+constexpr int KPROD = 8;        // batch-wide product: more pairs per shared squaring
 
+template <int KMAX>
 __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                              const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
                                              u64* gout, uint8_t* is_one, int raw_miller) {
@@ -118,13 +120,13 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
     S12 one = s12_one();
     w12_from_s12(acc, one);
   }
-  PairStateW st[KMAXW];
+  PairStateW st[KMAX];
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   while (wave_max(next < hi ? 1 : 0)) {
     int k = 0;
 #pragma unroll 1
-    for (int slot = 0; slot < KMAXW; ++slot) {
+    for (int slot = 0; slot < KMAX; ++slot) {
       bool have = false;
       size_t idx = 0;
       while (next < hi) {
@@ -261,13 +263,13 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
 // ------------------------------------------------------------------ one product over a whole batch ---------------------------
 // glued_pairing over n pairs as ONE Gt (examples/verify_multiple_messages_same_signer.rs:41-60: 2n pairs, one final
 // exponentiation, == identity).  The shared-squaring Miller value of a set of pairs is exactly the product of the per-pair Miller
-// values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KMAXW pairs per lane pair (k_multi_pairing with
+// values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KPROD pairs per lane pair (k_multi_pairing with
 // raw_miller = 1), the chunk values are multiplied together by a log-depth tree of Fp12 products, and one lane pair runs the
 // final exponentiation.
 __global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs) {
   const size_t j = TID;
   if (j > n_jobs) return;
-  const size_t v = j * (size_t)KMAXW;
+  const size_t v = j * (size_t)KPROD;
   off[j] = v < n_pairs ? v : n_pairs;
 }
 // out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out

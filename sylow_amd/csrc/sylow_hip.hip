@@ -1125,13 +1125,13 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (single_lane()) { k_multi_pairing<<<GRID(n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one); LAUNCHED(); }
-  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
+  plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
 }
 int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                         size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK((gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy)));
   hipStream_t st = (hipStream_t)stream;
-  const size_t n_jobs = (n_pairs + plk::KMAXW - 1) / plk::KMAXW;
+  const size_t n_jobs = (n_pairs + plk::KPROD - 1) / plk::KPROD;
   if (n_jobs == 0) {
     plk::k_final_exp_flag<<<1, 64, 0, st>>>(nullptr, 0, gt_out, is_one); LAUNCHED();
   }
@@ -1142,7 +1142,7 @@ int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_i
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *off = (u64*)base, *bufa = off + n_off, *bufb = bufa + n_a;
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs);
-  plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   u64 *cur = bufa, *nxt = bufb;
   size_t m = n_jobs;
   while (m > 1) {
@@ -1327,7 +1327,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   uint8_t* isone = pst + np;
   if (n_pairs) k_evm_decode_pairs<<<dim3((unsigned)((2 * n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
   if (single_lane()) k_multi_pairing<<<GRID(n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone);
-  else plk::k_multi_pairing<<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
+  else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
   k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
   LAUNCHED();
 }
