@@ -74,6 +74,12 @@ int32_t sylow_hip_fp_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* o
 int32_t sylow_hip_fp_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp_neg_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+/* Fp::pow(U256) (fp.rs:451-457), per-element exponents e [4][n] */
+int32_t sylow_hip_fp_pow_batch(const uint64_t* a, const uint64_t* e, uint64_t* out, size_t n, void* stream);
+/* Fp::sqrt (fp.rs:611-616): out = a^((p+1)/4), is_some[i] = (out_i^2 == a_i), i.e. the CtOption's value and flag */
+int32_t sylow_hip_fp_sqrt_batch(const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n, void* stream);
+/* Fp::is_square (fp.rs:625-631): 1 for squares and for 0 */
+int32_t sylow_hip_fp_is_square_batch(const uint64_t* a, uint8_t* flags, size_t n, void* stream);
 
 /* ---- Fr, the r-torsion scalar field (fields/fp.rs:556-565: the same macro-generated API as Fp, modulus r) -----------
  * Same contract as the Fp calls: [4][n] canonical limbs in and out, any 256-bit input accepted like Fr::new,

@@ -92,6 +92,27 @@ def fp_op(op, a, b=None):
     return _field_op(lib().oracle_fp_op, 4, op, a, b)
 
 
+def fp_pow(a, e):
+    a, e = _u64(a, 4), _u64(e, 4)
+    out = np.empty_like(a)
+    lib().oracle_fp_pow(_p(a), _p(e), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fp_sqrt(a):
+    a = _u64(a, 4)
+    out, ok = np.empty_like(a), np.empty(a.shape[0], dtype=np.uint8)
+    lib().oracle_fp_sqrt(_p(a), _p(out), _p(ok), ctypes.c_size_t(a.shape[0]))
+    return out, ok
+
+
+def fp_is_square(a):
+    a = _u64(a, 4)
+    flags = np.empty(a.shape[0], dtype=np.uint8)
+    lib().oracle_fp_is_square(_p(a), _p(flags), ctypes.c_size_t(a.shape[0]))
+    return flags
+
+
 def fr_op(op, a, b=None):
     return _field_op(lib().oracle_fr_op, 4, op, a, b)
 

@@ -745,6 +745,20 @@ API void oracle_fp_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
     st(out + 4 * i, r);
   }
 }
+/* Fp::pow(U256) (fp.rs:451-457), sqrt (fp.rs:611-616: value a^((p+1)/4) and whether it squares back), is_square (fp.rs:625-631),
+ * sgn0 (fp.rs:636-644) */
+API void oracle_fp_pow(const u64 *a, const u64 *e, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st(out + 4 * i, fp_pow(ld(a + 4 * i), e + 4 * i));
+}
+API void oracle_fp_sqrt(const u64 *a, u64 *out, uint8_t *ok, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) { fp r; ok[i] = (uint8_t)fp_sqrt(ld(a + 4 * i), &r); st(out + 4 * i, r); }
+}
+API void oracle_fp_is_square(const u64 *a, uint8_t *flags, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) flags[i] = (uint8_t)fp_is_square(ld(a + 4 * i));
+}
 API void oracle_fp2_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
   oracle_init();
   for (size_t i = 0; i < n; ++i) {

@@ -71,6 +71,9 @@ SIGNATURES = {
     "sylow_hip_bls_verify_same_signer_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_precompute_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_f29_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_pow_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp_sqrt_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_fp_is_square_batch": [c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_fr_add_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fr_sub_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fr_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],

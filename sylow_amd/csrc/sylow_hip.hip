@@ -125,6 +125,33 @@ __global__ void __launch_bounds__(BLOCK) k_fp_unop(const u64* __restrict__ a, u6
   }
 }
 
+// Fp::pow(U256) with a per-element exponent (fp.rs:451-457): uniform 256-step square-and-multiply (a lane whose bit is
+// clear multiplies by one); sqrt (fp.rs:611-616); is_square (fp.rs:625-631, as a Jacobi symbol); sgn0 is bit 0 of the value
+__global__ void __launch_bounds__(BLOCK) k_fp_pow(const u64* a, const u64* e, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const Fp x = load_fp(a, n, i, 0), one = fp_one();
+  const Fp ev = load_plain(e, n, i, 0);
+  Fp r = one;
+#pragma unroll 1
+  for (int b = 255; b >= 0; --b) {
+    r = fp_mul(r, r);
+    r = fp_mul(r, fp_select(one, x, (ev.v[b >> 5] >> (b & 31)) & 1));
+  }
+  store_fp(out, n, i, 0, r);
+}
+__global__ void __launch_bounds__(BLOCK) k_fp_sqrt(const u64* a, u64* out, uint8_t* ok, uint8_t* sq, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const Fp x = load_fp(a, n, i, 0);
+  if (out) {
+    const Fp r = fp_mul(x, fp_pow_pm3_quarter(x));            // x^((p+1)/4)
+    store_fp(out, n, i, 0, r);
+    if (ok) ok[i] = fp_eq(fp_mul(r, r), x) ? 1 : 0;
+  }
+  if (sq) sq[i] = fp_is_square(x) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ tower test hooks ----------
 __global__ void __launch_bounds__(BLOCK) k_fp2_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
   size_t i = TID;
@@ -1030,6 +1057,15 @@ FP_BIN(fr, 1, add, OP_ADD) FP_BIN(fr, 1, sub, OP_SUB) FP_BIN(fr, 1, mul, OP_MUL)
 FP_UN(fp, 0, sqr, OP_SQR) FP_UN(fp, 0, neg, OP_NEG) FP_UN(fp, 0, inv, OP_INV)
 FP_UN(fr, 1, sqr, OP_SQR) FP_UN(fr, 1, neg, OP_NEG) FP_UN(fr, 1, inv, OP_INV)
 
+int32_t sylow_hip_fp_pow_batch(const uint64_t* a, const uint64_t* e, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && e && out); if (!n) return SYLOW_HIP_OK; k_fp_pow<<<GRID(n)>>>(a, e, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp_sqrt_batch(const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n, void* stream) {
+  ARGCHK(a && out && is_some); if (!n) return SYLOW_HIP_OK; k_fp_sqrt<<<GRID(n)>>>(a, out, is_some, nullptr, n); LAUNCHED();
+}
+int32_t sylow_hip_fp_is_square_batch(const uint64_t* a, uint8_t* flags, size_t n, void* stream) {
+  ARGCHK(a && flags); if (!n) return SYLOW_HIP_OK; k_fp_sqrt<<<GRID(n)>>>(a, nullptr, nullptr, flags, n); LAUNCHED();
+}
 int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OP_MUL, a, b, out, n); LAUNCHED();
 }

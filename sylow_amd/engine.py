@@ -121,6 +121,22 @@ class Engine:
     def fp_sqr(self, a): return self._unop("sylow_hip_fp_sqr_batch", 4, a)
     def fp_neg(self, a): return self._unop("sylow_hip_fp_neg_batch", 4, a)
     def fp_inv(self, a): return self._unop("sylow_hip_fp_inv_batch", 4, a)
+    def fp_pow(self, a, e): return self._binop("sylow_hip_fp_pow_batch", 4, a, e)
+
+    def fp_sqrt(self, a):
+        a = _aos(a, 4)
+        n = a.shape[0]
+        da, do, dk = self.to_device_soa(a, 4), self.empty((4, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_fp_sqrt_batch", da.ptr, do.ptr, dk.ptr, n)
+        return self.from_device_soa(do), dk.download()
+
+    def fp_is_square(self, a):
+        a = _aos(a, 4)
+        n = a.shape[0]
+        da, dk = self.to_device_soa(a, 4), self.empty((n,), np.uint8)
+        self._call("sylow_hip_fp_is_square_batch", da.ptr, dk.ptr, n)
+        return dk.download()
+
     def fr_add(self, a, b): return self._binop("sylow_hip_fr_add_batch", 4, a, b)
     def fr_sub(self, a, b): return self._binop("sylow_hip_fr_sub_batch", 4, a, b)
     def fr_mul(self, a, b): return self._binop("sylow_hip_fr_mul_batch", 4, a, b)

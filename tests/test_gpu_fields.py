@@ -142,3 +142,20 @@ def test_f29_tower_vs_saturated_tower(engine, coracle):
     # edge: the identity and zero
     z = np.zeros((2, 48), dtype=np.uint64); z[0, 0] = 1
     assert np.array_equal(engine.fp12_hook(10, z), z) and np.array_equal(engine.fp12_hook(8, z, z), z)
+
+
+def test_fp_pow_sqrt_is_square_vs_oracle(engine, coracle):
+    """a5 of SURVEY.md 8: Fp::pow / sqrt / is_square (the latter as a fixed-trip Jacobi symbol on the GPU) against the oracle's
+    plain powers, edge values included."""
+    rng = Xoshiro(SEED + 9)
+    vals = [v % P for v in EDGE] + [rng.fp() for _ in range(1500)]
+    vals += [v * v % P for v in vals[:300]]                      # guaranteed squares
+    a = limbs(vals)
+    sq = engine.fp_is_square(a)
+    assert np.array_equal(sq, coracle.fp_is_square(a))
+    assert sq.tolist() == [1 if pow(v, (P - 1) // 2, P) in (0, 1) else 0 for v in vals]
+    r, ok = engine.fp_sqrt(a)
+    er, eok = coracle.fp_sqrt(a)
+    assert np.array_equal(r, er) and np.array_equal(ok, eok) and np.array_equal(ok, sq)
+    e = limbs([0, 1, 2, P - 1, P - 2, (1 << 256) - 1] + [rng.u256() for _ in range(58)])
+    assert np.array_equal(engine.fp_pow(a[:64], e), coracle.fp_pow(a[:64], e))
