@@ -138,6 +138,9 @@ int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* 
 /* GroupAffine::from(&GroupProjective) (group.rs:475-495) */
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (xi^((p-1)/3) conj x, xi^((p-1)/2) conj y), identity -> identity.
+ * status (may be NULL): NOT_ON_CURVE where the reference's on-curve re-check of the image would panic. */
+int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream);
 /* G2Projective::new on affine input (g2.rs:460-525): status = OK / NOT_ON_CURVE / NOT_IN_SUBGROUP.
  * (The reference panics for off-curve input, g2.rs:151; this returns NOT_ON_CURVE instead.) */
 int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream);

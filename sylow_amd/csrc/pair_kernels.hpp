@@ -403,6 +403,20 @@ __global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* 
   const G2Q p{w2_from_s2(load_s2(pxyz, n, i, 0, odd)), w2_from_s2(load_s2(pxyz, n, i, 8, odd)), w2_from_s2(load_s2(pxyz, n, i, 16, odd))};
   store_g2q_affine(oxy, oinf, n, i, odd, p);
 }
+// G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (eps0 conj x, eps1 conj y), psi(identity) = identity; status reports the
+// on-curve re-check the reference performs on the result (it panics there; here NOT_ON_CURVE)
+__global__ void __launch_bounds__(BLOCK) k_g2_psi(const u64* qxy, const uint8_t* qinf, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const bool inf = qinf && qinf[i];
+  S2 x = load_s2(qxy, n, i, 0, odd), y = load_s2(qxy, n, i, 8, odd), px, py;
+  g2_psi_affine(px, py, x, y);
+  const bool on = inf || g2q_on_curve_affine(px, py);
+  store_s2(oxy, n, i, 0, odd, inf ? x : px);
+  store_s2(oxy, n, i, 8, odd, inf ? y : py);
+  if (!odd) { oinf[i] = inf ? 1 : 0; if (status) status[i] = on ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE; }
+}
 // g2.rs:460-525 on an affine input
 __global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* qinf, uint8_t* status, size_t n) {
   const size_t t = TID, i = t >> 1;

@@ -1135,6 +1135,10 @@ int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, ui
   if (single_lane()) { k_g2_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED(); }
   plk::k_g2_normalize<<<GRID(2 * n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
 }
+int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(q_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  plk::k_g2_psi<<<GRID(2 * n)>>>(q_xy, q_inf, out_xy, out_inf, status, n); LAUNCHED();
+}
 int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream) {
   ARGCHK(q_xy && status); if (!n) return SYLOW_HIP_OK;
   if (single_lane()) { k_g2_subgroup_check<<<GRID(n)>>>(q_xy, q_inf, status, n); LAUNCHED(); }

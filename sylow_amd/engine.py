@@ -262,6 +262,14 @@ class Engine:
     def g1_normalize(self, p_xyz): return self._normalize("sylow_hip_g1_normalize_batch", 12, 8, p_xyz)
     def g2_normalize(self, p_xyz): return self._normalize("sylow_hip_g2_normalize_batch", 24, 16, p_xyz)
 
+    def g2_psi(self, q_xy, q_inf=None):
+        q_xy = _aos(q_xy, 16)
+        n = q_xy.shape[0]
+        dq, di = self.to_device_soa(q_xy, 16), self._flags(q_inf, n)
+        do, doi, dst = self.empty((16, n)), self.empty((n,), np.uint8), self.empty((n,), np.uint8)
+        self._call("sylow_hip_g2_psi_batch", dq.ptr, self._ptr(di), do.ptr, doi.ptr, dst.ptr, n)
+        return self.from_device_soa(do), doi.download(), dst.download()
+
     def g2_subgroup_check(self, q_xy, q_inf=None):
         q_xy = _aos(q_xy, 16)
         n = q_xy.shape[0]

@@ -178,3 +178,22 @@ def test_scalar_mul_group_properties_large(engine):
     sp, _ = engine.g1_scalar_mul(g, s)
     sum_xy, sum_inf = engine.g1_add(ap, bp)
     assert np.array_equal(sum_xy, sp) and not sum_inf.any()
+
+
+def test_g2_endomorphism_vs_oracle(engine, coracle):
+    """G2Affine::endomorphism (g2.rs:140-152): psi against the oracle, psi^2 ... relations, identity and off-curve inputs."""
+    rng = Xoshiro(SEED + 28)
+    n = 70
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    inf = np.zeros(n, np.uint8); inf[3] = 1
+    out, oinf, st = engine.g2_psi(q, inf)
+    exp = coracle.g2_psi(q)
+    live = inf == 0
+    assert np.array_equal(out[live], exp[live]) and np.array_equal(oinf, inf) and not st.any()
+    assert np.array_equal(out[3], q[3])                                   # identity -> identity, coordinates untouched
+    # psi acts on G2 as multiplication by p mod r (the Frobenius eigenvalue)
+    mu, _ = engine.g2_scalar_mul(q[8:16], limbs([P % R.R_ORDER] * 8))
+    assert np.array_equal(mu, out[8:16])
+    bad = q.copy(); bad[0, 0] ^= np.uint64(1)                             # off the twist: the image is off the twist too
+    _, _, st2 = engine.g2_psi(bad)
+    assert st2[0] == 1 and not st2[1:].any()
