@@ -165,6 +165,11 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
 int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
                                       uint64_t* gt_out, uint8_t* is_one, void* stream);
+/* glued_miller_loop(&[G2PreComputed], &[G1Affine]) -> MillerLoopResult (pairing.rs:970-1022), one raw value per job (same job
+ * layout as multi_pairing_batch, no final exponentiation, no identity handling -- exactly like the reference's loop).  The value
+ * is the product of the per-pair Miller values, which is what the shared-squaring loop computes. */
+int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
+                                          uint64_t* f_out, void* stream);
 /* glued_pairing over the WHOLE batch as one product (pairing.rs:1029-1037 applied to n_pairs pairs; the batch-verification
  * shape of examples/verify_multiple_messages_same_signer.rs:41-60 and threshold_signing.rs:92-121): gt_out [48][1] =
  * final_exponentiation(prod_i miller(P_i, Q_i)), is_one[0] = (that == Gt::identity()).  The pairs are spread over the whole

@@ -241,6 +241,15 @@ class G2PreComputed:
         return MillerLoopResult(engine().miller_loop(g1.xy, self.q.xy))
 
 
+def glued_miller_loop(g2s, g1s: G1Affine, offsets=None) -> MillerLoopResult:
+    """glued_miller_loop(&[G2PreComputed], &[G1Affine]) -> MillerLoopResult (pairing.rs:970-1022).  `g2s` is a G2PreComputed or
+    G2Affine batch; without `offsets` the whole batch is one job."""
+    q = g2s.q if isinstance(g2s, G2PreComputed) else g2s
+    if offsets is None:
+        offsets = [0, min(len(g1s), len(q))]               # zip truncates (pairing.rs:975)
+    return MillerLoopResult(engine().glued_miller_loop(g1s.xy, q.xy, offsets))
+
+
 def pairing(p: G1Affine, q: G2Affine) -> Gt:
     """pairing(&G1Projective, &G2Projective) -> Gt (pairing.rs:870-893), n independent values."""
     return Gt(engine().pairing(p.xy, q.xy, p.infinity, q.infinity))

@@ -315,6 +315,17 @@ class Engine:
         gt = self.from_device_soa(dgt)[:nj] if want_gt else None
         return gt, dis.download()[:nj]
 
+    def glued_miller_loop(self, p_xy, q_xy, offsets):
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nj = off.shape[0] - 1
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dq = self.to_device_soa(q_xy, 16) if n else None
+        doff, df = self.to_device(off), self.empty((48, max(nj, 1)))
+        self._call("sylow_hip_glued_miller_loop_batch", self._ptr(dp), self._ptr(dq), doff.ptr, nj, n, df.ptr)
+        return self.from_device_soa(df)[:nj]
+
     def pairing_product(self, p_xy, q_xy, p_inf=None, q_inf=None, skip_infinity=False):
         """prod_i e(P_i, Q_i) as ONE Gt, computed in parallel over the batch; returns (gt [1, 48], is_one)."""
         p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)

@@ -173,3 +173,23 @@ def test_batch_wide_product_is_deterministic(engine, coracle):
     for _ in range(25):
         gt, _ = engine.pairing_product(p, q)
         assert np.array_equal(gt, exp)
+
+
+def test_glued_miller_loop_raw_value(engine, coracle):
+    """glued_miller_loop (pairing.rs:970-1022): the raw value of a job is the product of its pairs' Miller values; final
+    exponentiation of it is glued_pairing; an empty job yields one."""
+    rng = Xoshiro(SEED + 80)
+    ks = [1, 2, 3, 5, 0, 9]
+    n = sum(ks)
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.uint64)
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    f = engine.glued_miller_loop(p, q, off)
+    per_pair = coracle.miller_loop(p, q)
+    one = np.zeros((1, 48), dtype=np.uint64); one[0, 0] = 1
+    for j, k in enumerate(ks):
+        e = one
+        for i in range(int(off[j]), int(off[j + 1])):
+            e = coracle.fp12_op("mul", e, per_pair[i:i + 1])
+        assert np.array_equal(f[j:j + 1], e), j
+    assert np.array_equal(engine.final_exp(f), coracle.glued_pairing(proj1(p), proj2(q), off))
