@@ -179,6 +179,10 @@ int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_i
                                         size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream);
 
 /* ---- hash-to-curve and BLS: src/hasher.rs, src/svdw.rs, src/groups/g1.rs:307-331, src/lib.rs --- */
+/* Expander::hash_to_field(msg, 2, 48) with XMDExpander<Keccak256>(dst, 128) (hasher.rs:84-128, 157-250): out_u [8][n] = (u0, u1),
+ * each the 48-byte big-endian slice of expand_message_xmd(msg, DST', 96) reduced mod p.  dst_host NULL = the library DST. */
+int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                      uint64_t* out_u, size_t n, void* stream);
 /* G1Projective::hash_to_curve with XMDExpander<Keccak256>(dst, 128), COUNT=2, L=48.
  * msgs: concatenated message bytes; msg_offsets: n+1 uint64 byte offsets.  dst/dst_len: HOST
  * pointer to the domain separation tag (NULL -> sylow's DST, lib.rs:90). */

@@ -474,6 +474,15 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const
   oinf[i] = inf ? 1 : 0;
   if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
 }
+// Expander::hash_to_field(msg, 2, 48) (hasher.rs:84-128) over XMDExpander<Keccak256>::expand_message (hasher.rs:201-250)
+__global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, const u64* off, DstPrime dp, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  uint8_t em[96];
+  expand_message_xmd96(em, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  store_fp(out, n, i, 0, fp_from_be48(em));
+  store_fp(out, n, i, 4, fp_from_be48(em + 48));
+}
 // lib.rs:179-187
 __global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
@@ -1209,6 +1218,12 @@ int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offs
   ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; dst_arg(dp, dst_host, dst_len);
   k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n); LAUNCHED();
+}
+int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                      uint64_t* out_u, size_t n, void* stream) {
+  ARGCHK(msgs && msg_offsets && out_u); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; dst_arg(dp, dst_host, dst_len);
+  k_hash_to_field<<<GRID(n)>>>(msgs, msg_offsets, dp, out_u, n); LAUNCHED();
 }
 int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                  uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {

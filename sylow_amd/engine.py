@@ -369,6 +369,13 @@ class Engine:
         blob = np.frombuffer(b"".join(msgs) or b"\x00", dtype=np.uint8)
         return self.to_device(blob), self.to_device(off)
 
+    def hash_to_field(self, msgs, dst: bytes | None = None):
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        do = self.empty((8, n))
+        self._call("sylow_hip_hash_to_field_batch", dm.ptr, doff.ptr, dst, len(dst) if dst else 0, do.ptr, n)
+        return self.from_device_soa(do)
+
     def hash_to_g1(self, msgs, dst: bytes | None = None):
         n = len(msgs)
         dm, doff = self._msgs(msgs)

@@ -132,3 +132,18 @@ def test_same_signer_and_precompute(engine, coracle):
     sinf = (np.random.default_rng(4).random(n) < 0.3).astype(np.uint8)
     assert np.array_equal(engine.bls_verify_same_signer(pk, msgs, mixed, sig_inf=sinf), engine.bls_verify(np.repeat(pk, n, 0), msgs, mixed, sig_inf=sinf))
     assert np.array_equal(engine.bls_verify_same_signer(pk, msgs, mixed, pk_inf=[1], sig_inf=sinf).astype(bool), sinf.astype(bool))
+
+
+def test_hash_to_field_vs_oracle(engine, coracle):
+    """Expander::hash_to_field (hasher.rs:84-128): Keccak-256 XMD + 48-byte reduction, ragged message lengths across the
+    136-byte rate boundary, default and custom DST (incl. an oversize one, hasher.rs:157-173)."""
+    from oracle import pyref as R
+    msgs = [bytes((7 * i + j) & 0xFF for j in range(L)) for i, L in enumerate([0, 1, 3, 31, 32, 33, 55, 100, 135, 136, 137, 200, 271, 272, 273, 500])]
+    for dst in (None, b"QUUX-V01-CS02-with-expander-SHA256-128", b"x" * 300):
+        got = engine.hash_to_field(msgs, dst)
+        d = dst if dst is not None else R.DST
+        for i, m in enumerate(msgs):
+            em = coracle.expand_message_xmd_keccak(m, d, 96)
+            want = [int.from_bytes(em[:48], "big") % R.P, int.from_bytes(em[48:], "big") % R.P]
+            have = [sum(int(got[i, 4 * c + k]) << (64 * k) for k in range(4)) for c in range(2)]
+            assert have == want, (i, dst)
