@@ -125,9 +125,10 @@ BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp
 // digit).  Here every lane does 4 doublings + one complete addition of +-T[|d|] per window
 // (T[0] = identity: the RCB formulas are complete, so adding it is exact), 64 windows, table of
 // 1P..8P in the lane's scratch frame.  k*P as a group element is the same; only affine-normalised
-// results cross the boundary.  k is the Fp VALUE (< p, not reduced mod r: N4).
+// results cross the boundary.  k is the Fp VALUE (< p, not reduced mod r: N4).  `nwin` < 64 walks only the low
+// 4 nwin bits (callers with a short fixed scalar, e.g. the 63-bit BN parameter of the subgroup check: 17 windows incl. the carry).
 template <class O, class DBL, class ADD>
-BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add) {
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin = 64) {
   typedef Proj<typename O::F> Pt;
   // signed recoding: k = sum d_i 16^i, d_i in [-8, 7]; k < 2^254 so the top digit cannot overflow
   signed char dig[64];
@@ -150,8 +151,8 @@ BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const
   T[8] = dbl(T[4]);
   Pt res = proj_zero<O>();
 #pragma unroll 1
-  for (int i = 63; i >= 0; --i) {
-    if (i != 63) {
+  for (int i = nwin - 1; i >= 0; --i) {
+    if (i != nwin - 1) {
 #pragma unroll 1
       for (int j = 0; j < 4; ++j) res = dbl(res);
     }

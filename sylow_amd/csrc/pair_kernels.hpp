@@ -322,9 +322,9 @@ struct OpsW2 {
 typedef Proj<W2> G2Q;
 BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
 BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
-BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
+BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64) {
   out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
-                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; });
+                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin);
 }
 // group.rs:475-495 (through the saturated core: one Fp2 inversion)
 BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
@@ -341,7 +341,7 @@ BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
   const G2Q q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()};
   const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
   G2Q a;
-  g2q_scalar_mul(a, q, bx);
+  g2q_scalar_mul(a, q, bx, 17);                   // x < 2^63: 16 digits + the recoding carry
   // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
   const W2 e0 = w2_const(C_EPS_EXP0), e1 = w2_const(C_EPS_EXP1);
   auto psi = [&](G2Q& r, const G2Q& p) {
