@@ -138,6 +138,8 @@ int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* 
 /* GroupAffine::from(&GroupProjective) (group.rs:475-495) */
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* G1Affine::new (g1.rs:111-132): status[i] = OK when y^2 == x^3 + 3 (or the identity flag is set), NOT_ON_CURVE otherwise */
+int32_t sylow_hip_g1_on_curve_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* status, size_t n, void* stream);
 /* G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (xi^((p-1)/3) conj x, xi^((p-1)/2) conj y), identity -> identity.
  * status (may be NULL): NOT_ON_CURVE where the reference's on-curve re-check of the image would panic. */
 int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "sylow_hip_g1_lincomb_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_sz, c_vp],
     "sylow_hip_glued_miller_loop_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_sz, c_u64p, c_vp],
     "sylow_hip_pairing_product_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_i32, c_u64p, c_u8p, c_vp],
+    "sylow_hip_g1_on_curve_batch": [c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_psi_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_gt_pow_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_g2_add_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],

@@ -264,6 +264,13 @@ __global__ void HEAVY_BOUNDS k_g1_lincomb(const u64* pxy, const uint8_t* pinf, c
   store_fp(oxy, n_jobs, j, 0, x); store_fp(oxy, n_jobs, j, 4, y);
   oinf[j] = rinf ? 1 : 0;
 }
+// G1Affine::new (g1.rs:111-132): y^2 - x^3 == 3, the identity flag passes
+__global__ void __launch_bounds__(BLOCK) k_g1_on_curve(const u64* pxy, const uint8_t* pinf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const bool ok = (pinf && pinf[i]) || g1_on_curve_affine(load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4));
+  status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
 __global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
@@ -1134,6 +1141,9 @@ int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const
 int32_t sylow_hip_g1_lincomb_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n_jobs, size_t n_terms, void* stream) {
   ARGCHK(out_xy && out_inf && (n_terms == 0 || (p_xy && k))); if (!n_jobs) return SYLOW_HIP_OK;
   k_g1_lincomb<<<GRID(n_jobs)>>>(p_xy, p_inf, k, out_xy, out_inf, n_jobs, n_terms); LAUNCHED();
+}
+int32_t sylow_hip_g1_on_curve_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(p_xy && status); if (!n) return SYLOW_HIP_OK; k_g1_on_curve<<<GRID(n)>>>(p_xy, p_inf, status, n); LAUNCHED();
 }
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;

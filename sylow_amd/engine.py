@@ -262,6 +262,13 @@ class Engine:
     def g1_normalize(self, p_xyz): return self._normalize("sylow_hip_g1_normalize_batch", 12, 8, p_xyz)
     def g2_normalize(self, p_xyz): return self._normalize("sylow_hip_g2_normalize_batch", 24, 16, p_xyz)
 
+    def g1_on_curve(self, p_xy, p_inf=None):
+        p_xy = _aos(p_xy, 8)
+        n = p_xy.shape[0]
+        dp, di, dst = self.to_device_soa(p_xy, 8), self._flags(p_inf, n), self.empty((n,), np.uint8)
+        self._call("sylow_hip_g1_on_curve_batch", dp.ptr, self._ptr(di), dst.ptr, n)
+        return dst.download()
+
     def g2_psi(self, q_xy, q_inf=None):
         q_xy = _aos(q_xy, 16)
         n = q_xy.shape[0]

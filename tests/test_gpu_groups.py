@@ -197,3 +197,19 @@ def test_g2_endomorphism_vs_oracle(engine, coracle):
     bad = q.copy(); bad[0, 0] ^= np.uint64(1)                             # off the twist: the image is off the twist too
     _, _, st2 = engine.g2_psi(bad)
     assert st2[0] == 1 and not st2[1:].any()
+
+
+def test_g1_affine_new_check(engine):
+    """G1Affine::new (g1.rs:111-132): curve equation check on random points, perturbed points, edge coordinates and the identity."""
+    rng = Xoshiro(SEED + 29)
+    n = 64
+    pts, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    bad = pts.copy()
+    bad[::2, 4] ^= np.uint64(1)                                   # y perturbed on even rows
+    st = engine.g1_on_curve(bad)
+    assert st.tolist() == [1 if i % 2 == 0 else 0 for i in range(n)]
+    extra = np.concatenate([pack([0, 0], 8), pack([1, 2], 8), pack([1, P - 2], 8), pack([0, 1], 8), pack([P - 1, 5], 8)])
+    inf = np.array([0, 0, 0, 1, 0], np.uint8)
+    exp = [0 if (y * y - x * x * x - 3) % P == 0 else 1 for x, y in [(0, 0), (1, 2), (1, P - 2), (0, 1), (P - 1, 5)]]
+    exp[3] = 0
+    assert engine.g1_on_curve(extra, inf).tolist() == exp
