@@ -57,3 +57,12 @@ def test_argument_errors_are_reported_not_thrown():
     rc = lib.sylow_hip_fp_mul_batch(None, None, None, 4, None)
     assert rc == -2 and b"bad argument" in lib.sylow_hip_last_error()
     assert lib.sylow_hip_fp_mul_batch(None, None, None, 0, None) == -2
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/sylow_hip.h is the drop-in boundary: it must compile as C99 with no C++ / HIP / torch types."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "sylow_hip.h"\nint main(void) { return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
