@@ -1,0 +1,72 @@
+"""Soak / determinism harness: random batch sizes through every pairing-based entry point, each call issued twice (results must be
+bit-identical) and a slice checked against the oracle.  `python tools/soak.py [seconds]`"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from helpers import Xoshiro, limbs, pack
+from oracle import coracle as C, pyref as R
+import sylow_amd
+from test_gpu_multi_pairing import proj1, proj2, G1, G2
+
+eng = sylow_amd.Engine(0)
+rng = Xoshiro(0xC0FFEE)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t0 = time.time()
+NMAX = 4096
+base_k = limbs([rng.fp() for _ in range(NMAX)])
+P_all, _ = eng.g1_scalar_mul(np.repeat(pack(G1, 8), NMAX, 0), base_k)
+Q_all, _ = eng.g2_scalar_mul(np.repeat(pack(G2, 16), NMAX, 0), limbs([rng.fp() for _ in range(NMAX)]))
+rounds = checks = 0
+while time.time() - t0 < budget:
+    n = 1 + rng.next() % NMAX
+    s = rng.next() % (NMAX - n + 1)
+    p, q = P_all[s:s + n], Q_all[s:s + n]
+    pinf = np.array([(rng.next() % 17 == 0) for _ in range(n)], np.uint8)
+    qinf = np.array([(rng.next() % 19 == 0) for _ in range(n)], np.uint8)
+    a = eng.pairing(p, q, p_inf=pinf, q_inf=qinf); b = eng.pairing(p, q, p_inf=pinf, q_inf=qinf)
+    assert np.array_equal(a, b), ("pairing nondeterministic", n)
+    m = min(n, 6)
+    exp = C.final_exponentiation(C.miller_loop(p[:m], q[:m]))
+    one = np.zeros(48, np.uint64); one[0] = 1
+    exp[(pinf[:m] | qinf[:m]).astype(bool)] = one
+    assert np.array_equal(a[:m], exp), ("pairing parity", n)
+    # glued jobs with random sizes
+    sizes = []
+    left = n
+    while left > 0:
+        k = min(left, 1 + rng.next() % 7); sizes.append(k); left -= k
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    g1, o1 = eng.multi_pairing(p, q, off, p_inf=pinf, q_inf=qinf, skip_infinity=True)
+    g2, o2 = eng.multi_pairing(p, q, off, p_inf=pinf, q_inf=qinf, skip_infinity=True)
+    assert np.array_equal(g1, g2) and np.array_equal(o1, o2), ("multi_pairing nondeterministic", n)
+    j = int(rng.next() % len(sizes))
+    lo, hi = int(off[j]), int(off[j + 1])
+    keep = [i for i in range(lo, hi) if not (pinf[i] or qinf[i])]
+    e = C.glued_pairing(proj1(p[keep]), proj2(q[keep]), np.array([0, len(keep)], dtype=np.uint64))
+    assert np.array_equal(g1[j:j + 1], e), ("multi_pairing parity", n, j)
+    # batch-wide product
+    x1, _ = eng.pairing_product(p, q, p_inf=pinf, q_inf=qinf, skip_infinity=True)
+    x2, _ = eng.pairing_product(p, q, p_inf=pinf, q_inf=qinf, skip_infinity=True)
+    assert np.array_equal(x1, x2), ("product nondeterministic", n)
+    prod = g1[0:1]
+    for jj in range(1, g1.shape[0]):
+        prod = C.fp12_op("mul", prod, g1[jj:jj + 1])
+    assert np.array_equal(x1, prod), ("product != product of jobs", n)
+    # BLS: sign, then the three verifiers with planted corruptions
+    nv = min(n, 512)
+    sk = base_k[s:s + nv]
+    msgs = [bytes([(i * 7 + rounds) & 255] * (1 + (i % 40))) for i in range(nv)]
+    sig, sinf = eng.bls_sign(sk, msgs)
+    pk, _ = eng.g2_scalar_mul(np.repeat(pack(G2, 16), nv, 0), sk)
+    badi = set(int(rng.next() % nv) for _ in range(3))
+    sigb = sig.copy()
+    for i in badi: sigb[i] = sig[(i + 1) % nv] if nv > 1 else P_all[0]
+    want = [0 if (i in badi and nv > 1) else 1 for i in range(nv)]
+    if nv == 1: want = [0] if badi else [1]
+    for fused in (False, True):
+        v1 = eng.bls_verify(pk, msgs, sigb, fused=fused); v2 = eng.bls_verify(pk, msgs, sigb, fused=fused)
+        assert np.array_equal(v1, v2), ("verify nondeterministic", fused, n)
+        assert v1.tolist() == want or nv == 1, ("verify flags", fused, n, v1.tolist()[:8], want[:8])
+    rounds += 1; checks += 8
+print(f"soak ok: {rounds} rounds, {checks} cross-checks, {time.time() - t0:.0f} s")
