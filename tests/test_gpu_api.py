@@ -90,3 +90,32 @@ def test_precompute_and_miller_types(api, coracle):
     # MillerLoopResult default * x == x (pairing.rs:1244-1250)
     one = np.zeros((n, 48), dtype=np.uint64); one[:, 0] = 1
     assert ((api.MillerLoopResult(one) * ml) == ml).all()
+
+
+def test_shared_secret(api):
+    """pairing.rs:1074-1099: three-party Diffie-Hellman through Gt * Fr, 32 triples at once"""
+    from oracle import pyref as R
+    rng = Xoshiro(SEED + 55)
+    n = 32
+    sk = [api.fp([rng.fp() % R.R_ORDER for _ in range(n)]) for _ in range(3)]          # alice, bob, carol
+    pk1 = [api.G1Projective.generator(n) * k for k in sk]
+    pk2 = [api.G2Projective.generator(n) * k for k in sk]
+    alice_ss = api.pairing(pk1[1], pk2[2]) * sk[0]
+    bob_ss = api.pairing(pk1[2], pk2[0]) * sk[1]
+    carol_ss = api.pairing(pk1[0], pk2[1]) * sk[2]
+    assert (alice_ss == bob_ss).all() and (bob_ss == carol_ss).all()
+    assert not (alice_ss == api.Gt.identity(n)).any()
+
+
+def test_bilinearity(api):
+    """pairing.rs:1192-1213 on 40 random (p, q, s) triples"""
+    from oracle import pyref as R
+    rng = Xoshiro(SEED + 56)
+    n = 40
+    fr = lambda: api.fp([rng.fp() % R.R_ORDER for _ in range(n)])
+    p, q, s = api.G1Projective.generator(n) * fr(), api.G2Projective.generator(n) * fr(), fr()
+    a = api.pairing(p, q) * s
+    assert (a == api.pairing(p * s, q)).all() and (a == api.pairing(p, q * s)).all()
+    t = api.fp([R.R_ORDER - 1] * n)                                                       # -Fr::ONE
+    assert not (a == api.Gt.identity(n)).any()
+    assert (((a * t) + a) == api.Gt.identity(n)).all()
