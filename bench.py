@@ -3,21 +3,29 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n L]
 
-A "step" is one pass of the hot path (sylow_hip_pairing_batch: Miller loop + final
-exponentiation, pairing.rs:870-893) over one batch of 2^L synthetic (P_i, Q_i) pairs PER GPU,
-inputs and outputs resident in HBM (nothing crosses PCIe inside the timed region).  Batches
-shard trivially (independent pairings), so scaling is weak and the data path has no collective;
-the only exchange is the 4-byte MIN(=AND) all-reduce of the aggregate BLS-verify flag, exercised
-in the untimed `aux` leg.
+A "step" is one pass of the hot path (sylow_hip_pairing_batch: Miller loop + final exponentiation,
+pairing.rs:870-893) over one batch of 2^L synthetic (P_i, Q_i) pairs PER GPU, inputs and outputs
+resident in HBM (nothing crosses PCIe inside the timed region).  Batches shard trivially
+(independent pairings), so scaling is weak and the data path has no collective; the only exchange
+is the 4-byte MIN(=AND) all-reduce of the aggregate BLS-verify flag (sylow_amd/sharding.py),
+exercised in the untimed `aux` leg.
 
-One JSON line is printed by rank 0.  `roofline` prices the dominant kernel (k_pairing) against
-HBM as the contract asks (576 algorithmic bytes per pairing); because a pairing is ~2x10^4 field
-multiplications on 576 bytes the meaningful ceiling is VALU issue rate, reported beside it as
-`issue_roofline` (see DESIGN.md "Rooflines").
+One JSON line is printed by rank 0:
+ * `roofline`      the contract's HBM pricing of the dominant kernel (576 algorithmic bytes per pairing) -- a pairing is
+                   ~2x10^4 field multiplications on 576 bytes, so this fraction is tiny by nature;
+ * `issue_roofline` the roof that binds it: VALU issue cycles (cycle-weighted by instruction class, <= 1);
+ * `aux`           BLS verify at batch 2^20 (BASELINE configs[3]) incl. the AND over ranks, and at N = 1 the other single-GPU
+                   configs (C2a Fp mul/add -- the HBM-bound kernels --, C2b G1 scalar-mul, C3 2^18 pairings, C5 byte-level
+                   ecPairing) each with its own algorithmic GB/s and fraction of the HBM roof;
+ * `cpu_baseline`  the C oracle (a port of the reference) on the host cores, the sign shape, the cargo probe, and an oracle
+                   spot check of rows the TIMED launches wrote (`checked` / `mismatches`).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -27,21 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
-ISSUE_PEAK_GINSTR = 580.0             # measured VOP3 wave-instr/s ceiling, profiles/r01_issue_rate_ubench.txt
+N_SIMD = 1024                         # 256 CUs x 4 SIMDs
 PAIRING_BYTES = 576                   # 64 (G1 affine) + 128 (G2 affine) + 384 (Gt)  -- SURVEY.md §8(d)
 VERIFY_BYTES = 225                    # pk 128 + sig 64 + 32-byte msg + flag
-# rocprofv3 PMC facts about the dominant kernel (plk::k_pairing): bench.py cannot collect PMC counters itself, so the
-# per-pairing constants measured by tools/prof_pairing.sh (separate --pmc passes, n = 2^20) are read from the committed summary
-# profiles/pmc_current.json and scale with n.  Refresh with tools/prof_pairing.sh whenever the kernel changes.
-def _load_pmc():
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
-            return json.load(f)
-    except OSError:
-        return None
-
-
-PMC = _load_pmc()
+FP_OP_BYTES = 96                      # 2 x 32 in + 32 out
+G1_MUL_BYTES = 160                    # 64 affine in + 32 scalar + 64 affine out
+SEED = 0x53594C4F57                   # "SYLOW" (BASELINE.md §3); + config index
 
 G1 = [1, 2]
 G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
@@ -49,26 +48,40 @@ G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
       0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA,
       0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B]
 M64 = (1 << 64) - 1
+# sources the dominant kernel is compiled from: the committed PMC summary is only valid for the build it was measured on
+PAIRING_KERNEL_SOURCES = ["plk_pairing.hip", "plk_common.hpp", "host.hpp", "common.hpp", "bn254_pair29.hpp", "bn254_pair.hpp", "bn254_f29.hpp",
+                          "bn254_tower.hpp", "bn254_fp.hpp", "bn254_constants.hpp", "bn254_pairing.hpp", "bn254_hash.hpp", "bn254_fr.hpp"]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in PAIRING_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "sylow_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """rocprofv3 PMC facts about plk::k_pairing (bench.py cannot collect PMC counters itself): per-pairing constants measured by
+    tools/prof_pairing.sh (separate --pmc passes, n = 2^20) in profiles/pmc_current.json.  Returns (pmc or None, stale?)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        return None, False
+    return pmc, pmc.get("kernel_source_hash") != kernel_source_hash()
 
 
 def limbs_row(vals):
     return np.array([[(v >> (64 * k)) & M64 for v in vals for k in range(4)]], dtype=np.uint64)
 
 
-def rand_scalars_soa(seed, n):
-    """n scalars < 2^253 (< p, uniform enough for synthetic points) directly in SoA [4][n]"""
-    g = np.random.default_rng(seed)
-    a = g.integers(0, 1 << 63, size=(4, n), dtype=np.uint64) * np.uint64(2) + g.integers(0, 2, size=(4, n), dtype=np.uint64)
-    a[3] &= np.uint64((1 << 61) - 1)
-    return a
-
-
 def make_points(eng, n, seed):
-    """P_i = a_i*G1gen, Q_i = b_i*G2gen generated on the device; returns SoA device arrays."""
+    """P_i = a_i*G1gen, Q_i = b_i*G2gen generated on the device from the xoshiro stream; returns SoA device arrays."""
     g1 = eng.empty((8, n)).upload(np.repeat(limbs_row(G1).T, n, axis=1))
     g2 = eng.empty((16, n)).upload(np.repeat(limbs_row(G2).T, n, axis=1))
-    ka = eng.empty((4, n)).upload(rand_scalars_soa(seed, n))
-    kb = eng.empty((4, n)).upload(rand_scalars_soa(seed + 1, n))
+    ka = eng.empty((4, n)).upload(eng.xoshiro_fp_soa(seed, n))
+    kb = eng.empty((4, n)).upload(eng.xoshiro_fp_soa(seed + (1 << 32), n))
     p, pi = eng.empty((8, n)), eng.empty((n,), np.uint8)
     q, qi = eng.empty((16, n)), eng.empty((n,), np.uint8)
     eng._call("sylow_hip_g1_scalar_mul_batch", g1.ptr, None, ka.ptr, p.ptr, pi.ptr, n)
@@ -77,9 +90,24 @@ def make_points(eng, n, seed):
     return p, q, ka, kb
 
 
-def cpu_baseline(target_seconds=10.0):
-    """The C oracle (a port of the reference's pairing(), 256-iteration loops as written) on the
-    host cores.  Strictly time-bounded: every worker thread runs small chunks until the deadline."""
+# ------------------------------------------------------------------------------------------------- CPU leg (rank 0, N = 1)
+def cargo_probe():
+    """sylow's own benches can only be timed if the box has cargo AND an offline registry."""
+    exe = shutil.which("cargo")
+    if not exe:
+        return {"cargo": None, "case": "no cargo on this box: sylow's own criterion benches cannot be built; baseline = C port of the reference"}
+    try:
+        ver = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:  # noqa: BLE001
+        ver = f"error: {e}"
+    return {"cargo": ver, "case": "cargo present but the reference sources and its un-vendored crates (crypto-bigint 0.6.0-rc.3, sha3 0.11.0-pre.4) "
+                                  "do not travel to this box: baseline = C port of the reference"}
+
+
+def cpu_baseline(check=None, target_seconds=10.0):
+    """The C oracle (a port of the reference's pairing(), 256-iteration loops as written) on the host cores: single-thread
+    generator pairing (benches/pairing.rs:5-10) and sign (benches/sig.rs:10-21) shapes, then all cores for `target_seconds`.
+    `check` = (p_xy, q_xy, gt) host AoS rows the TIMED launches produced: recomputed here and compared bit for bit."""
     import threading
 
     from oracle import coracle as C
@@ -89,9 +117,21 @@ def cpu_baseline(target_seconds=10.0):
     one_q = np.concatenate([limbs_row(G2), np.array([[1, 0, 0, 0, 0, 0, 0, 0]], dtype=np.uint64)], axis=1)
     chunk = 32
     p, q = np.repeat(one_p, chunk, 0), np.repeat(one_q, chunk, 0)
+    C.pairing(p[:2], q[:2])
     t0 = time.perf_counter()
     C.pairing(p, q)
     single = chunk / (time.perf_counter() - t0)
+    # sign shape: sk = first PRNG draw, msg = 20_i32.to_be_bytes() (benches/sig.rs:7), n >= 100
+    ns = 128
+    from sylow_amd import _lib                                  # host-side PRNG only (no GPU involved)
+    first = np.empty((4, 1), dtype=np.uint64)
+    _lib.check(_lib.load().sylow_hip_host_xoshiro_fp(SEED + 1, first.ctypes.data, 1, 1), "xoshiro")
+    sk = np.repeat(first.T.copy(), ns, 0)
+    msgs = [(20).to_bytes(4, "big")] * ns
+    C.sign(sk[:2], msgs[:2])
+    t0 = time.perf_counter()
+    C.sign(sk, msgs)
+    sign_single = ns / (time.perf_counter() - t0)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -113,10 +153,99 @@ def cpu_baseline(target_seconds=10.0):
         t.join()
     dt = time.perf_counter() - t0
     total = sum(counts)
-    return {"value": total / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
-            "sample": f"{total} generator pairings e(G1,G2) (benches/pairing.rs shape) in {dt:.1f} s on {cores} threads, "
-                      f"C oracle restating sylow pairing() incl. its 256-iteration loops; single-thread {single:.0f}/s; "
-                      "the reference's only published figure: 8.183 ms/pairing (hardware unstated)"}
+    out = {"value": total / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
+           "sample": f"{total} generator pairings e(G1gen, G2gen) (benches/pairing.rs:5-10 shape) on {cores} threads for {dt:.1f} s; "
+                     f"C restatement of the reference's formulas and loop structure (oracle/sylow_oracle.c), not sylow itself",
+           "single_thread_pairings_per_s": single, "single_thread_signs_per_s": sign_single,
+           "sign_sample": f"{ns} x sign(sk, 20_i32.to_be_bytes()) (benches/sig.rs:10-21 shape), one thread",
+           "reference_published": {"pairing_ms": 8.183, "sign_us": 954, "source": "sylow_devguide.pdf p.62, hardware unstated"},
+           "rust_toolchain": cargo_probe()}
+    if check is not None:
+        p_xy, q_xy, gt = check
+        m = p_xy.shape[0]
+        one = np.zeros((m, 4), dtype=np.uint64); one[:, 0] = 1
+        exp = C.pairing(np.concatenate([p_xy, one], axis=1), np.concatenate([q_xy, one, np.zeros((m, 4), dtype=np.uint64)], axis=1))
+        out["checked"] = int(m)
+        out["mismatches"] = int(m - int(np.all(exp == gt, axis=1).sum()))
+        out["check_note"] = "rows of the Gt array written by the TIMED launches, PRNG-chosen indices, recomputed by the oracle"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- timing helpers
+def hip_timed(torch, stream, fn, reps):
+    """Average seconds per call of `fn` (a launch sequence on `stream`), HIP events on that stream."""
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        fn()
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def single_gpu_configs(eng, torch, stream, p, q, ka, n):
+    """BASELINE.json configs[1], [2], [4] on one GPU, device-resident, HIP-event timed (units/s, algorithmic GB/s, fraction of
+    the 8 TB/s HBM roof).  Fp mul / add are the HBM-bound kernels of the path (96 algorithmic bytes per element)."""
+    res = {}
+    for log2n, reps in ((20, 200), (24, 20)):           # 2^20 = 96 MB per launch (~20 us): 200 back-to-back launches
+        m = 1 << log2n
+        a = eng.empty((4, m)).upload(eng.xoshiro_fp_soa(SEED + 2, m))
+        b = eng.empty((4, m)).upload(eng.xoshiro_fp_soa(SEED + 2 + (1 << 32), m))
+        o = eng.empty((4, m))
+        for name in ("mul", "add"):
+            t = hip_timed(torch, stream, lambda: eng._call(f"sylow_hip_fp_{name}_batch", a.ptr, b.ptr, o.ptr, m), reps)
+            gbs = FP_OP_BYTES * m / t / 1e9
+            res[f"C2a_fp_{name}_2^{log2n}"] = {"units_per_s": m / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS, "launch_us": t * 1e6,
+                                              "kernel": f"k_fp_binop<{'2' if name == 'mul' else '0'},0>"}
+        del a, b, o
+    o, oi = eng.empty((8, n)), eng.empty((n,), np.uint8)
+    t = hip_timed(torch, stream, lambda: eng._call("sylow_hip_g1_scalar_mul_batch", p.ptr, None, ka.ptr, o.ptr, oi.ptr, n), 3)
+    gbs = G1_MUL_BYTES * n / t / 1e9
+    res[f"C2b_g1_scalar_mul_2^{n.bit_length() - 1}"] = {"units_per_s": n / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS, "kernel": "k_g1_scalar_mul"}
+    del o, oi
+    n3 = min(n, 1 << 18)
+    p3 = eng.empty((8, n3)).upload(np.ascontiguousarray(p.download()[:, :n3]))
+    q3 = eng.empty((16, n3)).upload(np.ascontiguousarray(q.download()[:, :n3]))
+    gt3 = eng.empty((48, n3))
+    t = hip_timed(torch, stream, lambda: eng._call("sylow_hip_pairing_batch", p3.ptr, None, q3.ptr, None, gt3.ptr, n3), 3)
+    gbs = PAIRING_BYTES * n3 / t / 1e9
+    res[f"C3_pairing_2^{n3.bit_length() - 1}"] = {"units_per_s": n3 / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS, "kernel": "plk::k_pairing"}
+    # C5: byte-level ecPairing (EIP-197 192-byte pairs: decode + curve / subgroup checks + glued pairing), 2^16 jobs x k pairs.
+    # job j: e(P, Q) e(-P, Q) [k = 2] or e(P, Q) e(-P, Q) e(P', Q') e(-P', Q') [k = 4] -> true; every other job has its last G1
+    # point replaced by a different one -> false.
+    nj = min(1 << 16, n // 4)
+    npts = 2 * nj
+    ny = eng.empty((4, n3))
+    eng._call("sylow_hip_fp_neg_batch", p3.ptr + 4 * n3 * 8, ny.ptr, n3)                      # y rows of the SoA array are contiguous
+    pneg = eng.empty((8, n3)).upload(np.concatenate([p3.download()[:4], ny.download()], axis=0))
+    b1, b1n, b2 = eng.empty((n3 * 64,), np.uint8), eng.empty((n3 * 64,), np.uint8), eng.empty((n3 * 128,), np.uint8)
+    eng._call("sylow_hip_g1_to_be_bytes_batch", p3.ptr, None, b1.ptr, n3)
+    eng._call("sylow_hip_g1_to_be_bytes_batch", pneg.ptr, None, b1n.ptr, n3)
+    eng._call("sylow_hip_g2_to_be_bytes_batch", q3.ptr, None, b2.ptr, n3)
+    g1b, g1nb, g2b = (x.download().reshape(n3, -1)[:npts] for x in (b1, b1n, b2))
+    pos, neg = np.concatenate([g1b, g2b], axis=1), np.concatenate([g1nb, g2b], axis=1)        # [npts][192] each
+    for k in (2, 4):
+        njk = nj if k == 2 else nj // 2
+        if k == 2:
+            jobs = np.concatenate([pos[:njk], neg[:njk]], axis=1)
+        else:
+            jobs = np.concatenate([pos[0:2 * njk:2], neg[0:2 * njk:2], pos[1:2 * njk:2], neg[1:2 * njk:2]], axis=1)
+        jobs = jobs.copy()
+        spoil = np.arange(njk) % 2 == 1
+        jobs[spoil, (k - 1) * 192:(k - 1) * 192 + 64] = g1b[(np.arange(njk)[spoil] + 7) % npts]
+        d_in = eng.to_device(jobs.reshape(-1))
+        d_off = eng.to_device(np.arange(njk + 1, dtype=np.uint64) * np.uint64(k))
+        d_res, d_st = eng.empty((njk,), np.uint8), eng.empty((njk,), np.uint8)
+        t = hip_timed(torch, stream, lambda: eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, njk, k * njk, d_res.ptr, d_st.ptr), 3)
+        gbs = (192 * k + 1) * njk / t / 1e9
+        r = d_res.download()
+        res[f"C5_ecpairing_bytes_2^{int(np.log2(njk))}_k{k}"] = {
+            "units_per_s": njk / t, "pairs_per_s": k * njk / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS,
+            "pattern_ok": int(np.array_equal(r, (~spoil).astype(np.uint8)) and not d_st.download().any()),
+            "kernel": "k_evm_decode_pairs + plk::k_multi_pairing<4>"}
+    return res
 
 
 def main():
@@ -125,11 +254,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2n", type=int, default=20, help="pairings per GPU per step = 2^L")
-    ap.add_argument("--no-aux", action="store_true", help="skip the untimed BLS-verify aux leg")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-aux", action="store_true", help="skip the untimed BLS-verify / other-config aux leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and the oracle spot check)")
+    ap.add_argument("--plant-bad", type=int, default=-1, metavar="RANK", help="corrupt one signature on that rank (aux leg): the global AND must read 0")
     args = ap.parse_args()
 
     import torch
+
+    from sylow_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,28 +271,25 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
     # debugging aid for boxes with fewer GPUs than ranks: SYLOW_BENCH_BACKEND=gloo SYLOW_BENCH_SINGLE_DEVICE=1 runs every
-    # rank on cuda:0 with CPU-side collectives, exercising the same barrier / MAX / MIN logic as the RCCL path
+    # rank on cuda:0 with host-side collectives, exercising the same barrier / MAX / MIN logic as the RCCL path
     backend = os.environ.get("SYLOW_BENCH_BACKEND", "nccl")
     if os.environ.get("SYLOW_BENCH_SINGLE_DEVICE"):
         local_rank = 0
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(local_rank)
 
     import sylow_amd
     stream = torch.cuda.current_stream()
     eng = sylow_amd.Engine(local_rank, stream=stream.cuda_stream or None)
 
     n = 1 << args.log2n
-    p, q, ka, kb = make_points(eng, n, seed=0x53594C4F57 + 3 + 1000 * rank)
+    p, q, ka, kb = make_points(eng, n, seed=SEED + 3 + 1000 * rank)          # config index 3 = the pairing batch
     gt = eng.empty((48, n))
 
     def step():
@@ -184,11 +313,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    elapsed = sharding.max_over_ranks(elapsed, dist)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # rows of what the timed launches wrote, for the oracle spot check in the CPU leg
+    check = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        idx = np.sort(np.random.default_rng(SEED).choice(n, size=min(16, n), replace=False))
+        check = tuple(np.ascontiguousarray(d.download()[:, idx].T) for d in (p, q, gt))
 
     # ---- untimed aux leg: batched BLS verify + aggregate AND over ranks (RCCL MIN) ----------------
     aux = {}
@@ -198,7 +329,7 @@ def main():
         msgs_np = rng.integers(0, 256, size=(nv, 32), dtype=np.uint8)
         off = (np.arange(nv + 1, dtype=np.uint64) * np.uint64(32))
         dm, doff = eng.to_device(msgs_np.reshape(-1)), eng.to_device(off)
-        sk = eng.empty((4, nv)).upload(rand_scalars_soa(99 + rank, nv))
+        sk = eng.empty((4, nv)).upload(eng.xoshiro_fp_soa(SEED + 4 + 1000 * rank, nv))
         g2 = eng.empty((16, nv)).upload(np.repeat(limbs_row(G2).T, nv, axis=1))
         pk, pki = eng.empty((16, nv)), eng.empty((nv,), np.uint8)
         sig, sigi = eng.empty((8, nv)), eng.empty((nv,), np.uint8)
@@ -210,6 +341,11 @@ def main():
         eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv)
         fence()
         dtsg = time.perf_counter() - tsg
+        if args.plant_bad == rank:                # sig_j <- sig_{j+1}: a valid point, the wrong signature
+            s_h = sig.download()
+            j = nv // 3
+            s_h[:, j] = s_h[:, (j + 1) % nv]
+            sig.upload(s_h)
         eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)  # warm
         # torch's first device allocation initialises its allocator (seconds on a cold box): keep it outside the clocks
         flag = torch.ones(1, dtype=torch.int32, device="cuda")
@@ -218,9 +354,7 @@ def main():
         tv = time.perf_counter()
         eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
         eng._call("sylow_hip_flags_all", ok.ptr, nv, flag.data_ptr())
-        if dist is not None:
-            flag = flag.to(coll_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # AND over ranks, 4 bytes over xGMI
+        flag = sharding.and_reduce_(flag, dist)          # AND over ranks: 4 bytes over xGMI (RCCL MIN)
         fence()
         dtv = time.perf_counter() - tv
         eng._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)  # warm (+ builds the G2gen line table)
@@ -228,11 +362,10 @@ def main():
         tf = time.perf_counter()
         eng._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
         eng._call("sylow_hip_flags_all", ok.ptr, nv, flag2.data_ptr())
-        if dist is not None:
-            flag2 = flag2.to(coll_dev)
-            dist.all_reduce(flag2, op=dist.ReduceOp.MIN)
+        flag2 = sharding.and_reduce_(flag2, dist)
         fence()
         dtf = time.perf_counter() - tf
+        n_bad = int(nv - int(ok.download().sum()))
         eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)   # warm
         fence()
         ts = time.perf_counter()
@@ -264,14 +397,20 @@ def main():
         aux = {"aggregate_verify_sigs_per_s": world * na / dta, "aggregate_all_valid": agg_ok, "aggregate_batch_per_gpu": na,
                "bls_signs_per_s": world * nv / dtsg, "bls_verifies_per_s": world * nv / dtv, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
                "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
-               "bls_verifies_per_s_fused": world * nv / dtf, "bls_all_valid_fused": int(flag2.item()),
+               "bls_verify_frac_of_hbm": world * nv * VERIFY_BYTES / dtv / 1e9 / (HBM_PEAK_GBS * world),
+               "bls_verifies_per_s_fused": world * nv / dtf, "bls_all_valid_fused": int(flag2.item()), "bad_flags_this_rank": n_bad,
                "note": "verify = lib.rs:223-236 as written (hash + two full pairings); fused = e(sig,G2gen)*e(-H,pk)==1, one final exponentiation; "
                        "aggregate = all 2n pairs as one glued product == identity (hash + negation + product tree + one final exponentiation), one boolean"}
+        if world == 1:
+            del dm, doff, sk, g2, pk, pki, sig, sigi, ok, qq, hh, hhi, pp, hneg
+            aux["configs"] = single_gpu_configs(eng, torch, stream, p, q, ka, n)
 
     if rank == 0:
         total = world * n * args.steps
         value = total / elapsed
         achieved = PAIRING_BYTES * n / (kern_ms * 1e-3) / 1e9
+        pmc, stale = load_pmc()
+        live = pmc is not None and not stale
         out = {
             "metric": "BN254 optimal-ate pairings/s", "value": value, "unit": "pairings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,23 +421,27 @@ def main():
                        "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (PMC["hbm_bytes_per_pairing"] * n) if PMC else None,
-                         "traffic_note": ("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + PMC["source"] + "): "
-                                          "what is left beyond the algorithmic bytes is the stack frame of the final exponentiation's "
-                                          "straight-line part; the Miller loop and the f^x loops run out of registers") if PMC else None,
+                         "achieved_note": "ALGORITHMIC bytes (576 per pairing) / kernel time; the HBM-bound kernels of the path are aux.configs C2a",
+                         "traffic": (pmc["hbm_bytes_per_pairing"] * n) if live else None,
+                         "traffic_note": (("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + pmc["source"] + ")") if live else
+                                          ("profiles/pmc_current.json was measured on another build of the kernel (source hash differs): re-run tools/prof_pairing.sh"
+                                           if pmc is not None else None)),
                          "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
         }
-        if PMC:
-            ginstr = PMC["valu_instr_per_pairing"] * n / (kern_ms * 1e-3) / 1e9
-            out["issue_roofline"] = {"bound": "valu-issue", "achieved": ginstr, "peak": ISSUE_PEAK_GINSTR,
-                                     "unit": "G wave-instr/s", "frac": ginstr / ISSUE_PEAK_GINSTR,
-                                     "note": "the roof that actually binds a pairing (integer multiply-add chains): SQ_INSTS_VALU per "
-                                             "launch / kernel time vs the measured VOP3 issue ceiling (profiles/r01_issue_rate_ubench.txt: "
-                                             "~580 G wave-instr/s for VOP3, 477-520 for pure v_mad_*64 streams, ~900 for VOP2 adds)"}
+        if live and "valu_cycles_ideal_per_pairing" in pmc:
+            # cycle-weighted issue roofline: sum over instruction classes of (measured wave-instructions x issue cycles of the class) /
+            # SIMD-cycles available in the launch (clock from GRBM_GUI_ACTIVE of the same PMC run)
+            simd_cycles = kern_ms * 1e-3 * pmc["clock_ghz"] * 1e9 * N_SIMD
+            out["issue_roofline"] = {"bound": "valu-issue", "unit": "SIMD issue cycles per launch",
+                                     "achieved": pmc["valu_cycles_ideal_per_pairing"] * n, "peak": simd_cycles,
+                                     "frac": pmc["valu_cycles_ideal_per_pairing"] * n / simd_cycles,
+                                     "frac_vs_measured_issue_rates": pmc["valu_cycles_ubench_per_pairing"] * n / simd_cycles,
+                                     "valu_instr_per_pairing": pmc["valu_instr_per_pairing"], "mix": pmc.get("mix"),
+                                     "note": pmc.get("issue_note")}
         if aux:
             out["aux"] = aux
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(check)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

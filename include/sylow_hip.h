@@ -26,6 +26,10 @@
  *    The canonical affine encoding of the identity is (0, 1, inf=1) (groups/group.rs:271-277).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *    asynchronous on that stream; use sylow_hip_stream_sync or your own events.
+ *  - Threads: entry points may be called concurrently from several host threads and on several streams.  The
+ *    few calls that need device scratch (pairing_product*, fp12_product_final_exp, evm_ecpairing,
+ *    bls_verify_same_signer, *_all) lease a private block per call; blocks are recycled in stream order through
+ *    HIP events, never by synchronising a stored stream handle.
  *  - Return value: 0 on success, negative SYLOW_HIP_E_* otherwise.  No call throws or aborts.
  *    Per-element failures are reported through `status` byte arrays using codes that mirror
  *    sylow's GroupError (groups/group.rs:38-47).
@@ -54,6 +58,15 @@ extern "C" {
 
 /* ---- runtime ------------------------------------------------------------------------------ */
 int32_t sylow_hip_init(int32_t device);                 /* hipSetDevice + arch check (gfx950) */
+/* One process driving several GPUs: checks every listed device (gfx950) and makes device_ids[0] current.  All per-device
+ * state (scratch workspace, generator line tables) is created lazily on the device that is current when a call needs it. */
+int32_t sylow_hip_init_devices(const int32_t* device_ids, int32_t n_dev);
+/* Launches go to the CALLING THREAD's current HIP device.  Hosts that switch devices (or share the process with code that
+ * does) call this before a batch of entry points; pointers passed to a call must belong to that device. */
+int32_t sylow_hip_set_device(int32_t device);
+/* Frees every scratch block, completion event and generator table on every device (after a device synchronise).  The library
+ * stays usable: state is rebuilt on demand. */
+int32_t sylow_hip_shutdown(void);
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
 int32_t sylow_hip_malloc(void** dptr, size_t bytes);
@@ -61,6 +74,10 @@ int32_t sylow_hip_free(void* dptr);
 int32_t sylow_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int32_t sylow_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int32_t sylow_hip_stream_sync(void* stream);
+/* Synthetic inputs: n draws of the SplitMix64-seeded xoshiro256** stream, each 256 bits (four outputs, least-significant
+ * word first) masked to 254 bits and rejection-sampled to < p (Fp::rand's role for benches and tests).
+ * HOST function: out_host is a HOST array in the SoA layout [4][stride] (stride >= n). */
+int32_t sylow_hip_host_xoshiro_fp(uint64_t seed, uint64_t* out_host, size_t n, size_t stride);
 /* layout helpers for hosts that hold array-of-structs ([n][W], e.g. a Rust Vec<[u64; 4]>) */
 int32_t sylow_hip_aos_to_soa(const uint64_t* aos, uint64_t* soa, size_t words, size_t n, void* stream);
 int32_t sylow_hip_soa_to_aos(const uint64_t* soa, uint64_t* aos, size_t words, size_t n, void* stream);
@@ -80,6 +97,14 @@ int32_t sylow_hip_fp_pow_batch(const uint64_t* a, const uint64_t* e, uint64_t* o
 int32_t sylow_hip_fp_sqrt_batch(const uint64_t* a, uint64_t* out, uint8_t* is_some, size_t n, void* stream);
 /* Fp::is_square (fp.rs:625-631): 1 for squares and for 0 */
 int32_t sylow_hip_fp_is_square_batch(const uint64_t* a, uint8_t* flags, size_t n, void* stream);
+/* Fp::from_be_bytes / Fr::from_be_bytes (fp.rs:686-719, 746-778) = CtOption::new(Self::new(v), v < modulus) on 32 big-endian
+ * bytes per element, in [n][32]: out [4][n] receives the value (v mod modulus, like Self::new) and status[i] the flag --
+ * OK, or DECODE_ERROR where the reference's CtOption is none (v >= p resp. v >= r).  to_be_bytes (fp.rs:727-737) writes the
+ * canonical value, out [n][32]. */
+int32_t sylow_hip_fp_from_be_bytes_batch(const uint8_t* in, uint64_t* out, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_fr_from_be_bytes_batch(const uint8_t* in, uint64_t* out, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_fp_to_be_bytes_batch(const uint64_t* a, uint8_t* out, size_t n, void* stream);
+int32_t sylow_hip_fr_to_be_bytes_batch(const uint64_t* a, uint8_t* out, size_t n, void* stream);
 
 /* ---- Fr, the r-torsion scalar field (fields/fp.rs:556-565: the same macro-generated API as Fp, modulus r) -----------
  * Same contract as the Fp calls: [4][n] canonical limbs in and out, any 256-bit input accepted like Fr::new,
@@ -180,6 +205,25 @@ int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* 
 int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                         size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream);
 
+/* The same loops against line tables a host CACHED from sylow_hip_g2_precompute_batch (`G2PreComputed`, pairing.rs:556):
+ * G2PreComputed::miller_loop(&G1Affine) (pairing.rs:590-619) and glued_miller_loop(&[G2PreComputed], &[G1Affine])
+ * (pairing.rs:970-1022).  coeffs is the canonical SoA array [87*24][n_tables] exactly as g2_precompute_batch wrote it; pair i
+ * uses table table_idx[i] (uint64 device array), or table i when table_idx is NULL (then n_tables must equal the number of
+ * pairs) -- so one cached key serves any number of G1 points.  Raw MillerLoopResult out, no identity handling (as the
+ * reference).  The glued form takes the job layout of multi_pairing_batch; an empty job yields 1. */
+int32_t sylow_hip_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,
+                                                uint64_t* f_out, size_t n, void* stream);
+int32_t sylow_hip_glued_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,
+                                                      const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, uint64_t* f_out, void* stream);
+/* The two halves of pairing_product_batch, for hosts that split one product over several GPUs:
+ * partial: f_out [48][1] = prod_i miller(P_i, Q_i) of this shard, the raw MillerLoopResult (no final exponentiation;
+ *          n_pairs = 0 gives 1);
+ * final:   gt_out [48][1] = final_exponentiation(prod_{j<k} parts_j), parts SoA [48][k]; is_one[0] = (== Gt::identity()).
+ * glued_pairing over all shards == fp12_product_final_exp over the shards' partials (Fp12 products commute). */
+int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                                size_t n_pairs, int32_t skip_infinity, uint64_t* f_out, void* stream);
+int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64_t* gt_out, uint8_t* is_one, void* stream);
+
 /* ---- hash-to-curve and BLS: src/hasher.rs, src/svdw.rs, src/groups/g1.rs:307-331, src/lib.rs --- */
 /* Expander::hash_to_field(msg, 2, 48) with XMDExpander<Keccak256>(dst, 128) (hasher.rs:84-128, 157-250): out_u [8][n] = (u0, u1),
  * each the 48-byte big-endian slice of expand_message_xmd(msg, DST', 96) reduced mod p.  dst_host NULL = the library DST. */
@@ -233,12 +277,40 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
  * loops contain no G2 arithmetic. */
 int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* The same check against a key table the host keeps across calls ("G2PreComputed cached per pk"): sylow_hip_g2_line_table
+ * writes the line table of element idx of an SoA G2 array (n = its stride) into `table`, a device buffer of
+ * sylow_hip_g2_line_table_words() int32 words (opaque, device-internal digit layout); bls_verify_line_table_batch then runs
+ * the same-signer check with no G2 arithmetic and nothing rebuilt per call.  pk_inf: one device byte or NULL. */
+int32_t sylow_hip_g2_line_table_words(void);
+int32_t sylow_hip_g2_line_table(const uint64_t* q_xy, size_t n, size_t idx, int32_t* table, void* stream);
+int32_t sylow_hip_bls_verify_line_table_batch(const int32_t* pk_table, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                              const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
 /* G2Affine::precompute (pairing.rs:676-708): the 87 line-coefficient triples [Ell; 87] of each point, canonical
  * words, SoA [87*24][n] (triple t = words 24t..24t+23 = ell.0, ell.1, ell.2 as Fp2).  Strict replay. */
 int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream);
 /* AND of a flag array -> one int32 on the device (1 = all set); the multi-GPU aggregate then
  * MIN-reduces that word over ranks (RCCL has no bit-AND; min over {0,1} is AND). */
 int32_t sylow_hip_flags_all(const uint8_t* flags, size_t n, int32_t* out_dev, void* stream);
+
+
+/* ---- multi-GPU aggregates (one process per GPU): the only exchange steps of the path --------------------------------------
+ * `comm` is the caller's RCCL communicator (ncclComm_t) passed as void*; NULL means a single rank.  RCCL is bound at run time
+ * (dlopen of librccl.so.1), so single-GPU hosts never load it.  Both calls are asynchronous on `stream` and must be issued by
+ * every rank of the communicator, like any collective.
+ * all_valid: out_dev[0] (device int32) = 1 iff every flag on EVERY rank is set -- flags_all + a 4-byte MIN all-reduce
+ *            (verify(...) over a sharded batch -> one boolean, lib.rs:223-236).
+ * pairing_product_all: glued_pairing (pairing.rs:1029-1037) over the union of all ranks' pairs: every rank computes its
+ *            partial Miller product, the 384-byte partials are all-gathered and each rank finishes product + final
+ *            exponentiation, so every rank ends with the same gt_out [48][1] / is_one[0]. */
+int32_t sylow_hip_all_valid(const uint8_t* flags, size_t n, void* comm, int32_t* out_dev, void* stream);
+int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, size_t n_pairs,
+                                      int32_t skip_infinity, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream);
+
+/* ---- test hooks (stable enough for the repo's own tests; not part of the drop-in surface) ------------------------------------
+ * Granger-Scott cyclotomic square (pairing.rs:309-350) and the raw Fp12 selector: 0..7 single-lane tower ops, 8 / 9 product /
+ * cyclotomic square on the carry-free core, 10 / 11 exp_by_neg_z (carry-free / saturated), 16..28 the lane-pair Fp12 layer. */
+int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,9 @@ c_vp = ctypes.c_void_p
 # name -> argtypes (restype is int32 unless listed in _RESTYPE)
 SIGNATURES = {
     "sylow_hip_init": [c_i32],
+    "sylow_hip_init_devices": [ctypes.POINTER(c_i32), c_i32],
+    "sylow_hip_set_device": [c_i32],
+    "sylow_hip_shutdown": [],
     "sylow_hip_last_error": [],
     "sylow_hip_device_count": [],
     "sylow_hip_malloc": [ctypes.POINTER(c_vp), c_sz],
@@ -29,6 +32,7 @@ SIGNATURES = {
     "sylow_hip_memcpy_h2d": [c_vp, c_vp, c_sz, c_vp],
     "sylow_hip_memcpy_d2h": [c_vp, c_vp, c_sz, c_vp],
     "sylow_hip_stream_sync": [c_vp],
+    "sylow_hip_host_xoshiro_fp": [ctypes.c_uint64, c_vp, c_sz, c_sz],
     "sylow_hip_aos_to_soa": [c_u64p, c_u64p, c_sz, c_sz, c_vp],
     "sylow_hip_soa_to_aos": [c_u64p, c_u64p, c_sz, c_sz, c_vp],
     "sylow_hip_fp_add_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
@@ -91,6 +95,21 @@ SIGNATURES = {
     "sylow_hip_g1_double_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_double_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_flags_all": [c_u8p, c_sz, c_vp, c_vp],
+    "sylow_hip_fp_from_be_bytes_batch": [c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_fr_from_be_bytes_batch": [c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_fp_to_be_bytes_batch": [c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_fr_to_be_bytes_batch": [c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_miller_loop_precomputed_batch": [c_u64p, c_sz, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_glued_miller_loop_precomputed_batch": [c_u64p, c_sz, c_u64p, c_u64p, c_u64p, c_sz, c_sz, c_u64p, c_vp],
+    "sylow_hip_pairing_product_partial_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_i32, c_u64p, c_vp],
+    "sylow_hip_fp12_product_final_exp": [c_u64p, c_sz, c_u64p, c_u8p, c_vp],
+    "sylow_hip_g2_line_table_words": [],
+    "sylow_hip_g2_line_table": [c_u64p, c_sz, c_sz, c_vp, c_vp],
+    "sylow_hip_bls_verify_line_table_batch": [c_vp, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
+    "sylow_hip_all_valid": [c_u8p, c_sz, c_vp, c_vp, c_vp],
+    "sylow_hip_pairing_product_all": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_i32, c_vp, c_u64p, c_u8p, c_vp],
+    "sylow_hip_fp12_cyclotomic_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp12_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
 }
 _RESTYPE = {"sylow_hip_last_error": ctypes.c_char_p}
 

@@ -1,0 +1,89 @@
+// common.hpp -- device-side helpers shared by every translation unit of libsylow_hip.so: struct-of-arrays load / store,
+// launch geometry, byte codecs for 32-byte big-endian field elements.  gfx950 only.
+#pragma once
+#include "../../include/sylow_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include "bn254_hash.hpp"
+#include "bn254_fr.hpp"
+
+using namespace bn254;
+
+// ------------------------------------------------------------------ SoA load / store ----------
+// word w of element i lives at base[w * n + i]: a wavefront reads 64 consecutive uint64 (512 B)
+// per word -> fully coalesced, and the 4 words of an Fp are 4 independent loads in flight.
+BN_DEV Fp load_plain(const u64* __restrict__ base, size_t n, size_t i, int w0) {
+  Fp r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    u64 w = base[(size_t)(w0 + k) * n + i];
+    r.v[2 * k] = (u32)w;
+    r.v[2 * k + 1] = (u32)(w >> 32);
+  }
+  return r;
+}
+BN_DEV void store_plain(u64* __restrict__ base, size_t n, size_t i, int w0, const Fp& a) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) base[(size_t)(w0 + k) * n + i] = (u64)a.v[2 * k] | ((u64)a.v[2 * k + 1] << 32);
+}
+BN_DEV Fp load_fp(const u64* base, size_t n, size_t i, int w0) { return fp_to_mont(load_plain(base, n, i, w0)); }
+BN_DEV void store_fp(u64* base, size_t n, size_t i, int w0, const Fp& a) { store_plain(base, n, i, w0, fp_from_mont(a)); }
+BN_DEV Fp2 load_fp2(const u64* base, size_t n, size_t i, int w0) { return Fp2{load_fp(base, n, i, w0), load_fp(base, n, i, w0 + 4)}; }
+BN_DEV void store_fp2(u64* base, size_t n, size_t i, int w0, const Fp2& a) { store_fp(base, n, i, w0, a.c0); store_fp(base, n, i, w0 + 4, a.c1); }
+BN_DEV void load_fp6(Fp6& r, const u64* base, size_t n, size_t i, int w0) {
+  r.c0 = load_fp2(base, n, i, w0); r.c1 = load_fp2(base, n, i, w0 + 8); r.c2 = load_fp2(base, n, i, w0 + 16);
+}
+BN_DEV void store_fp6(u64* base, size_t n, size_t i, int w0, const Fp6& a) {
+  store_fp2(base, n, i, w0, a.c0); store_fp2(base, n, i, w0 + 8, a.c1); store_fp2(base, n, i, w0 + 16, a.c2);
+}
+BN_DEV void load_fp12(Fp12& r, const u64* base, size_t n, size_t i) { load_fp6(r.c0, base, n, i, 0); load_fp6(r.c1, base, n, i, 24); }
+BN_DEV void store_fp12(u64* base, size_t n, size_t i, const Fp12& a) { store_fp6(base, n, i, 0, a.c0); store_fp6(base, n, i, 24, a.c1); }
+
+#define TID ((size_t)blockIdx.x * blockDim.x + threadIdx.x)
+constexpr int BLOCK = 256;
+// the heavy kernels keep an Fp12 working set per lane: ask for 2 waves per SIMD (<= 256 VGPRs),
+// the occupancy at which v_mad_u64_u32 already reaches its peak issue rate (profiles/r01_issue_rate_ubench.txt)
+#define HEAVY_BOUNDS __launch_bounds__(BLOCK, 2)
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
+
+// ------------------------------------------------------------------ group kernels --------------
+BN_DEV void load_scalar(u32 (&k)[8], const u64* base, size_t n, size_t i) {
+  // scalars are Fp values: reduce like Fp::new so that k >= p behaves as in the reference
+  Fp s = fp_from_mont(fp_to_mont(load_plain(base, n, i, 0)));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = s.v[j];
+}
+
+BN_DEV int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(v, off); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// ---- 32-byte big-endian field elements (Fp::from_be_bytes / to_be_bytes, fp.rs:686-737) ----------
+BN_DEV bool read_be_fp(Fp& out, const uint8_t* b) {         // returns false when the value is >= p
+  Fp x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = b + 28 - 4 * j;
+    x.v[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+  }
+  const u32 pl[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    if (!decided && x.v[j] != pl[j]) { lt = x.v[j] < pl[j]; decided = true; }
+  }
+  out = x;
+  return lt;
+}
+BN_DEV void write_be_fp(uint8_t* b, const Fp& plain) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32 w = plain.v[j];
+    uint8_t* q = b + 28 - 4 * j;
+    q[0] = (uint8_t)(w >> 24); q[1] = (uint8_t)(w >> 16); q[2] = (uint8_t)(w >> 8); q[3] = (uint8_t)w;
+  }
+}

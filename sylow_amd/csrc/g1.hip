@@ -1,0 +1,261 @@
+// g1.hip -- one-element-per-lane G1 kernels: group law, scalar multiplication (GLV, carry-free core), weighted aggregation,
+// hash-to-G1 (XMD-Keccak256 + SvdW), BLS signing, the G1 wire format and the EIP-196 ecAdd / ecMul byte adapters.
+#include "host.hpp"
+
+__global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool inf = pinf && pinf[i];
+  G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), inf ? fp_zero() : fp_one()};
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G1P r = g1_scalar_mul(p, k);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P b{load_fp(bxy, n, i, 0), load_fp(bxy, n, i, 4), (binf && binf[i]) ? fp_zero() : fp_one()};
+  G1P r = g1_add(a, b);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+// out_j = sum_i k_{j,i} * P_{j,i}: the aggregation loop of examples/threshold_signing.rs:124-143 (Lagrange-weighted partial
+// signatures), one job per lane, terms walked in order with the reference's own scalar multiplication and complete addition.
+// Term-major layout: element (job j, term i) lives at index i * n_jobs + j, so a wave reads consecutive addresses.
+__global__ void HEAVY_BOUNDS k_g1_lincomb(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n_jobs, size_t n_terms) {
+  size_t j = TID;
+  if (j >= n_jobs) return;
+  const size_t n = n_jobs * n_terms;
+  G1P acc{fp_zero(), fp_one(), fp_zero()};               // G1Projective::default() = identity
+#pragma unroll 1
+  for (size_t t = 0; t < n_terms; ++t) {
+    const size_t i = t * n_jobs + j;
+    G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), (pinf && pinf[i]) ? fp_zero() : fp_one()};
+    u32 k[8];
+    load_scalar(k, ks, n, i);
+    acc = g1_add(acc, g1_scalar_mul(p, k));
+  }
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, acc);
+  store_fp(oxy, n_jobs, j, 0, x); store_fp(oxy, n_jobs, j, 4, y);
+  oinf[j] = rinf ? 1 : 0;
+}
+// G1Affine::new (g1.rs:111-132): y^2 - x^3 == 3, the identity flag passes
+__global__ void __launch_bounds__(BLOCK) k_g1_on_curve(const u64* pxy, const uint8_t* pinf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const bool ok = (pinf && pinf[i]) || g1_on_curve_affine(load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4));
+  status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P p{load_fp(pxyz, n, i, 0), load_fp(pxyz, n, i, 4), load_fp(pxyz, n, i, 8)};
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, p);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ hash / BLS kernels ----------
+__global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  bool ok = hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, h);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = inf ? 1 : 0;
+  if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
+}
+// Expander::hash_to_field(msg, 2, 48) (hasher.rs:84-128) over XMDExpander<Keccak256>::expand_message (hasher.rs:201-250)
+__global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, const u64* off, DstPrime dp, u64* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  uint8_t em[96];
+  expand_message_xmd96(em, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  store_fp(out, n, i, 0, fp_from_be48(em));
+  store_fp(out, n, i, 4, fp_from_be48(em + 48));
+}
+// lib.rs:179-187
+__global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P h;
+  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  u32 k[8];
+  load_scalar(k, sk, n, i);
+  G1P s = g1_scalar_mul(h, k);
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, s);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = inf ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ EVM alt_bn128 adapter -------
+// Byte-level batches of the three precompile shapes of examples/reth_bn128.rs:99-217 (EIP-196/197):
+// 32-byte big-endian field elements (Fp::from_be_bytes rejects >= p, fp.rs:686-719), (0,0) encodes the
+// identity, G1 points must be on the curve (G1Affine::new, g1.rs:111-132), G2 points on the twist AND in
+// the r-torsion (G2Projective::new, g2.rs:460-525); G2 is encoded x.c1 | x.c0 | y.c1 | y.c0.
+// status: OK, DECODE_ERROR (= Bn128FieldPointNotAMember), NOT_ON_CURVE / NOT_IN_SUBGROUP (= Bn128AffineGFailedToCreate).
+// read_point + new_g1_point (reth_bn128.rs:107-128): Montgomery-form affine point or identity
+BN_DEV uint8_t evm_read_g1(G1P& out, const uint8_t* b) {
+  Fp x, y;
+  bool okx = read_be_fp(x, b), oky = read_be_fp(y, b + 32);
+  if (!(okx && oky)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_DECODE_ERROR; }
+  if (fp_is_zero(x) && fp_is_zero(y)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_OK; }
+  Fp xm = fp_to_mont(x), ym = fp_to_mont(y);
+  out = G1P{xm, ym, fp_one()};
+  return g1_on_curve_affine(xm, ym) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
+// to_be_bytes_scrubbed (g1.rs:182-192): all-zero bytes for the identity
+BN_DEV void evm_write_g1(uint8_t* b, const G1P& p) {
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, p);
+  Fp zero = fp_zero();
+  write_be_fp(b, inf ? zero : fp_from_mont(x));
+  write_be_fp(b + 32, inf ? zero : fp_from_mont(y));
+}
+__global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a, b;
+  uint8_t sa = evm_read_g1(a, in + 128 * i), sb = evm_read_g1(b, in + 128 * i + 64);
+  uint8_t st = sa ? sa : sb;
+  status[i] = st;
+  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  evm_write_g1(out + 64 * i, g1_add(a, b));
+}
+__global__ void HEAVY_BOUNDS k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a;
+  uint8_t st = evm_read_g1(a, in + 96 * i);
+  status[i] = st;
+  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  Fp kx;
+  read_be_fp(kx, in + 96 * i + 64);
+  // EIP-196 accepts any 256-bit scalar; G1 has prime order r, so reduce mod r (2^256 < 6r).  (The reference
+  // adapter unwraps Fr::from_be_bytes and would panic for k >= r, reth_bn128.rs:144.)
+  u32 k[8] = {kx.v[0], kx.v[1], kx.v[2], kx.v[3], kx.v[4], kx.v[5], kx.v[6], kx.v[7]};
+  cond_sub_const(k, 0xc0000004u, 0x0f87d64fu, 0xe6e5c245u, 0xa0cfa121u, 0x06056174u, 0xe14116dau, 0x84c680a6u, 0xc19139cbu);  // 4r
+  cond_sub_const(k, 0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2r
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);  // r
+  evm_write_g1(out + 64 * i, g1_scalar_mul(a, k));
+}
+
+// ------------------------------------------------------------------ wire formats -----------------
+// G1Affine::to_be_bytes / from_be_bytes (g1.rs:151-280): x | y big-endian, bit 7 of byte 0 = infinity flag,
+// identity encoded as (0, 1) + flag; decoding masks the flag, rejects coordinates >= p (DECODE_ERROR),
+// a set flag with (x, y) != (0, 1) (DECODE_ERROR) and off-curve points (NOT_ON_CURVE).
+// G2: x.c1 | x.c0 | y.c1 | y.c0 (g2.rs:319-433); decoding also runs the subgroup check of G2Projective::new.
+__global__ void __launch_bounds__(BLOCK) k_g1_to_bytes(const u64* xy, const uint8_t* inf, uint8_t* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool z = inf && inf[i];
+  Fp x = z ? fp_zero() : fp_reduce_plain(load_plain(xy, n, i, 0));
+  Fp y = z ? fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0) : fp_reduce_plain(load_plain(xy, n, i, 4));
+  write_be_fp(out + 64 * i, x);
+  write_be_fp(out + 64 * i + 32, y);
+  if (z) out[64 * i] |= 0x80;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  uint8_t b[64];
+  for (int k = 0; k < 64; ++k) b[k] = in[64 * i + k];
+  bool flag = (b[0] >> 7) & 1;
+  b[0] &= 0x7f;
+  Fp x, y;
+  bool ok = read_be_fp(x, b);
+  ok = read_be_fp(y, b + 32) && ok;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool is01 = fp_is_zero(x) && fp_eq(y, fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0));
+  if (!ok) st = SYLOW_HIP_ST_DECODE_ERROR;
+  else if (flag) st = is01 ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_DECODE_ERROR;
+  else if (!g1_on_curve_affine(fp_to_mont(x), fp_to_mont(y))) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+  bool z = flag || st != SYLOW_HIP_ST_OK;
+  store_plain(xy, n, i, 0, z ? fp_zero() : x);
+  store_plain(xy, n, i, 4, z ? fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0) : y);
+  inf[i] = z ? 1 : 0;
+  status[i] = st;
+}
+
+// GroupProjective::double (group.rs:339-386) on affine inputs
+__global__ void __launch_bounds__(BLOCK) k_g1_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P r = g1_double(a);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+
+// ================================================================== C ABI ======================
+extern "C" {
+int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_lincomb_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n_jobs, size_t n_terms, void* stream) {
+  ARGCHK(out_xy && out_inf && (n_terms == 0 || (p_xy && k))); if (!n_jobs) return SYLOW_HIP_OK;
+  k_g1_lincomb<<<GRID(n_jobs)>>>(p_xy, p_inf, k, out_xy, out_inf, n_jobs, n_terms); LAUNCHED();
+}
+int32_t sylow_hip_g1_on_curve_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(p_xy && status); if (!n) return SYLOW_HIP_OK; k_g1_on_curve<<<GRID(n)>>>(p_xy, p_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                   uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n); LAUNCHED();
+}
+int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
+                                      uint64_t* out_u, size_t n, void* stream) {
+  ARGCHK(msgs && msg_offsets && out_u); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
+  k_hash_to_field<<<GRID(n)>>>(msgs, msg_offsets, dp, out_u, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                 uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
+  ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;
+  k_evm_ecadd<<<GRID(n)>>>(in, out, status, n); LAUNCHED();
+}
+int32_t sylow_hip_evm_ecmul_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;
+  k_evm_ecmul<<<GRID(n)>>>(in, out, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {
+  ARGCHK(p_xy && out); if (!n) return SYLOW_HIP_OK; k_g1_to_bytes<<<GRID(n)>>>(p_xy, p_inf, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g1_from_bytes<<<GRID(n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK; k_g1_double<<<GRID(n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
+}
+
+}  // extern "C"

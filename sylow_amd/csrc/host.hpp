@@ -1,0 +1,69 @@
+// host.hpp -- host-side plumbing shared by the translation units of libsylow_hip.so: error reporting, launch macros,
+// the per-(device, stream) scratch workspace, the per-device G2-generator line tables, and the launchers each unit exports
+// to the others.  Every unit compiles its own kernels (no relocatable device code): a kernel and the host function that
+// launches it always live in the same .hip file.
+#pragma once
+#include "common.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+extern thread_local char sylow_g_err[256];
+namespace host {
+int32_t fail(hipError_t e, const char* what);
+// SYLOW_HIP_SINGLE_LANE=1 selects the one-element-per-lane kernels (single.hip): the slower twin kept for A/B measurements and
+// as a second implementation for the parity tests.
+bool single_lane();
+
+// Scratch workspace (runtime.hip).  A Lease hands out one device block for the duration of ONE entry-point call: blocks are
+// keyed per device, a block whose previous user ran on the same stream is reused in stream order, a block last used on another
+// stream is reused only after that stream's completion event (the new stream waits on the event; no stored stream handle is
+// ever dereferenced), and two host threads never hold the same block.  release() records the completion event.
+struct Lease {
+  void* p = nullptr;
+  int dev = -1, slot = -1;
+  hipStream_t st = nullptr;
+  int32_t acquire(size_t bytes, hipStream_t stream);
+  int32_t release();                 // records the block's completion event on the stream; idempotent
+  ~Lease() { release(); }
+};
+// per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
+int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair layout [87][3][2][9] int32
+int32_t gen_lines_sat(const u32** out, hipStream_t st);         // single-lane Montgomery layout [87][48] uint32
+void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
+}  // namespace host
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return host::fail(e_, #x); } while (0)
+#define ARGCHK(c) do { if (!(c)) { snprintf(sylow_g_err, sizeof(sylow_g_err), "bad argument: %s", #c); return SYLOW_HIP_E_ARG; } } while (0)
+#define GRID(n) dim3((unsigned)(((n) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream
+#define LAUNCH_RC() (hipGetLastError() == hipSuccess ? SYLOW_HIP_OK : host::fail(hipErrorLaunchFailure, "kernel launch"))
+#define LAUNCHED() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return host::fail(e_, "kernel launch"); return SYLOW_HIP_OK; } while (0)
+
+// ---- launchers exported between units (argument lists as the C entry points of include/sylow_hip.h) ----------------------
+namespace single {      // single.hip: one element per lane
+int32_t g2_scalar_mul(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t g2_normalize(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t g2_subgroup_check(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream);
+int32_t g2_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t g2_double(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t miller_loop(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
+int32_t final_exp(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
+int32_t pairing(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream);
+int32_t multi_pairing(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
+                      size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream);
+int32_t gt_pow(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream);
+int32_t bls_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+int32_t bls_verify_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+int32_t bls_verify_same_signer(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                               const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+int32_t build_gen_lines(u32* table, void* stream);              // k_g2_lines on the generator
+int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);   // k_fp12_op selectors 0..11
+}  // namespace single
+namespace plkh {        // lane-pair units
+int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
+// plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
+int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
+}  // namespace plkh

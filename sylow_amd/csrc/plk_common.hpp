@@ -1,0 +1,29 @@
+// plk_common.hpp -- helpers shared by the LANE-PAIR kernel units (bn254_pair.hpp, bn254_pair29.hpp).
+// Thread t handles coordinate (t & 1) of element t >> 1, so a launch covers 2 n threads and a wavefront carries 32 elements.
+// Both lanes of a pair always take the same branches.
+#pragma once
+#include "host.hpp"
+#include "bn254_pair29.hpp"
+
+namespace plk {
+using namespace bn254;
+using namespace bn254::pl;
+
+BN_DEV S2 load_s2(const u64* base, size_t n, size_t i, int w0, int odd) { return S2{load_fp(base, n, i, w0 + 4 * odd)}; }
+BN_DEV void store_s2(u64* base, size_t n, size_t i, int w0, int odd, const S2& a) { store_fp(base, n, i, w0 + 4 * odd, a.c); }
+BN_DEV void load_s12(S12& r, const u64* base, size_t n, size_t i, int odd) {
+  r.c0.c0 = load_s2(base, n, i, 0, odd); r.c0.c1 = load_s2(base, n, i, 8, odd); r.c0.c2 = load_s2(base, n, i, 16, odd);
+  r.c1.c0 = load_s2(base, n, i, 24, odd); r.c1.c1 = load_s2(base, n, i, 32, odd); r.c1.c2 = load_s2(base, n, i, 40, odd);
+}
+BN_DEV void store_s12(u64* base, size_t n, size_t i, int odd, const S12& a) {
+  store_s2(base, n, i, 0, odd, a.c0.c0); store_s2(base, n, i, 8, odd, a.c0.c1); store_s2(base, n, i, 16, odd, a.c0.c2);
+  store_s2(base, n, i, 24, odd, a.c1.c0); store_s2(base, n, i, 32, odd, a.c1.c1); store_s2(base, n, i, 40, odd, a.c1.c2);
+}
+BN_DEV S2 s2_g2gen_x() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1]))}; }
+BN_DEV S2 s2_g2gen_y() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3]))}; }
+BN_DEV W2 w2_select(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }     // c ? b : a
+
+
+// [87][3 coefficients][2 coordinates][9 limbs] int32, R-class: G2Affine::precompute (pairing.rs:676-708) of one point
+constexpr int LINE_TABLE_WORDS = 87 * 54;
+}  // namespace plk

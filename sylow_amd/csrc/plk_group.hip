@@ -1,0 +1,321 @@
+// plk_group.hip -- the G2 side on lane pairs: group law, scalar multiplication, subgroup check, endomorphism, the G2 wire format,
+// EIP-197 pair decoding, and Gt * Fr.
+#include "plk_common.hpp"
+
+namespace plk {
+// ------------------------------------------------------------------ G2 group law on lane pairs -------------------------------
+// The complete RCB'15 formulas of bn254_pairing.hpp (proj_double / proj_add, generic over the coordinate field like
+// group.rs) instantiated over the lane-pair Fp2 on the carry-free core: a projective G2 point is 27 VGPRs per lane.
+// Class invariant and value bounds as for OpsF29 (bn254_pairing.hpp): coordinates N-class, additions carry-normalised,
+// products |V| < 2 VaVb/169 + 1; with inputs |V| <= 7 proj_double returns |V| <= 2.3, proj_add (inputs <= 2.3) <= 2.3.
+struct OpsW2 {
+  typedef W2 F;
+  static BN_DEV F add(const F& a, const F& b) { return w2_norm(w2_add(a, b)); }
+  static BN_DEV F sub(const F& a, const F& b) { return w2_norm(w2_sub(a, b)); }
+  static BN_DEV F neg(const F& a) { return w2_norm(w2_neg(a)); }
+  static BN_DEV F mul(const F& a, const F& b) { return w2_mul(a, b); }
+  static BN_DEV F zero() { return W2{OpsF29::zero()}; }
+  static BN_DEV F one() { return W2{sel9(lane_odd(), OpsF29::one(), OpsF29::zero())}; }
+  static BN_DEV bool is_zero(const F& a) { return s2_is_zero(w2_to_s2(a)); }
+  static BN_DEV F select(const F& a, const F& b, bool c) { return w2_select(a, b, c); }
+  static BN_DEV F mul_b3(const F& a) { return w2_mul(a, w2_const(C_TWIST_B3)); }
+};
+typedef Proj<W2> G2Q;
+BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
+BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
+BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64) {
+  out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
+                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin);
+}
+// group.rs:475-495 (through the saturated core: one Fp2 inversion)
+BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
+  const S2 zi = s2_inv(w2_to_s2(p.z));
+  inf = s2_is_zero(zi);
+  x = s2_select(s2_mul(w2_to_s2(p.x), zi), s2_zero(), inf);
+  y = s2_select(s2_mul(w2_to_s2(p.y), zi), s2_one(), inf);
+}
+BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-297
+  return s2_eq(s2_sub(s2_sqr(y), s2_mul(s2_sqr(x), x)), s2_const(C_TWIST_B));
+}
+// g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
+BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
+  const G2Q q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()};
+  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
+  G2Q a;
+  g2q_scalar_mul(a, q, bx, 17);                   // x < 2^63: 16 digits + the recoding carry
+  // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
+  const W2 e0 = w2_const(C_EPS_EXP0), e1 = w2_const(C_EPS_EXP1);
+  auto psi = [&](G2Q& r, const G2Q& p) {
+    r.x = w2_mul(e0, w2_conj(p.x));
+    r.y = w2_mul(e1, w2_conj(p.y));
+    r.z = w2_conj(p.z);
+  };
+  G2Q b, c, l, r;
+  psi(b, a);
+  g2q_add(a, a, q);
+  psi(c, b);
+  g2q_add(l, c, b);
+  g2q_add(l, l, a);
+  psi(r, c);
+  g2q_double(r, r);
+  const G2Q nl = proj_neg<OpsW2>(l);
+  g2q_add(r, r, nl);
+  return OpsW2::is_zero(r.z);
+}
+BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
+  return G2Q{w2_from_s2(load_s2(xy, n, i, 0, odd)), w2_from_s2(load_s2(xy, n, i, 8, odd)), (inf && inf[i]) ? OpsW2::zero() : OpsW2::one()};
+}
+BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {
+  S2 x, y; bool rinf;
+  g2q_to_affine(x, y, rinf, r);
+  store_s2(oxy, n, i, 0, odd, x); store_s2(oxy, n, i, 8, odd, y);
+  if (!odd) oinf[i] = rinf ? 1 : 0;
+}
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G2Q r;
+  g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k);
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  G2Q r;
+  g2q_add(r, load_g2q(axy, ainf, n, i, odd), load_g2q(bxy, binf, n, i, odd));
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  G2Q r;
+  g2q_double(r, load_g2q(axy, ainf, n, i, odd));
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+__global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const G2Q p{w2_from_s2(load_s2(pxyz, n, i, 0, odd)), w2_from_s2(load_s2(pxyz, n, i, 8, odd)), w2_from_s2(load_s2(pxyz, n, i, 16, odd))};
+  store_g2q_affine(oxy, oinf, n, i, odd, p);
+}
+// G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (eps0 conj x, eps1 conj y), psi(identity) = identity; status reports the
+// on-curve re-check the reference performs on the result (it panics there; here NOT_ON_CURVE)
+__global__ void __launch_bounds__(BLOCK) k_g2_psi(const u64* qxy, const uint8_t* qinf, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const bool inf = qinf && qinf[i];
+  S2 x = load_s2(qxy, n, i, 0, odd), y = load_s2(qxy, n, i, 8, odd), px, py;
+  g2_psi_affine(px, py, x, y);
+  const bool on = inf || g2q_on_curve_affine(px, py);
+  store_s2(oxy, n, i, 0, odd, inf ? x : px);
+  store_s2(oxy, n, i, 8, odd, inf ? y : py);
+  if (!odd) { oinf[i] = inf ? 1 : 0; if (status) status[i] = on ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE; }
+}
+// g2.rs:460-525 on an affine input
+__global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* qinf, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  if (!(qinf && qinf[i])) {                       // Z == 0 passes both tests (g2.rs:469,510)
+    const S2 x = load_s2(qxy, n, i, 0, odd), y = load_s2(qxy, n, i, 8, odd);
+    if (!g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    else if (!g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+  }
+  if (!odd) status[i] = st;
+}
+
+// ------------------------------------------------------------------ Gt * Fr ---------------------------------------------------
+// Mul<&Fr> for &Gt (gt.rs:161-187): the reference's 256-step signed-digit square-and-multiply on generic Fp12 squares and
+// products (exact for any input), negative digits multiply by the conjugate.  Wave-uniform: every step squares; a step
+// multiplies when any lane of the wavefront has a non-zero digit, lanes with a zero digit multiply by one.
+__global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = i < n;
+  const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
+  S12 sa;
+  load_s12(sa, g, n, ii, odd);
+  W12 a, na, one, res;
+  w12_from_s12(a, sa);
+  na = w12_conj(a);
+  {
+    S12 so = s12_one();
+    w12_from_s12(one, so);
+  }
+  res = one;
+  // digits of fp.rs:653-662 on the raw 256-bit scalar
+  u32 k[8], xh[8], x3[8], np[8], nm[8];
+  {
+    const Fp kp = load_plain(ks, n, ii, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = kp.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xh[j] = (k[j] >> 1) | (j < 7 ? (k[j + 1] << 31) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
+#pragma unroll 1
+  for (int b = 255; b >= 0; --b) {
+    res = w12_sqr(res);
+    const bool bp = (np[b >> 5] >> (b & 31)) & 1, bm = (nm[b >> 5] >> (b & 31)) & 1;
+    if (__any(bp || bm)) {
+      W12 m;
+      W2* mc[6] = {&m.c0.c0, &m.c0.c1, &m.c0.c2, &m.c1.c0, &m.c1.c1, &m.c1.c2};
+      const W2* ac[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+      const W2* nc[6] = {&na.c0.c0, &na.c0.c1, &na.c0.c2, &na.c1.c0, &na.c1.c1, &na.c1.c2};
+      const W2* oc[6] = {&one.c0.c0, &one.c0.c1, &one.c0.c2, &one.c1.c0, &one.c1.c1, &one.c1.c2};
+#pragma unroll
+      for (int q = 0; q < 6; ++q) *mc[q] = w2_select(w2_select(*oc[q], *nc[q], bm), *ac[q], bp);
+      w12_mul_nl(res, res, m);
+    }
+  }
+  S12 sr;
+  w12_to_s12(sr, res);
+  if (active) store_s12(out, n, i, odd, sr);
+}
+}  // namespace plk
+
+// one LANE PAIR per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes.  Both lanes decode
+// the six field elements; the G2 checks (twist equation, subgroup) run on the lane-pair Fp2 (g2q_* above).
+__global__ void HEAVY_BOUNDS k_evm_decode_pairs(const uint8_t* in, size_t n_pairs, u64* pxy, uint8_t* pinf, u64* qxy, uint8_t* qinf, uint8_t* pst) {
+  const size_t t = TID, i = t >> 1;
+  const bool odd = (t & 1) != 0;
+  if (i >= n_pairs) return;
+  const uint8_t* b = in + 192 * i;
+  Fp f[6];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ok = read_be_fp(f[k], b + 32 * k) && ok;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool ainf = true, binf = true;
+  if (!ok) {
+    st = SYLOW_HIP_ST_DECODE_ERROR;
+  } else {
+    ainf = fp_is_zero(f[0]) && fp_is_zero(f[1]);
+    if (!ainf && !g1_on_curve_affine(fp_to_mont(f[0]), fp_to_mont(f[1]))) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    binf = fp_is_zero(f[2]) && fp_is_zero(f[3]) && fp_is_zero(f[4]) && fp_is_zero(f[5]);
+    if (!st && !binf) {
+      // (bax, bay), (bbx, bby): x = f[3] + f[2] u, y = f[5] + f[4] u; this lane's coordinate
+      const pl::S2 x{fp_to_mont(pl::sel(odd, f[3], f[2]))}, y{fp_to_mont(pl::sel(odd, f[5], f[4]))};
+      if (!plk::g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+      else if (!plk::g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+    }
+  }
+  if (odd) return;
+  bool dead = st != SYLOW_HIP_ST_OK;
+  Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  // identities (and invalid pairs, whose job is rejected anyway) are stored in the canonical (0, 1) encoding
+  store_plain(pxy, n_pairs, i, 0, (ainf || dead) ? zero : f[0]);
+  store_plain(pxy, n_pairs, i, 4, (ainf || dead) ? one : f[1]);
+  store_plain(qxy, n_pairs, i, 0, (binf || dead) ? zero : f[3]);
+  store_plain(qxy, n_pairs, i, 4, (binf || dead) ? zero : f[2]);
+  store_plain(qxy, n_pairs, i, 8, (binf || dead) ? one : f[5]);
+  store_plain(qxy, n_pairs, i, 12, (binf || dead) ? zero : f[4]);
+  pinf[i] = (ainf || dead) ? 1 : 0;
+  qinf[i] = (binf || dead) ? 1 : 0;
+  pst[i] = st;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_g2_to_bytes(const u64* xy, const uint8_t* inf, uint8_t* out, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  bool z = inf && inf[i];
+  const Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  Fp xc0 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 0)), xc1 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 4));
+  Fp yc0 = z ? one : fp_reduce_plain(load_plain(xy, n, i, 8)), yc1 = z ? zero : fp_reduce_plain(load_plain(xy, n, i, 12));
+  uint8_t* o = out + 128 * i;
+  write_be_fp(o, xc1); write_be_fp(o + 32, xc0); write_be_fp(o + 64, yc1); write_be_fp(o + 96, yc0);
+  if (z) o[0] |= 0x80;
+}
+// one LANE PAIR per 128-byte encoding (both lanes decode, the curve / subgroup checks run on the lane-pair Fp2)
+__global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const bool odd = (t & 1) != 0;
+  if (i >= n) return;
+  uint8_t b[128];
+  for (int k = 0; k < 128; ++k) b[k] = in[128 * i + k];
+  bool flag = (b[0] >> 7) & 1;
+  b[0] &= 0x7f;
+  Fp xc1, xc0, yc1, yc0;
+  bool ok = read_be_fp(xc1, b);
+  ok = read_be_fp(xc0, b + 32) && ok;
+  ok = read_be_fp(yc1, b + 64) && ok;
+  ok = read_be_fp(yc0, b + 96) && ok;
+  const Fp zero = fp_zero(), one = fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0);
+  uint8_t st = SYLOW_HIP_ST_OK;
+  bool is01 = fp_is_zero(xc0) && fp_is_zero(xc1) && fp_eq(yc0, one) && fp_is_zero(yc1);
+  if (!ok) st = SYLOW_HIP_ST_DECODE_ERROR;
+  else if (flag) st = is01 ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_DECODE_ERROR;
+  else {
+    const pl::S2 x{fp_to_mont(pl::sel(odd, xc0, xc1))}, y{fp_to_mont(pl::sel(odd, yc0, yc1))};
+    if (!plk::g2q_on_curve_affine(x, y)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+    else if (!plk::g2q_in_subgroup(x, y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+  }
+  if (odd) return;
+  bool z = flag || st != SYLOW_HIP_ST_OK;
+  store_plain(xy, n, i, 0, z ? zero : xc0); store_plain(xy, n, i, 4, z ? zero : xc1);
+  store_plain(xy, n, i, 8, z ? one : yc0); store_plain(xy, n, i, 12, z ? zero : yc1);
+  inf[i] = z ? 1 : 0;
+  status[i] = st;
+}
+
+namespace plkh {
+int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream) {
+  k_evm_decode_pairs<<<dim3((unsigned)((2 * n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
+  LAUNCHED();
+}
+}  // namespace plkh
+
+extern "C" {
+int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
+  plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_normalize(p_xyz, out_xy, out_inf, n, stream);
+  plk::k_g2_normalize<<<GRID(2 * n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(q_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  plk::k_g2_psi<<<GRID(2 * n)>>>(q_xy, q_inf, out_xy, out_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(q_xy && status); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_subgroup_check(q_xy, q_inf, status, n, stream);
+  plk::k_g2_subgroup_check<<<GRID(2 * n)>>>(q_xy, q_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {
+  ARGCHK(p_xy && out); if (!n) return SYLOW_HIP_OK; k_g2_to_bytes<<<GRID(n)>>>(p_xy, p_inf, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(in && out_xy && out_inf && status); if (!n) return SYLOW_HIP_OK; k_g2_from_bytes<<<GRID(2 * n)>>>(in, out_xy, out_inf, status, n); LAUNCHED();
+}
+int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::gt_pow(gt, k, out, n, stream);
+  plk::k_gt_pow<<<GRID(2 * n)>>>(gt, k, out, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_add(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n, stream);
+  plk::k_g2_add<<<GRID(2 * n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_double(a_xy, a_inf, out_xy, out_inf, n, stream);
+  plk::k_g2_double<<<GRID(2 * n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
+}
+}  // extern "C"

@@ -1,0 +1,370 @@
+// plk_multi.hip -- glued pairings on lane pairs: one product per job (ecPairing shape), raw glued Miller values, and the
+// batch-wide product (chunked Miller loops + a log-depth tree of Fp12 products + one final exponentiation).
+#include "plk_common.hpp"
+
+namespace plk {
+// ------------------------------------------------------------------ glued pairing ----------------------------------------
+// Same wave-uniform schedule as the single-lane k_multi_pairing (single.hip): chunks of KMAX pairs share the squarings of
+// one accumulator, a lane pair whose job has fewer pairs multiplies by the unit line.  Pair states live in the stack frame
+// (they are touched once per loop iteration); the accumulator and the working point stay in registers.
+struct PairStateW { G2W r; W2 qx, qy; S2 qxs, qys; F29 px, py; bool qinf, live; };
+constexpr int KMAXW = 4;        // ecPairing / glued jobs (a few pairs each)
+constexpr int KPROD = 8;        // batch-wide product: more pairs per shared squaring
+
+template <int KMAX>
+__global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                             const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
+                                             u64* gout, uint8_t* is_one, int raw_miller) {
+  const size_t t = TID, job = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
+  size_t next = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
+  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  const W2 twist_b = w2_const(C_TWIST_B);
+  W12 acc;
+  {
+    S12 one = s12_one();
+    w12_from_s12(acc, one);
+  }
+  PairStateW st[KMAX];
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  while (wave_max(next < hi ? 1 : 0)) {
+    int k = 0;
+#pragma unroll 1
+    for (int slot = 0; slot < KMAX; ++slot) {
+      bool have = false;
+      size_t idx = 0;
+      while (next < hi) {
+        bool pi = pinf && pinf[next], qi = qinf && qinf[next];
+        idx = next++;
+        if (!(skip_infinity && (pi || qi))) { have = true; break; }   // EIP-197: identity pairs contribute 1
+      }
+      PairStateW& s = st[slot];
+      s.live = have;
+      const size_t src = have ? idx : 0;
+      const bool qi = have && qinf && qinf[src];
+      const bool ld = have && n_pairs != 0;
+      s.px = f29_reduce(f29_from_fp(ld ? load_fp(pxy, n_pairs, src, 0) : fp_one()));
+      s.py = f29_reduce(f29_from_fp(ld ? load_fp(pxy, n_pairs, src, 4) : fp_one()));
+      s.qxs = ld ? load_s2(qxy, n_pairs, src, 0, odd) : s2_g2gen_x();
+      s.qys = ld ? load_s2(qxy, n_pairs, src, 8, odd) : s2_g2gen_y();
+      s.qx = w2_from_s2(s.qxs);
+      s.qy = w2_from_s2(s.qys);
+      s.qinf = qi;
+      // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the glued loop never looks at the flag
+      // again in replay mode
+      s.r = G2W{s.qx, s.qy, qi ? w_zero : w_one};
+      if (have) k = slot + 1;
+    }
+    const int kw = wave_max(k);
+    if (kw == 0) continue;
+    W12 f;
+    {
+      S12 one = s12_one();
+      w12_from_s12(f, one);
+    }
+    W2 l0, l1, l2;
+    auto apply = [&](const PairStateW& s) {          // f *= line, or *= 1 for a dead slot
+      const bool lv = s.live;
+      f = w12_sparse_mul(f, w2_select(w_one, l0, lv), w2_select(w_zero, w2_scale(l1, s.py), lv), w2_select(w_zero, w2_scale(l2, s.px), lv));
+    };
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      f = w12_sqr(f);
+#pragma unroll 1
+      for (int j = 0; j < kw; ++j) { g2_doubling_step29(st[j].r, l0, l1, l2, twist_b); apply(st[j]); }
+      if ((nz >> (63 - i)) & 1) {
+        const bool neg = (ng >> (63 - i)) & 1;
+#pragma unroll 1
+        for (int j = 0; j < kw; ++j) {
+          const W2 by = neg ? w2_neg(st[j].qy) : st[j].qy;
+          g2_addition_step29(st[j].r, st[j].qx, by, l0, l1, l2);
+          apply(st[j]);
+        }
+      }
+    }
+    // the two Frobenius additions; endomorphism() returns self for the identity (g2.rs:141-143)
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+#pragma unroll 1
+      for (int j = 0; j < kw; ++j) {
+        S2 q1x, q1y, q2x, q2y;
+        g2_psi_affine(q1x, q1y, st[j].qxs, st[j].qys);
+        g2_psi_affine(q2x, q2y, q1x, q1y);
+        const bool qi = st[j].qinf;
+        q1x = s2_select(q1x, st[j].qxs, qi); q1y = s2_select(q1y, st[j].qys, qi);
+        q2x = s2_select(q2x, st[j].qxs, qi); q2y = s2_select(q2y, st[j].qys, qi);
+        if (step == 0) g2_addition_step29(st[j].r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+        else g2_addition_step29(st[j].r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+        apply(st[j]);
+      }
+    }
+    w12_mul_nl(acc, acc, f);
+  }
+  S12 fin, g;
+  w12_to_s12(fin, acc);
+  if (raw_miller) g = fin;                     // partial Miller product for the batch-wide reduction below
+  else final_exponentiation29(g, fin);
+  if (active) {
+    if (gout) store_s12(gout, n_jobs, job, odd, g);
+    const bool one = s12_is_one(g);
+    if (is_one && !odd) is_one[job] = one ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------ one product over a whole batch ---------------------------
+// glued_pairing over n pairs as ONE Gt (examples/verify_multiple_messages_same_signer.rs:41-60: 2n pairs, one final
+// exponentiation, == identity).  The shared-squaring Miller value of a set of pairs is exactly the product of the per-pair Miller
+// values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KPROD pairs per lane pair (k_multi_pairing with
+// raw_miller = 1), the chunk values are multiplied together by a log-depth tree of Fp12 products, and one lane pair runs the
+// final exponentiation.
+__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs) {
+  const size_t j = TID;
+  if (j > n_jobs) return;
+  const size_t v = j * (size_t)KPROD;
+  off[j] = v < n_pairs ? v : n_pairs;
+}
+// out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out
+__global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* out, size_t n_out) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n_out) return;
+  S12 a;
+  load_s12(a, in, n_in, 2 * i, odd);
+  if (2 * i + 1 < n_in) {
+    S12 b;
+    load_s12(b, in, n_in, 2 * i + 1, odd);
+    W12 x, y, r;
+    w12_from_s12(x, a);
+    w12_from_s12(y, b);
+    w12_mul_nl(r, x, y);
+    w12_to_s12(a, r);
+  }
+  store_s12(out, n_out, i, odd, a);
+}
+// f = 1 (the empty Miller product), SoA stride 1
+__global__ void k_fp12_set_one(u64* out) {
+  if (TID >= 2) return;
+  store_s12(out, 1, 0, (int)(TID & 1), s12_one());
+}
+__global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one) {
+  const size_t t = TID;
+  const int odd = (int)(t & 1);
+  if (t >= 2) return;
+  S12 f, g;
+  if (n_in) load_s12(f, fin, n_in, 0, odd); else f = s12_one();      // empty product = identity (pairing.rs:1218-1219)
+  final_exponentiation29(g, f);
+  if (gout) store_s12(gout, 1, 0, odd, g);
+  const bool one = s12_is_one(g);
+  if (is_one && !odd) is_one[0] = one ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ Miller loops against precomputed line tables ------------
+// G2PreComputed::miller_loop(&G1Affine) (pairing.rs:590-619) and glued_miller_loop(&[G2PreComputed], &[G1Affine])
+// (pairing.rs:970-1022) consuming tables a host cached from sylow_hip_g2_precompute_batch: coeffs is the canonical SoA array
+// [87*24][m] (triple t of table k = words 24t..24t+23 = ell.0, ell.1, ell.2), pair i reads table tab_idx[i] (or table i when
+// tab_idx is NULL).  No G2 arithmetic: per step one shared squaring and, per pair, three coefficient loads, two scalings by the
+// G1 coordinates and one sparse product.  Canonical words enter the carry-free core directly: the 29-bit digits of x times
+// R'^2 mod p in one carry-free product (R' = 2^261), output N-class.
+BN_DEV F29 f29_from_plain(const Fp& x) {
+  F29 d;
+  d.v[0] = (i32)(x.v[0] & BN_M29);
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    const int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+    const u32 lo = x.v[w] >> sh;
+    const u32 hi = (sh > 3 && w + 1 < 8) ? (x.v[w + 1] << (32 - sh)) : 0u;
+    d.v[i] = (i32)((lo | hi) & BN_M29);
+  }
+  const F29 rr{{0x059bac10, 0x0d1503a3, 0x018016b8, 0x10ab0ca8, 0x02632639, 0x02c0169f, 0x169bfd53, 0x11869d4c, 0x002a11a6}};
+  return f29_mul_leaf(W_ARGS(d), W_ARGS(rr));
+}
+// job j owns pairs [offsets[j], offsets[j+1]) (offsets NULL: job j = pair j); wave-uniform schedule, a lane pair whose job has
+// fewer pairs than the wavefront maximum multiplies by the unit line
+__global__ void HEAVY_BOUNDS k_miller_precomputed(const u64* coeffs, size_t m, const u64* tab_idx, const u64* pxy, size_t n_pairs,
+                                                  const u64* offsets, size_t n_jobs, u64* fout) {
+  const size_t t = TID, job = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = job < n_jobs;
+  const size_t lo = !active ? 0 : offsets ? offsets[job] : job, hi = !active ? 0 : offsets ? offsets[job + 1] : job + 1;
+  const int kw = wave_max((int)(hi - lo));
+  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  W12 f;
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  const u64 nz = BN_ATE_NAF_NZ;
+  int idx = 0;
+  // the first pair's G1 coordinates stay in registers (the plain, one-pair-per-job loop never reloads them)
+  const bool ld0 = lo < hi && n_pairs != 0;
+  const F29 px0 = ld0 ? f29_from_plain(load_plain(pxy, n_pairs, lo, 0)) : w_one.c;
+  const F29 py0 = ld0 ? f29_from_plain(load_plain(pxy, n_pairs, lo, 4)) : w_one.c;
+  auto lines = [&]() {
+#pragma unroll 1
+    for (int j = 0; j < kw; ++j) {
+      const bool live = lo + (size_t)j < hi;
+      const size_t pi = live ? lo + (size_t)j : 0;
+      const bool ld = live && n_pairs != 0;
+      const size_t tb = !ld ? 0 : tab_idx ? (size_t)tab_idx[pi] : pi;
+      const F29 px = j == 0 ? px0 : ld ? f29_from_plain(load_plain(pxy, n_pairs, pi, 0)) : w_one.c;
+      const F29 py = j == 0 ? py0 : ld ? f29_from_plain(load_plain(pxy, n_pairs, pi, 4)) : w_one.c;
+      const int w0 = 24 * idx + 4 * odd;
+      const W2 l0 = ld ? W2{f29_from_plain(load_plain(coeffs, m, tb, w0))} : w_one;
+      const W2 l1 = ld ? W2{f29_from_plain(load_plain(coeffs, m, tb, w0 + 8))} : w_zero;
+      const W2 l2 = ld ? W2{f29_from_plain(load_plain(coeffs, m, tb, w0 + 16))} : w_zero;
+      f = w12_sparse_mul(f, w2_select(w_one, l0, live), w2_select(w_zero, w2_scale(l1, py), live), w2_select(w_zero, w2_scale(l2, px), live));
+    }
+    ++idx;
+  };
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    f = w12_sqr(f);
+    lines();
+    if ((nz >> (63 - it)) & 1) lines();
+  }
+  lines();
+  lines();
+  S12 fs;
+  w12_to_s12(fs, f);
+  if (active) store_s12(fout, n_jobs, job, odd, fs);
+}
+}  // namespace plk
+
+__global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst, const u64* offsets, size_t n_jobs, const uint8_t* is_one, uint8_t* result, uint8_t* status) {
+  size_t j = TID;
+  if (j >= n_jobs) return;
+  uint8_t st = SYLOW_HIP_ST_OK;
+  for (u64 k = offsets[j]; k < offsets[j + 1]; ++k) if (!st && pst[k]) st = pst[k];     // first failing pair, like the `?` in run_pair
+  status[j] = st;
+  result[j] = st ? 0 : is_one[j];
+}
+
+extern "C" {
+int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                      const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
+                                      uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
+  plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
+}
+int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
+                                           uint64_t* f_out, void* stream) {
+  ARGCHK(pair_offsets && f_out && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
+  plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1); LAUNCHED();
+}
+
+int32_t sylow_hip_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,
+                                                uint64_t* f_out, size_t n, void* stream) {
+  ARGCHK(coeffs && p_xy && f_out && n_tables && (table_idx || n_tables == n)); if (!n) return SYLOW_HIP_OK;
+  plk::k_miller_precomputed<<<GRID(2 * n)>>>(coeffs, n_tables, table_idx, p_xy, n, nullptr, n, f_out); LAUNCHED();
+}
+int32_t sylow_hip_glued_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,
+                                                      const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, uint64_t* f_out, void* stream) {
+  ARGCHK(pair_offsets && f_out && (n_pairs == 0 || (coeffs && p_xy && n_tables && (table_idx || n_tables == n_pairs)))); if (!n_jobs) return SYLOW_HIP_OK;
+  plk::k_miller_precomputed<<<GRID(2 * n_jobs)>>>(coeffs, n_tables, table_idx, p_xy, n_pairs, pair_offsets, n_jobs, f_out); LAUNCHED();
+}
+
+// Chunked Miller loops + product tree: leaves ONE raw Miller product (SoA stride 1 = 48 contiguous words) in the leased workspace.
+// n_pairs > 0.  The caller releases the lease after enqueueing whatever consumes *result.
+static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, size_t n_pairs,
+                                   int32_t skip_infinity, host::Lease& ws, u64** result, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n_jobs = (n_pairs + plk::KPROD - 1) / plk::KPROD;
+  // workspace: chunk offsets + two ping-pong buffers of Fp12 values
+  const size_t n_off = (n_jobs + 2) & ~(size_t)1, n_a = 48 * n_jobs, n_b = 48 * ((n_jobs + 1) / 2);
+  int32_t rc = ws.acquire((n_off + n_a + n_b) * sizeof(u64), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
+  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs);
+  plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  u64 *cur = bufa, *nxt = bufb;
+  size_t m = n_jobs;
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    plk::k_fp12_tree_level<<<GRID(2 * h)>>>(cur, m, nxt, h);
+    u64* tmp = cur; cur = nxt; nxt = tmp;
+    m = h;
+  }
+  *result = cur;
+  return SYLOW_HIP_OK;
+}
+static int32_t finish(host::Lease& ws) {
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
+}
+int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                        size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK((gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy)));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_pairs == 0) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(nullptr, 0, gt_out, is_one); LAUNCHED(); }
+  host::Lease ws;
+  u64* prod = nullptr;
+  int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, skip_infinity, ws, &prod, stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_final_exp_flag<<<1, 64, 0, st>>>(prod, 1, gt_out, is_one);
+  return finish(ws);
+}
+int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
+                                                size_t n_pairs, int32_t skip_infinity, uint64_t* f_out, void* stream) {
+  ARGCHK(f_out && (n_pairs == 0 || (p_xy && q_xy)));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_pairs == 0) { plk::k_fp12_set_one<<<1, 64, 0, st>>>(f_out); LAUNCHED(); }
+  host::Lease ws;
+  u64* prod = nullptr;
+  int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, skip_infinity, ws, &prod, stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  hipError_t e = hipMemcpyAsync(f_out, prod, 48 * sizeof(u64), hipMemcpyDeviceToDevice, st);
+  rc = finish(ws);
+  return e != hipSuccess ? host::fail(e, "hipMemcpyAsync(partial product)") : rc;
+}
+int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK((gt_out || is_one) && (parts || !k));
+  hipStream_t st = (hipStream_t)stream;
+  if (k <= 1) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(parts, k, gt_out, is_one); LAUNCHED(); }
+  host::Lease ws;
+  const size_t n_a = 48 * ((k + 1) / 2), n_b = 48 * ((k + 3) / 4);
+  int32_t rc = ws.acquire((n_a + n_b) * sizeof(u64), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  const u64* cur = parts;
+  u64 *nxt = (u64*)ws.p, *other = nxt + n_a;
+  size_t m = k;
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    plk::k_fp12_tree_level<<<GRID(2 * h)>>>(cur, m, nxt, h);
+    cur = nxt; u64* tmp = nxt; nxt = other; other = tmp;
+    m = h;
+  }
+  plk::k_final_exp_flag<<<1, 64, 0, st>>>(cur, 1, gt_out, is_one);
+  return finish(ws);
+}
+
+int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
+                                      uint8_t* result, uint8_t* status, void* stream) {
+  ARGCHK(pair_offsets && result && status && (in || !n_pairs)); if (!n_jobs) return SYLOW_HIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t np = n_pairs ? n_pairs : 1;
+  // workspace: decoded SoA points, flags, per-pair status, per-job product flag
+  const size_t bytes = np * (8 + 16) * 8 + 3 * np + n_jobs + 64;
+  host::Lease lease;
+  int32_t rc = lease.acquire(bytes, st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  uint8_t* ws = (uint8_t*)lease.p;
+  u64* pxy = (u64*)ws;
+  u64* qxy = pxy + 8 * np;
+  uint8_t* pinf = (uint8_t*)(qxy + 16 * np);
+  uint8_t* qinf = pinf + np;
+  uint8_t* pst = qinf + np;
+  uint8_t* isone = pst + np;
+  if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
+  if (rc == SYLOW_HIP_OK) {
+    if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
+    else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
+  }
+  if (rc == SYLOW_HIP_OK) k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);
+  const int32_t rc2 = finish(lease);
+  return rc != SYLOW_HIP_OK ? rc : rc2;
+}
+}  // extern "C"

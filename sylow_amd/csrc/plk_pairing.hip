@@ -1,0 +1,105 @@
+// plk_pairing.hip -- pairing(), Miller loop and final exponentiation on lane pairs + the carry-free core: the kernels
+// behind BASELINE.json's metric (plk::k_pairing), and the lane-pair Fp12 test hook.
+#include "plk_common.hpp"
+
+namespace plk {
+// ------------------------------------------------------------------ pairing(), Miller loop, final exponentiation ------
+__global__ void HEAVY_BOUNDS k_miller_loop(const u64* pxy, const u64* qxy, u64* fout, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+  const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+  S12 f;
+  miller_loop29g(f, px, py, qx, qy);
+  store_s12(fout, n, i, odd, f);
+}
+__global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  S12 f, g;
+  load_s12(f, fin, n, i, odd);
+  final_exponentiation29(g, f);
+  store_s12(gout, n, i, odd, g);
+}
+// pairing.rs:870-893
+__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
+  S12 g;
+  if (either_zero) {
+    g = s12_one();                 // Miller value forced to one; final_exponentiation(1) == 1
+  } else {
+    const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+    const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+    S12 f;
+    miller_loop29g(f, px, py, qx, qy);
+    final_exponentiation29(g, f);
+  }
+  store_s12(gout, n, i, odd, g);
+}
+
+// test hook: the lane-pair Fp12 layer one operation at a time (ops 16.. of sylow_hip_fp12_hook_batch); `b` carries the second
+// operand, or the three line coefficients (ell_0, ell_vw, ell_vv) in its first 24 words for the sparse product
+enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 = 20, OPW_FROB2 = 21, OPW_FROB3 = 22, OPW_EXPZ = 23,
+       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28, OPW_LAST = 28 };
+__global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  S12 sx, sy, sr;
+  load_s12(sx, a, n, i, odd);
+  if (b) load_s12(sy, b, n, i, odd);
+  if (op >= OPW_S_MUL && op <= OPW_S_CYCSQR) {       // saturated lane-pair layer (bn254_pair.hpp)
+    if (op == OPW_S_MUL) sr = s12_mul(sx, sy);
+    else if (op == OPW_S_SQR) sr = s12_sqr(sx);
+    else if (op == OPW_S_INV) sr = s12_inv(sx);
+    else sr = cyclotomic_sqr(sx);
+  } else {
+    W12 x, y, r;
+    w12_from_s12(x, sx);
+    if (b) w12_from_s12(y, sy);
+    switch (op) {
+      case OPW_MUL: w12_mul_nl(r, x, y); break;
+      case OPW_SQR: r = w12_sqr(x); break;
+      case OPW_SPARSE: r = w12_sparse_mul(x, y.c0.c0, y.c0.c1, y.c0.c2); break;
+      case OPW_CYCSQR: w12_cyclotomic_sqr_nl(r, x); break;
+      case OPW_FROB1: w12_frobenius_nl<1>(r, x); break;
+      case OPW_FROB2: w12_frobenius_nl<2>(r, x); break;
+      case OPW_FROB3: w12_frobenius_nl<3>(r, x); break;
+      case OPW_CONJ: r = w12_conj(x); break;
+      default: exp_by_neg_z29(r, x); break;
+    }
+    w12_to_s12(sr, r);
+  }
+  store_s12(out, n, i, odd, sr);
+}
+}  // namespace plk
+
+extern "C" {
+int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
+  ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::miller_loop(p_xy, q_xy, f_out, n, stream);
+  plk::k_miller_loop<<<GRID(2 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
+}
+int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
+  ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::final_exp(f, gt_out, n, stream);
+  plk::k_final_exp<<<GRID(2 * n)>>>(f, gt_out, n); LAUNCHED();
+}
+int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
+  ARGCHK(p_xy && q_xy && gt_out); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::pairing(p_xy, p_inf, q_xy, q_inf, gt_out, n, stream);
+  plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
+}
+// test hook: raw Fp12 selector.  0..11: the single-lane layer (single.hip: 8 product on the carry-free core, 9 cyclotomic square on
+// it, 10 / 11 exp_by_neg_z on the carry-free / saturated core); 16..28: the lane-pair Fp12 layer (plk::k_w12_op)
+int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out && op >= 0 && (op <= 11 || (op >= 16 && op <= plk::OPW_LAST))); if (!n) return SYLOW_HIP_OK;
+  if (op < 16) return single::fp12_hook(op, a, b, out, n, stream);
+  plk::k_w12_op<<<GRID(2 * n)>>>(op, a, b, out, n); LAUNCHED();
+}
+}  // extern "C"

@@ -1,0 +1,254 @@
+// plk_verify.hip -- BLS verification on lane pairs: lib.rs:223-236 as written (two pairings), the fused two-pair check with one
+// final exponentiation, the same-signer shape with both line tables in LDS, and the line-table builder (G2Affine::precompute
+// of one point in the carry-free lane-pair layout).
+#include "plk_common.hpp"
+
+namespace plk {
+// ------------------------------------------------------------------ hash to G1 on a lane pair ---------------------------
+// g1.rs:307-331: map(u0) + map(u1).  The even lane maps u0, the odd lane u1 (the two SvdW maps are independent), the points
+// are exchanged and both lanes finish with the same complete addition and affine normalisation.
+BN_DEV bool hash_to_g1_pair(Fp& hx, Fp& hy, bool& hinf, const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
+  const bool odd = lane_odd();
+  uint8_t em[96];
+  expand_message_xmd96(em, msg, msg_len, dp);
+  const Fp u = fp_from_be48(em + (odd ? 48 : 0));
+  Fp x, y;
+  u32 ok = svdw_map(x, y, u) ? 1u : 0u;
+  ok &= swap_u32(ok);
+  const Fp ox = xchg(x), oy = xchg(y);
+  const G1P a{sel(odd, x, ox), sel(odd, y, oy), fp_one()}, b{sel(odd, ox, x), sel(odd, oy, y), fp_one()};
+  const G1P h = g1_add(a, b);
+  g1_to_affine(hx, hy, hinf, h);
+  return ok != 0;
+}
+
+// ------------------------------------------------------------------ G2 line tables on the carry-free core ---------------
+// [87][3 coefficients][2 coordinates][9 limbs] int32, R-class: G2Affine::precompute (pairing.rs:676-708) of one point
+// launched with ONE lane pair: the generator (qxy == nullptr) or element idx of an SoA G2 array
+__global__ void k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
+  if (TID >= 2) return;
+  const int odd = (int)(TID & 1);
+  S2 qxs = s2_g2gen_x(), qys = s2_g2gen_y();
+  if (qxy) { qxs = load_s2(qxy, n, idx, 0, odd); qys = load_s2(qxy, n, idx, 8, odd); }
+  i32* tb = table;
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
+  const W2 twist_b = w2_const(C_TWIST_B);
+  G2W r{qx, qy, w2_from_s2(s2_one())};
+  W2 l0, l1, l2;
+  int at = 0;
+  auto put = [&]() {
+    const W2 c[3] = {l0, w2_reduce(l1), w2_reduce(l2)};
+    for (int k = 0; k < 3; ++k) for (int j = 0; j < 9; ++j) tb[((at * 3 + k) * 2 + odd) * 9 + j] = c[k].c.v[j];
+    ++at;
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step29(r, l0, l1, l2, twist_b); put();
+    if ((nz >> (63 - i)) & 1) { g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(); }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qxs, qys);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2); put();
+  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2); put();
+}
+// block-cooperative copy of a line table into LDS
+BN_DEV void stage_table(i32* lds, const i32* src) {
+  for (int k = threadIdx.x; k < LINE_TABLE_WORDS; k += blockDim.x) lds[k] = src[k];
+}
+BN_DEV W2 table_w2(const i32* tab, int at, int c, int odd) {
+  const i32* t = tab + ((at * 3 + c) * 2 + odd) * 9;
+  return W2{F29{{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]}}};
+}
+
+// ------------------------------------------------------------------ BLS verification ----------------------------------------
+// lib.rs:223-236 as written: pairing(sig, G2gen) == pairing(H(msg), pk), two Miller loops and two final exponentiations
+__global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                          const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
+  __shared__ i32 tabA[LINE_TABLE_WORDS];
+  stage_table(tabA, gen_table);
+  __syncthreads();
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  Fp hx, hy; bool hinf;
+  hash_to_g1_pair(hx, hy, hinf, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  S12 lhs, rhs;
+  if (siginf && siginf[i]) {
+    lhs = s12_one();
+  } else {
+    // G2PreComputed::miller_loop (pairing.rs:590-619) against the generator's line table
+    const F29 sx = f29_reduce(f29_from_fp(load_fp(sigxy, n, i, 0))), sy = f29_reduce(f29_from_fp(load_fp(sigxy, n, i, 4)));
+    W12 f;
+    {
+      S12 one = s12_one();
+      w12_from_s12(f, one);
+    }
+    const u64 nz = BN_ATE_NAF_NZ;
+    int idx = 0;
+    auto line = [&]() {
+      f = w12_sparse_mul(f, table_w2(tabA, idx, 0, odd), w2_scale(table_w2(tabA, idx, 1, odd), sy), w2_scale(table_w2(tabA, idx, 2, odd), sx));
+      ++idx;
+    };
+#pragma unroll 1
+    for (int it = 0; it < 64; ++it) {
+      f = w12_sqr(f);
+      line();
+      if ((nz >> (63 - it)) & 1) line();
+    }
+    line();
+    line();
+    S12 fs;
+    w12_to_s12(fs, f);
+    final_exponentiation29(lhs, fs);
+  }
+  if (hinf || (pkinf && pkinf[i])) {
+    rhs = s12_one();
+  } else {
+    const S2 qx = load_s2(pkxy, n, i, 0, odd), qy = load_s2(pkxy, n, i, 8, odd);
+    S12 f;
+    miller_loop29g(f, hx, hy, qx, qy);
+    final_exponentiation29(rhs, f);
+  }
+  bool eq = s2_eq(lhs.c0.c0, rhs.c0.c0) && s2_eq(lhs.c0.c1, rhs.c0.c1) && s2_eq(lhs.c0.c2, rhs.c0.c2) &&
+            s2_eq(lhs.c1.c0, rhs.c1.c0) && s2_eq(lhs.c1.c1, rhs.c1.c1) && s2_eq(lhs.c1.c2, rhs.c1.c2);
+  if (!odd) okout[i] = eq ? 1 : 0;
+}
+
+// e(sig, G2gen) * e(-H(msg), pk) == 1 with one shared-squaring Miller loop and one final exponentiation (see the single-lane
+// k_bls_verify_fused in single.hip for the contract).  PK_TABLE: one public key for the whole batch, its lines precomputed.
+template <bool PK_TABLE>
+__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
+  __shared__ i32 tabA[LINE_TABLE_WORDS];
+  __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
+  stage_table(tabA, gen_table);
+  if (PK_TABLE) stage_table(tabB, pk_table);
+  __syncthreads();
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = i < n;
+  const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
+  Fp hxs, hys; bool hinf;
+  hash_to_g1_pair(hxs, hys, hinf, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
+  const F29 hx = f29_reduce(f29_from_fp(hxs)), hy = f29_reduce(f29_from_fp(fp_neg(hys)));   // pair B is (-H, pk)
+  const bool liveA = !(siginf && siginf[ii]);
+  const bool liveB = !(hinf || (pkinf && pkinf[PK_TABLE ? 0 : ii]));
+  const F29 sx = f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))), sy = f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4)));
+  // a dead pair B steps the generator instead (any curve point keeps the arithmetic defined) and multiplies by the unit line
+  const S2 qxs = (PK_TABLE || !liveB) ? s2_g2gen_x() : load_s2(pkxy, n, ii, 0, odd);
+  const S2 qys = (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd);
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
+  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  const W2 twist_b = w2_const(C_TWIST_B);
+  G2W r{qx, qy, w_one};
+  W12 f;
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  W2 l0, l1, l2;
+  int idx = 0;
+  auto lineA = [&]() {
+    const W2 a0 = table_w2(tabA, idx, 0, odd), a1 = w2_scale(table_w2(tabA, idx, 1, odd), sy), a2 = w2_scale(table_w2(tabA, idx, 2, odd), sx);
+    f = w12_sparse_mul(f, w2_select(w_one, a0, liveA), w2_select(w_zero, a1, liveA), w2_select(w_zero, a2, liveA));
+  };
+  auto lineB = [&]() {
+    if (PK_TABLE) { l0 = table_w2(tabB, idx, 0, odd); l1 = table_w2(tabB, idx, 1, odd); l2 = table_w2(tabB, idx, 2, odd); }
+    f = w12_sparse_mul(f, w2_select(w_one, l0, liveB), w2_select(w_zero, w2_scale(l1, hy), liveB), w2_select(w_zero, w2_scale(l2, hx), liveB));
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    f = w12_sqr(f);
+    lineA();
+    if (!PK_TABLE) g2_doubling_step29(r, l0, l1, l2, twist_b);
+    lineB();
+    ++idx;
+    if ((nz >> (63 - it)) & 1) {
+      lineA();
+      if (!PK_TABLE) g2_addition_step29(r, qx, ((ng >> (63 - it)) & 1) ? nqy : qy, l0, l1, l2);
+      lineB();
+      ++idx;
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, qxs, qys); g2_psi_affine(q2x, q2y, q1x, q1y); }
+  lineA();
+  if (!PK_TABLE) g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  lineB();
+  ++idx;
+  lineA();
+  if (!PK_TABLE) g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+  lineB();
+  S12 fs, g;
+  w12_to_s12(fs, f);
+  final_exponentiation29(g, fs);
+  const bool one = s12_is_one(g);
+  if (active && !odd) okout[i] = one ? 1 : 0;
+}
+}  // namespace plk
+
+namespace plkh {
+int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream) {
+  plk::k_g2_lines29<<<1, 64, 0, (hipStream_t)stream>>>(q_xy, n, idx, table); LAUNCHED();
+}
+}  // namespace plkh
+
+extern "C" {
+int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::bls_verify(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  const bn254::i32* gen = nullptr;
+  int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify<<<GRID(2 * n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::bls_verify_fused(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  const bn254::i32* gen = nullptr;
+  int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify_fused<false><<<GRID(2 * n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                               const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::bls_verify_same_signer(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+  hipStream_t st = (hipStream_t)stream;
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  const bn254::i32* gen = nullptr;
+  int32_t rc = host::gen_lines29(&gen, st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  host::Lease ws;
+  if ((rc = ws.acquire(plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st)) != SYLOW_HIP_OK) return rc;
+  bn254::i32* table = (bn254::i32*)ws.p;
+  plk::k_g2_lines29<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
+  plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n);
+  const hipError_t e = hipGetLastError();
+  rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
+}
+// The same check against a line table the host cached for the key (sylow_hip_g2_line_table: `G2PreComputed` cached per pk,
+// examples/verify_multiple_messages_same_signer.rs:41-60): no G2 arithmetic at all, nothing rebuilt per call.
+int32_t sylow_hip_g2_line_table_words(void) { return plk::LINE_TABLE_WORDS; }
+int32_t sylow_hip_g2_line_table(const uint64_t* q_xy, size_t n, size_t idx, int32_t* table, void* stream) {
+  ARGCHK(q_xy && table && idx < n);
+  return plkh::build_lines29(q_xy, n, idx, table, stream);
+}
+int32_t sylow_hip_bls_verify_line_table_batch(const int32_t* pk_table, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                              const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_table && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  const bn254::i32* gen = nullptr;
+  int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(nullptr, pk_inf, pk_table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+}
+}  // extern "C"

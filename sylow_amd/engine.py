@@ -85,6 +85,12 @@ class Engine:
     def sync(self):
         _lib.check(self.lib.sylow_hip_stream_sync(self.stream), "sync")
 
+    def xoshiro_fp_soa(self, seed: int, n: int) -> np.ndarray:
+        """n values < p from the SplitMix64-seeded xoshiro256** stream, host array in SoA layout [4, n]."""
+        out = np.empty((4, n), dtype=np.uint64)
+        _lib.check(self.lib.sylow_hip_host_xoshiro_fp(seed & ((1 << 64) - 1), out.ctypes.data, n, n), "xoshiro")
+        return out
+
     def _flags(self, inf, n):
         if inf is None:
             return None
@@ -96,7 +102,13 @@ class Engine:
         return None if d is None else d.ptr
 
     def _call(self, name, *args):
+        # launches go to the calling thread's current device: re-assert ours (other code in the process may have switched it)
+        _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
         _lib.check(getattr(self.lib, name)(*args, self.stream), name)
+
+    def shutdown(self):
+        """Free the library's scratch blocks and generator tables on every device (it stays usable)."""
+        _lib.check(self.lib.sylow_hip_shutdown(), "sylow_hip_shutdown")
 
     # ---- field ops (numpy AoS in/out) -----------------------------------------------------
     def _binop(self, name, width, a, b):
@@ -162,9 +174,6 @@ class Engine:
         return self.from_device_soa(do)
 
     def fp12_hook(self, op, a, b=None):
-        fn = self.lib.sylow_hip_fp12_hook_batch
-        fn.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-        fn.restype = ctypes.c_int32
         a = _aos(a, 48)
         n = a.shape[0]
         da = self.to_device_soa(a, 48)
@@ -174,9 +183,6 @@ class Engine:
         return self.from_device_soa(do)
 
     def fp12_cyclotomic_sqr(self, a):
-        fn = self.lib.sylow_hip_fp12_cyclotomic_sqr_batch
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-        fn.restype = ctypes.c_int32
         return self._unop("sylow_hip_fp12_cyclotomic_sqr_batch", 48, a)
 
     def fp12_sparse_mul(self, f, ell):
@@ -186,6 +192,28 @@ class Engine:
         do = self.empty((48, n))
         self._call("sylow_hip_fp12_sparse_mul_batch", df.ptr, dl.ptr, do.ptr, n)
         return self.from_device_soa(do)
+
+    # Fp / Fr ::from_be_bytes / to_be_bytes (fp.rs:686-737, 746-778): (value mod modulus, status) -- both halves of the CtOption
+    def _fe_from_bytes(self, name, blobs):
+        n = len(blobs)
+        assert all(len(b) == 32 for b in blobs)
+        din = self.to_device(np.frombuffer(b"".join(blobs) or b"\x00", dtype=np.uint8))
+        do, dst = self.empty((4, max(n, 1))), self.empty((max(n, 1),), np.uint8)
+        self._call(name, din.ptr, do.ptr, dst.ptr, n)
+        return self.from_device_soa(do)[:n], dst.download()[:n]
+
+    def _fe_to_bytes(self, name, a):
+        a = _aos(a, 4)
+        n = a.shape[0]
+        da, do = self.to_device_soa(a, 4), self.empty((n * 32,), np.uint8)
+        self._call(name, da.ptr, do.ptr, n)
+        raw = do.download().tobytes()
+        return [raw[32 * i:32 * (i + 1)] for i in range(n)]
+
+    def fp_from_be_bytes(self, blobs): return self._fe_from_bytes("sylow_hip_fp_from_be_bytes_batch", blobs)
+    def fr_from_be_bytes(self, blobs): return self._fe_from_bytes("sylow_hip_fr_from_be_bytes_batch", blobs)
+    def fp_to_be_bytes(self, a): return self._fe_to_bytes("sylow_hip_fp_to_be_bytes_batch", a)
+    def fr_to_be_bytes(self, a): return self._fe_to_bytes("sylow_hip_fr_to_be_bytes_batch", a)
 
     # ---- groups ----------------------------------------------------------------------------
     def _scalar_mul(self, name, width, p_xy, p_inf, k):
@@ -345,6 +373,67 @@ class Engine:
                    1 if skip_infinity else 0, dgt.ptr, dis.ptr)
         return self.from_device_soa(dgt), bool(dis.download()[0])
 
+    def pairing_product_partial(self, p_xy, q_xy, p_inf=None, q_inf=None, skip_infinity=False):
+        """Raw Miller product of one shard (no final exponentiation), [1, 48]."""
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dq = self.to_device_soa(q_xy, 16) if n else None
+        dpi, dqi = (self._flags(p_inf, n), self._flags(q_inf, n)) if n else (None, None)
+        df = self.empty((48, 1))
+        self._call("sylow_hip_pairing_product_partial_batch", self._ptr(dp), self._ptr(dpi), self._ptr(dq), self._ptr(dqi), n,
+                   1 if skip_infinity else 0, df.ptr)
+        return self.from_device_soa(df)
+
+    def fp12_product_final_exp(self, parts):
+        """final_exponentiation(prod parts) for parts [k, 48]; returns (gt [1, 48], is_one)."""
+        parts = _aos(parts, 48)
+        k = parts.shape[0]
+        dpa = self.to_device_soa(parts, 48) if k else None
+        dgt, dis = self.empty((48, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_fp12_product_final_exp", self._ptr(dpa), k, dgt.ptr, dis.ptr)
+        return self.from_device_soa(dgt), bool(dis.download()[0])
+
+    def pairing_product_all(self, p_xy, q_xy, comm=None, p_inf=None, q_inf=None, skip_infinity=False):
+        """glued_pairing over the union of all ranks' pairs (comm = raw ncclComm_t as int, None = one rank)."""
+        p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
+        n = p_xy.shape[0]
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dq = self.to_device_soa(q_xy, 16) if n else None
+        dpi, dqi = (self._flags(p_inf, n), self._flags(q_inf, n)) if n else (None, None)
+        dgt, dis = self.empty((48, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_pairing_product_all", self._ptr(dp), self._ptr(dpi), self._ptr(dq), self._ptr(dqi), n,
+                   1 if skip_infinity else 0, comm, dgt.ptr, dis.ptr)
+        return self.from_device_soa(dgt), bool(dis.download()[0])
+
+    def all_valid(self, dflags: DeviceArray, comm=None) -> int:
+        """AND of this rank's flags AND-ed over every rank of `comm` (raw ncclComm_t as int, None = one rank)."""
+        out = self.empty((1,), np.int32)
+        self._call("sylow_hip_all_valid", dflags.ptr, dflags.shape[0], comm, out.ptr)
+        return int(out.download()[0])
+
+    # G2PreComputed consumers (pairing.rs:590-619, 970-1022): coeffs [m, 87*24] as g2_precompute returns them
+    def miller_loop_precomputed(self, coeffs, p_xy, table_idx=None):
+        coeffs, p_xy = _aos(coeffs, 87 * 24), _aos(p_xy, 8)
+        n, m = p_xy.shape[0], coeffs.shape[0]
+        dc, dp = self.to_device_soa(coeffs, 87 * 24), self.to_device_soa(p_xy, 8)
+        dti = self.to_device(np.ascontiguousarray(table_idx, dtype=np.uint64)) if table_idx is not None else None
+        do = self.empty((48, n))
+        self._call("sylow_hip_miller_loop_precomputed_batch", dc.ptr, m, self._ptr(dti), dp.ptr, do.ptr, n)
+        return self.from_device_soa(do)
+
+    def glued_miller_loop_precomputed(self, coeffs, p_xy, offsets, table_idx=None):
+        coeffs, p_xy = _aos(coeffs, 87 * 24), _aos(p_xy, 8)
+        n, m = p_xy.shape[0], coeffs.shape[0]
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nj = off.shape[0] - 1
+        dc = self.to_device_soa(coeffs, 87 * 24) if m else None
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dti = self.to_device(np.ascontiguousarray(table_idx, dtype=np.uint64)) if table_idx is not None else None
+        doff, df = self.to_device(off), self.empty((48, max(nj, 1)))
+        self._call("sylow_hip_glued_miller_loop_precomputed_batch", self._ptr(dc), m, self._ptr(dti), self._ptr(dp), doff.ptr, nj, n, df.ptr)
+        return self.from_device_soa(df)[:nj]
+
     # ---- wire formats ----------------------------------------------------------------------
     def _to_bytes(self, name, width, nbytes, xy, inf):
         xy = _aos(xy, width)
@@ -418,6 +507,26 @@ class Engine:
         dpi, dsi = self._flags(pk_inf, 1), self._flags(sig_inf, n)
         dok = self.empty((n,), np.uint8)
         self._call("sylow_hip_bls_verify_same_signer_batch", dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
+        return dok.download()
+
+    def g2_line_table(self, pk_xy) -> DeviceArray:
+        """Device-resident line table of ONE key (opaque int32 words): build once, reuse across bls_verify_line_table calls."""
+        pk_xy = _aos(pk_xy, 16)
+        assert pk_xy.shape[0] == 1
+        dpk = self.to_device_soa(pk_xy, 16)
+        table = self.empty((int(self.lib.sylow_hip_g2_line_table_words()),), np.int32)
+        self._call("sylow_hip_g2_line_table", dpk.ptr, 1, 0, table.ptr)
+        self.sync()                      # dpk is released when this frame returns
+        return table
+
+    def bls_verify_line_table(self, table: DeviceArray, msgs, sig_xy, pk_inf=None, sig_inf=None):
+        sig_xy = _aos(sig_xy, 8)
+        n = len(msgs)
+        dm, doff = self._msgs(msgs)
+        dsig = self.to_device_soa(sig_xy, 8)
+        dpi, dsi = self._flags(pk_inf, 1), self._flags(sig_inf, n)
+        dok = self.empty((n,), np.uint8)
+        self._call("sylow_hip_bls_verify_line_table_batch", table.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
         return dok.download()
 
     def g2_precompute(self, q_xy):

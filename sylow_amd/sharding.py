@@ -18,16 +18,43 @@ def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def collective_device(dist=None):
+    """Where the 4-byte flag word lives for the reduce: the GPU for backend nccl (= RCCL over xGMI), the host for gloo."""
+    import torch
+    if dist is not None and dist.is_initialized() and dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def and_reduce_(flag, dist=None):
+    """THE exchange step: in-place MIN (= AND over {0,1}) of a one-element int32 tensor over all ranks; returns the tensor
+    that holds the result (a host copy when the backend reduces on the host).  No-op for a single rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return flag
+    dev = collective_device(dist)
+    if flag.device != dev:
+        flag = flag.to(dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return flag
+
+
 def all_valid(local_ok: int, dist=None, device=None) -> int:
     """AND of the per-rank flags.  `dist` is torch.distributed (already initialised) or None."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(bool(local_ok))
     import torch
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return int(t.item())
+    t = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device if device is not None else collective_device(dist))
+    return int(and_reduce_(t, dist).item())
+
+
+def max_over_ranks(value: float, dist=None) -> float:
+    """Slowest rank's wall time (the bench contract's MAX over ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=collective_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def gather_flags(local_flags: np.ndarray, n: int, dist=None) -> np.ndarray:

@@ -66,3 +66,19 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "sylow_hip.h"\nint main(void) { return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_host_xoshiro_matches_the_test_stream():
+    """sylow_hip_host_xoshiro_fp (bench inputs) is the generator of tests/helpers.py (oracle inputs): BASELINE.md §3."""
+    import numpy as np
+
+    import sylow_amd
+    from helpers import SEED, Xoshiro, limbs
+    lib = sylow_amd.load()
+    for seed, n in ((SEED, 300), (SEED + 3, 1), (0, 17), ((1 << 64) - 1, 64)):
+        out = np.zeros((4, n + 2), dtype=np.uint64)
+        assert lib.sylow_hip_host_xoshiro_fp(seed, out.ctypes.data, n, n + 2) == 0
+        r = Xoshiro(seed)
+        assert np.array_equal(out[:, :n].T, limbs([r.fp() for _ in range(n)]))
+        assert not out[:, n:].any()                                    # the stride tail is left alone
+    assert lib.sylow_hip_host_xoshiro_fp(1, None, 4, 4) == -2

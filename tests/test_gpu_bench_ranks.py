@@ -1,0 +1,57 @@
+"""The N > 1 code the driver runs (bench.py under torch.distributed.run), executed before the driver does: two ranks as FRESH
+child processes on this box's one GPU (SYLOW_BENCH_BACKEND=gloo SYLOW_BENCH_SINGLE_DEVICE=1: host-side collectives, same
+barrier / MAX / MIN(=AND) logic as the RCCL path, which differs only in the backend name).  Checks the JSON line, the
+aggregate flag, and that ONE planted bad signature on rank 1 flips the global AND on rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SYLOW_BENCH_BACKEND="gloo", SYLOW_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "12", "--steps", "1", "--warmup", "1", "--no-cpu"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_all_valid():
+    out = run_bench([])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["batch_per_gpu"] == 4096 and out["value"] > 0
+    aux = out["aux"]
+    assert aux["bls_all_valid"] == 1 and aux["bls_all_valid_fused"] == 1 and aux["aggregate_all_valid"] == 1
+    assert aux["bls_verify_batch_per_gpu"] == 4096 and aux["bad_flags_this_rank"] == 0
+
+
+def test_two_rank_bench_planted_bad_signature_on_rank_1():
+    out = run_bench(["--plant-bad", "1"])
+    aux = out["aux"]
+    assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_fused"] == 0      # rank 0 sees rank 1's failure through the reduce
+    assert aux["bad_flags_this_rank"] == 0                                       # ... although all of rank 0's own flags are set
+
+
+def test_single_rank_bench_self_check():
+    """The N = 1 line at a small batch: oracle spot check of the timed output, all single-GPU configs, CPU leg."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2n", "13", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    cb = out["cpu_baseline"]
+    assert cb["checked"] == 16 and cb["mismatches"] == 0 and cb["kind"] == "port" and cb["cores"] >= 1
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    cfg = out["aux"]["configs"]
+    assert {"C2a_fp_mul_2^20", "C2a_fp_add_2^24", "C2b_g1_scalar_mul_2^13", "C3_pairing_2^13"} <= set(cfg)
+    assert all(v["pattern_ok"] == 1 for k, v in cfg.items() if k.startswith("C5_"))
+    assert out["aux"]["bls_all_valid"] == 1

@@ -1,4 +1,4 @@
-"""Lane-pair kernels (pair_kernels.hpp): ragged batch sizes (partial wavefronts, odd element counts), identity flags mixed
+"""Lane-pair kernels (sylow_amd/csrc/plk_*.hip): ragged batch sizes (partial wavefronts, odd element counts), identity flags mixed
 inside one wavefront, and the single-lane twin (SYLOW_HIP_SINGLE_LANE=1) replaying the pairing test files in a subprocess."""
 import os
 import subprocess

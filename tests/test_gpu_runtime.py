@@ -1,0 +1,121 @@
+"""GPU tests of the runtime around the kernels: the leased scratch workspace under concurrent host threads on separate HIP
+streams (every result checked against the oracle), shutdown + reuse, device re-assertion, and a short run of the determinism
+soak (tools/soak.py: random batch sizes through every pairing-based entry point, each call issued twice)."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import SEED, Xoshiro, limbs, pack
+from test_gpu_multi_pairing import G1, G2, proj1, proj2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inputs(engine, n, seed):
+    rng = Xoshiro(seed)
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    return p, q
+
+
+def _evm_blob(p, q):
+    """EIP-197 encoding of pairs (P_i, Q_i): x | y | x.c1 | x.c0 | y.c1 | y.c0, 32-byte big-endian each"""
+    def be(col):
+        return col[:, ::-1].astype(">u8").view(np.uint8).reshape(len(col), 32)
+    return np.concatenate([be(p[:, 0:4]), be(p[:, 4:8]), be(q[:, 4:8]), be(q[:, 0:4]), be(q[:, 12:16]), be(q[:, 8:12])], axis=1)
+
+
+def test_two_threads_two_streams_workspace_users(engine, coracle):
+    """pairing_product_batch, evm_ecpairing_batch and bls_verify_same_signer_batch interleaved from two host threads on two
+    non-default streams: each call leases its own scratch block, so no result may ever differ from the oracle's."""
+    import torch
+
+    import sylow_amd
+    n = 96
+    p, q = _inputs(engine, n, SEED + 100)
+    exp_prod = {m: coracle.glued_pairing(proj1(p[:m]), proj2(q[:m]), np.array([0, m], dtype=np.uint64)) for m in (17, 64, 96)}
+    # ecPairing jobs of two pairs: e(P, Q) e(-P, Q) -> true; odd jobs use another P in the second pair -> false
+    from helpers import P as PMOD, ints
+    negy = limbs([(PMOD - y) % PMOD for y in ints(p[:, 4:8])])
+    pn = np.concatenate([p[:, :4], negy], axis=1)
+    pos, neg = _evm_blob(p, q), _evm_blob(pn, q)
+    nj = 48
+    jobs = np.concatenate([pos[:nj], neg[:nj]], axis=1).copy()
+    jobs[1::2, 192:256] = pos[(np.arange(nj)[1::2] + 5) % n, :64]
+    exp_evm = (np.arange(nj) % 2 == 0).astype(np.uint8)
+    rng = Xoshiro(SEED + 101)
+    sk = limbs([rng.fp()])
+    msgs = [bytes([i]) * (1 + i % 7) for i in range(40)]
+    sig, _ = engine.bls_sign(np.repeat(sk, 40, 0), msgs)
+    pk, _ = engine.g2_scalar_mul(pack(G2, 16), sk)
+    sig_bad = sig.copy(); sig_bad[11] = sig[12]
+    exp_ver = np.ones(40, dtype=np.uint8); exp_ver[11] = 0
+
+    errors = []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream()
+            eng = sylow_amd.Engine(0, stream=st.cuda_stream)
+            for it in range(12):
+                m = (17, 64, 96)[(it + tid) % 3]
+                g, _ = eng.pairing_product(p[:m], q[:m])
+                if not np.array_equal(g, exp_prod[m]):
+                    errors.append(("product", tid, it, m))
+                d_in = eng.to_device(jobs.reshape(-1)); d_off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(2))
+                d_res, d_st = eng.empty((nj,), np.uint8), eng.empty((nj,), np.uint8)
+                eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, 2 * nj, d_res.ptr, d_st.ptr)
+                if not (np.array_equal(d_res.download(), exp_evm) and not d_st.download().any()):
+                    errors.append(("evm", tid, it))
+                if not np.array_equal(eng.bls_verify_same_signer(pk, msgs, sig_bad), exp_ver):
+                    errors.append(("same_signer", tid, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", tid, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
+def test_shutdown_then_reuse(engine, coracle):
+    p, q = _inputs(engine, 20, SEED + 102)
+    before, _ = engine.pairing_product(p, q)
+    msgs = [b"a", b"bc"]
+    rng = Xoshiro(SEED + 103)
+    sk = limbs([rng.fp(), rng.fp()])
+    sig, _ = engine.bls_sign(sk, msgs)
+    pk, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 2, 0), sk)
+    assert engine.bls_verify(pk, msgs, sig, fused=True).tolist() == [1, 1]         # builds the generator line table
+    engine.shutdown()                                                              # frees blocks, events and the table
+    after, _ = engine.pairing_product(p, q)                                        # state is rebuilt on demand
+    assert np.array_equal(before, after)
+    assert engine.bls_verify(pk, msgs, sig, fused=True).tolist() == [1, 1]
+    engine.shutdown()
+    engine.shutdown()                                                              # idempotent
+
+
+def test_set_device_is_reasserted_and_checked(engine):
+    lib = engine.lib
+    assert lib.sylow_hip_set_device(0) == 0
+    assert lib.sylow_hip_set_device(lib.sylow_hip_device_count()) != 0             # out of range -> HIP error code, not a crash
+    assert lib.sylow_hip_set_device(-1) == -2
+    ids = (__import__("ctypes").c_int32 * 1)(0)
+    assert lib.sylow_hip_init_devices(ids, 1) == 0
+    assert lib.sylow_hip_init_devices(None, 0) == -2
+    a = limbs([3, 5])
+    assert engine.fp_mul(a[:1], a[1:]).tolist() == limbs([15]).tolist()
+
+
+def test_soak_short():
+    """~20 s of tools/soak.py as a fresh child process (it asserts determinism and oracle parity internally)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "soak ok" in r.stdout

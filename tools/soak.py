@@ -11,7 +11,7 @@ from test_gpu_multi_pairing import proj1, proj2, G1, G2
 
 eng = sylow_amd.Engine(0)
 rng = Xoshiro(0xC0FFEE)
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0      # tests/test_gpu_runtime.py runs 20 s of it
 t0 = time.time()
 NMAX = 4096
 base_k = limbs([rng.fp() for _ in range(NMAX)])
