@@ -128,6 +128,27 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP / HSA runtime per process.  A PyTorch-ROCm wheel ships its own libamdhip64.so.7 + libhsa-runtime64 (same sonames
+    as /opt/rocm's); if libsylow_hip.so pulled in the system copies first and torch (or torch's RCCL, which dlopens
+    libhsa-runtime64.so by file name) arrived later, the process would hold two HSA runtimes and the second one sees
+    "no ROCm-capable device".  So when torch is installed its runtime is loaded first -- whether or not torch is ever imported --
+    and both share it.  Hosts without torch (C, C++, Rust) get the system runtime.  SYLOW_HIP_SYSTEM_RUNTIME=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("SYLOW_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the shared library and declare every prototype.  Does not touch the GPU."""
     global _lib
@@ -136,6 +157,7 @@ def load():
             raise SylowHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
+        _preload_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -181,6 +181,7 @@ thread_local char sylow_g_err[256] = "";
 namespace host {
 int32_t fail(hipError_t e, const char* what) {
   snprintf(sylow_g_err, sizeof(sylow_g_err), "%s: %s", what, hipGetErrorString(e));
+  (void)hipGetLastError();          // the failure is reported through the return code: do not leave it sticky for the next launch check
   return SYLOW_HIP_E_HIP;
 }
 bool single_lane() {

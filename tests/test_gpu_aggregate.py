@@ -87,7 +87,9 @@ def test_rccl_entry_points_one_rank_communicator(engine, pairs):
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
     comm = ctypes.c_void_p()
-    assert lib.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    lib.ncclGetLastError.restype = ctypes.c_char_p
+    rc = lib.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0)
+    assert rc == 0, (rc, lib.ncclGetLastError(None))
     try:
         p, q = pairs
         f = np.ones(4097, dtype=np.uint8)
