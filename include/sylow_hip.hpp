@@ -80,6 +80,24 @@ inline DeviceBuffer to_device_bytes(const std::vector<uint8_t>& v) {
   return d;
 }
 
+// optional identity flags (one byte per element; nullptr = no element is the identity)
+struct Flags {
+  DeviceBuffer d;
+  const uint8_t* ptr;
+  Flags(const std::vector<uint8_t>* v, size_t n) : d(n + 8), ptr(nullptr) {
+    if (v) {
+      if (v->size() != n) throw Error("identity flags: length mismatch");
+      if (n) { check(sylow_hip_memcpy_h2d(d.as<void>(), v->data(), n, nullptr), "h2d"); check(sylow_hip_stream_sync(nullptr), "sync"); }
+      ptr = d.as<uint8_t>();
+    }
+  }
+};
+inline void fetch_flags(std::vector<uint8_t>* out, const DeviceBuffer& d, size_t n) {
+  if (!out) return;
+  out->resize(n);
+  if (n) { check(sylow_hip_memcpy_d2h(out->data(), d.as<void>(), n, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync"); }
+}
+
 inline G1Affine g1_generator() { return G1Affine{Fp{{1, 0, 0, 0}}, Fp{{2, 0, 0, 0}}}; }                 // g1.rs:54-60
 inline G2Affine g2_generator() {                                                                       // g2.rs:47-77
   return G2Affine{Fp2{Fp{{0x46DEBD5CD992F6EDull, 0x674322D4F75EDADDull, 0x426A00665E5C4479ull, 0x1800DEEF121F1E76ull}},
@@ -95,37 +113,51 @@ inline std::vector<Gt> pairing(const std::vector<G1Affine>& p, const std::vector
   const size_t n = p.size();
   auto dp = to_device_soa(p); auto dq = to_device_soa(q);
   DeviceBuffer dgt(n * sizeof(Gt) + 8);
-  DeviceBuffer dpi = to_device_bytes(p_inf ? *p_inf : std::vector<uint8_t>()), dqi = to_device_bytes(q_inf ? *q_inf : std::vector<uint8_t>());
-  check(sylow_hip_pairing_batch(dp.as<uint64_t>(), p_inf ? dpi.as<uint8_t>() : nullptr, dq.as<uint64_t>(), q_inf ? dqi.as<uint8_t>() : nullptr,
-                                dgt.as<uint64_t>(), n, nullptr), "sylow_hip_pairing_batch");
+  Flags dpi(p_inf, n), dqi(q_inf, n);
+  check(sylow_hip_pairing_batch(dp.as<uint64_t>(), dpi.ptr, dq.as<uint64_t>(), dqi.ptr, dgt.as<uint64_t>(), n, nullptr), "sylow_hip_pairing_batch");
   return from_device_soa<Gt>(dgt, n);
 }
-// glued_pairing(&[G1Projective], &[G2Projective]) -> Gt (pairing.rs:1029-1037): ONE product
-inline Gt glued_pairing(const std::vector<G1Affine>& g1s, const std::vector<G2Affine>& g2s) {
+// glued_pairing(&[G1Projective], &[G2Projective]) -> Gt (pairing.rs:1029-1037): ONE product.  Identity flags as in the reference:
+// skip_infinity = false replays it (flags only shape Z of the G2 point, a G2 identity zeroes the product),
+// true drops pairs with an identity on either side (EIP-197).
+inline Gt glued_pairing(const std::vector<G1Affine>& g1s, const std::vector<G2Affine>& g2s,
+                        const std::vector<uint8_t>* g1_inf = nullptr, const std::vector<uint8_t>* g2_inf = nullptr, bool skip_infinity = false) {
   const size_t k = g1s.size() < g2s.size() ? g1s.size() : g2s.size();        // zip truncates (pairing.rs:975)
   std::vector<G1Affine> a(g1s.begin(), g1s.begin() + k);
   std::vector<G2Affine> b(g2s.begin(), g2s.begin() + k);
+  std::vector<uint8_t> ai, bi;
+  if (g1_inf) ai.assign(g1_inf->begin(), g1_inf->begin() + k);
+  if (g2_inf) bi.assign(g2_inf->begin(), g2_inf->begin() + k);
   auto dp = to_device_soa(a); auto dq = to_device_soa(b);
+  Flags dpi(g1_inf ? &ai : nullptr, k), dqi(g2_inf ? &bi : nullptr, k);
   DeviceBuffer dgt(sizeof(Gt));
   // the whole batch as one product, spread over the GPU (chunked Miller loops, product tree, one final exponentiation)
-  check(sylow_hip_pairing_product_batch(dp.as<uint64_t>(), nullptr, dq.as<uint64_t>(), nullptr, k, 0, dgt.as<uint64_t>(), nullptr, nullptr),
+  check(sylow_hip_pairing_product_batch(dp.as<uint64_t>(), dpi.ptr, dq.as<uint64_t>(), dqi.ptr, k, skip_infinity ? 1 : 0, dgt.as<uint64_t>(), nullptr, nullptr),
         "sylow_hip_pairing_product_batch");
   return from_device_soa<Gt>(dgt, 1)[0];
 }
 // Mul<&Fp> for G1 / G2 (group.rs:639-667), elementwise
-inline std::vector<G1Affine> mul(const std::vector<G1Affine>& p, const std::vector<Fp>& k, std::vector<uint8_t>* inf_out = nullptr) {
+// inf_out receives the identity flags of the results (k = 0, k = r, identity in -> identity out); p_inf marks identity inputs
+inline std::vector<G1Affine> mul(const std::vector<G1Affine>& p, const std::vector<Fp>& k, std::vector<uint8_t>* inf_out = nullptr,
+                                 const std::vector<uint8_t>* p_inf = nullptr) {
+  if (p.size() != k.size()) throw Error("G1 * Fp: length mismatch");
   const size_t n = p.size();
   auto dp = to_device_soa(p); auto dk = to_device_soa(k);
+  Flags dpi(p_inf, n);
   DeviceBuffer dout(n * sizeof(G1Affine) + 8), dinf(n + 8);
-  check(sylow_hip_g1_scalar_mul_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g1_scalar_mul");
-  if (inf_out) { inf_out->resize(n); check(sylow_hip_memcpy_d2h(inf_out->data(), dinf.as<void>(), n, nullptr), "d2h"); }
+  check(sylow_hip_g1_scalar_mul_batch(dp.as<uint64_t>(), dpi.ptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g1_scalar_mul");
+  fetch_flags(inf_out, dinf, n);
   return from_device_soa<G1Affine>(dout, n);
 }
-inline std::vector<G2Affine> mul(const std::vector<G2Affine>& p, const std::vector<Fp>& k) {
+inline std::vector<G2Affine> mul(const std::vector<G2Affine>& p, const std::vector<Fp>& k, std::vector<uint8_t>* inf_out = nullptr,
+                                 const std::vector<uint8_t>* p_inf = nullptr) {
+  if (p.size() != k.size()) throw Error("G2 * Fp: length mismatch");
   const size_t n = p.size();
   auto dp = to_device_soa(p); auto dk = to_device_soa(k);
+  Flags dpi(p_inf, n);
   DeviceBuffer dout(n * sizeof(G2Affine) + 8), dinf(n + 8);
-  check(sylow_hip_g2_scalar_mul_batch(dp.as<uint64_t>(), nullptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
+  check(sylow_hip_g2_scalar_mul_batch(dp.as<uint64_t>(), dpi.ptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
+  fetch_flags(inf_out, dinf, n);
   return from_device_soa<G2Affine>(dout, n);
 }
 // Mul<&Fr> for &Gt (groups/gt.rs:161-187), elementwise: gt[i] "times" k[i]
@@ -175,22 +207,27 @@ struct Messages {                                    // concatenated bytes + off
   }
   static size_t total(const std::vector<std::vector<uint8_t>>& msgs) { size_t t = 0; for (auto& m : msgs) t += m.size(); return t; }
 };
-// sign(&Fp, &[u8]) -> Result<G1Projective, GroupError> (lib.rs:179-187), elementwise
-inline std::vector<G1Affine> sign(const std::vector<Fp>& k, const std::vector<std::vector<uint8_t>>& msgs) {
+// sign(&Fp, &[u8]) -> Result<G1Projective, GroupError> (lib.rs:179-187), elementwise; sig_inf receives the identity flags of
+// the signatures (k = 0 or a multiple of r signs to the identity)
+inline std::vector<G1Affine> sign(const std::vector<Fp>& k, const std::vector<std::vector<uint8_t>>& msgs, std::vector<uint8_t>* sig_inf = nullptr) {
   if (k.size() != msgs.size()) throw Error("sign: length mismatch");
   Messages m(msgs);
   auto dk = to_device_soa(k);
   DeviceBuffer dsig(m.n * sizeof(G1Affine) + 8), dinf(m.n + 8);
   check(sylow_hip_bls_sign_batch(dk.as<uint64_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), dinf.as<uint8_t>(), m.n, nullptr), "sylow_hip_bls_sign_batch");
+  fetch_flags(sig_inf, dinf, m.n);
   return from_device_soa<G1Affine>(dsig, m.n);
 }
-// verify(&G2Projective, &[u8], &G1Projective) -> Result<bool, GroupError> (lib.rs:223-236), elementwise
-inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig) {
+// verify(&G2Projective, &[u8], &G1Projective) -> Result<bool, GroupError> (lib.rs:223-236), elementwise.  An identity key or
+// signature is a flag, not a coordinate pair: pairing() maps it to Gt::identity() (pairing.rs:876-886)
+inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig,
+                                   const std::vector<uint8_t>* pk_inf = nullptr, const std::vector<uint8_t>* sig_inf = nullptr) {
   if (pubkey.size() != msgs.size() || sig.size() != msgs.size()) throw Error("verify: length mismatch");
   Messages m(msgs);
   auto dpk = to_device_soa(pubkey); auto dsig = to_device_soa(sig);
+  Flags dpi(pk_inf, m.n), dsi(sig_inf, m.n);
   DeviceBuffer dok(m.n + 8);
-  check(sylow_hip_bls_verify_batch(dpk.as<uint64_t>(), nullptr, m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), nullptr, dok.as<uint8_t>(), m.n, nullptr), "sylow_hip_bls_verify_batch");
+  check(sylow_hip_bls_verify_batch(dpk.as<uint64_t>(), dpi.ptr, m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), dsi.ptr, dok.as<uint8_t>(), m.n, nullptr), "sylow_hip_bls_verify_batch");
   std::vector<uint8_t> ok(m.n);
   if (m.n) { check(sylow_hip_memcpy_d2h(ok.data(), dok.as<void>(), m.n, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync"); }
   return ok;

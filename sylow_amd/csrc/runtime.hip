@@ -211,7 +211,25 @@ int32_t current_device(int& d) {
 // block (the new stream then waits for its event on the device, the host does not block), (4) a new block.  Reuse is always
 // ordered with hipStreamWaitEvent on the block's own event -- also on the "same" stream, since a destroyed stream's handle
 // value can come back for a different stream -- so no stale stream handle is ever passed to HIP.
+// SYLOW_HIP_WS_ASYNC=1 (debugging only, tools/dbg_prod.py): take the block from HIP's stream-ordered allocator instead, the design
+// round 1 abandoned after intermittent wrong products -- kept switchable so that the incident stays reproducible / re-testable.
+static bool ws_async() {
+  static const bool v = [] { const char* e = getenv("SYLOW_HIP_WS_ASYNC"); return e && e[0] == '1'; }();
+  return v;
+}
+// SYLOW_HIP_WS_POISON=1 (debugging only): fill every leased block with 0xA5 before use, so that a kernel reading scratch it has
+// not written yet cannot be masked by a previous call's identical contents
+static bool ws_poison() {
+  static const bool v = [] { const char* e = getenv("SYLOW_HIP_WS_POISON"); return e && e[0] == '1'; }();
+  return v;
+}
 int32_t Lease::acquire(size_t bytes, hipStream_t stream) {
+  if (ws_async()) {
+    HIPCHK(hipMallocAsync(&p, bytes ? bytes : 1, stream));
+    dev = -2; slot = 0; st = stream;
+    if (ws_poison()) HIPCHK(hipMemsetAsync(p, 0xA5, bytes, stream));
+    return SYLOW_HIP_OK;
+  }
   std::lock_guard<std::mutex> lock(g_mu);
   int d = 0;
   int32_t rc = current_device(d);
@@ -241,10 +259,16 @@ int32_t Lease::acquire(size_t bytes, hipStream_t stream) {
   }
   b.leased = true;
   p = b.p; dev = d; slot = pick; st = stream;
+  if (ws_poison()) HIPCHK(hipMemsetAsync(p, 0xA5, bytes, stream));
   return SYLOW_HIP_OK;
 }
 int32_t Lease::release() {
   if (slot < 0) return SYLOW_HIP_OK;
+  if (dev == -2) {
+    slot = -1;
+    HIPCHK(hipFreeAsync(p, st));
+    return SYLOW_HIP_OK;
+  }
   std::lock_guard<std::mutex> lock(g_mu);
   Block& b = g_dev[dev].blocks[slot];
   slot = -1;

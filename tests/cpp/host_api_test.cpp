@@ -46,6 +46,24 @@ int main() {
     bool same = true;
     for (int i = 0; i < 4; ++i) same = same && agg[0].x.w[i] == five[0].x.w[i] && agg[0].y.w[i] == five[0].y.w[i];
     std::printf("AGG %d\n", same ? 1 : 0);
+    // identity handling through the flags (pairing.rs:876-886: an identity operand maps to Gt::identity()):
+    //  * sk = 0 signs to the identity and the flag comes back; 0 * G2gen is the identity key
+    //  * verify with BOTH flags set: identity == identity -> true; with only one side the identity -> false
+    //  * the same coordinates WITHOUT the flags are just an off-curve pair and must not verify
+    std::vector<Fp> sk0 = {Fp{{0, 0, 0, 0}}, sk[0]};
+    std::vector<std::vector<uint8_t>> m2(2, std::vector<uint8_t>{9, 9});
+    std::vector<uint8_t> sinf, pinf;
+    auto sig2 = sign(sk0, m2, &sinf);
+    auto pk2 = mul(std::vector<G2Affine>(2, g2_generator()), sk0, &pinf);
+    auto v_flags = verify(pk2, m2, sig2, &pinf, &sinf);
+    std::vector<uint8_t> only_sig = {1, 0}, none = {0, 0};
+    auto v_half = verify(pk2, m2, sig2, &none, &only_sig);
+    auto v_noflag = verify(pk2, m2, sig2);
+    std::printf("IDENT %d%d %d%d %d%d %d%d %d%d\n", sinf[0], sinf[1], pinf[0], pinf[1], v_flags[0], v_flags[1], v_half[0], v_half[1], v_noflag[0], v_noflag[1]);
+    // glued product with an identity G1 flagged and skipped (EIP-197 semantics) == the product of the rest
+    std::vector<uint8_t> gi = {1, 0}, qi = {0, 0};
+    Gt skipped = glued_pairing({g1_generator(), g1_generator()}, {g2_generator(), g2_generator()}, &gi, &qi, true);
+    std::printf("GLUEDSKIP %d\n", skipped == gt[0] ? 1 : 0);
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
