@@ -56,6 +56,24 @@ def _row(vals):
     return np.array([[(v >> (64 * k)) & _M64 for v in vals for k in range(4)]], dtype=np.uint64)
 
 
+def _raise_status(st):
+    """per-element status bytes (include/sylow_hip.h) -> the reference's error for the first failing element"""
+    names = {1: GroupError.NOT_ON_CURVE, 2: GroupError.NOT_IN_SUBGROUP, 3: GroupError.CANNOT_HASH_TO_GROUP, 4: GroupError.DECODE_ERROR}
+    bad = np.nonzero(np.asarray(st))[0]
+    if len(bad):
+        raise GroupError(names[int(st[bad[0]])])
+
+
+def fp_from_be_bytes(blobs):
+    """Fp::from_be_bytes (fp.rs:686-719): (values [n, 4], is_some [n]) -- both halves of the CtOption (value = v mod p)."""
+    v, st = engine().fp_from_be_bytes(list(blobs))
+    return v, st == 0
+
+
+def fp_to_be_bytes(values):                         # fp.rs:727-737
+    return engine().fp_to_be_bytes(values)
+
+
 class _Points:
     WIDTH = 0
 
@@ -109,6 +127,19 @@ class G1Affine(_Points):
         xy, inf = engine().g1_double(self.xy, self.infinity)
         return G1Affine(xy, inf)
 
+    @classmethod
+    def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g1.rs:293-305): generator * random scalar (seeded, reproducible)
+        return cls.generator(n) * engine().xoshiro_fp_soa(seed, n).T.copy()
+
+    def to_be_bytes(self):                         # g1.rs:151-180
+        return engine().g1_to_be_bytes(self.xy, self.infinity)
+
+    @classmethod
+    def from_be_bytes(cls, blobs):                 # g1.rs:224-280: CtOption none -> GroupError(DecodeError / NotOnCurve)
+        xy, inf, st = engine().g1_from_be_bytes(list(blobs))
+        _raise_status(st)
+        return cls(xy, inf)
+
 
 G1Projective = G1Affine   # results are compared after normalisation: one batch type serves both names
 
@@ -152,6 +183,24 @@ class G2Affine(_Points):
 
     def precompute(self) -> "G2PreComputed":        # pairing.rs:676
         return G2PreComputed(self)
+
+    def endomorphism(self) -> "G2Affine":           # GroupTrait::endomorphism = psi (g2.rs:140-152); panics upstream if the image is off-curve
+        xy, inf, st = engine().g2_psi(self.xy, self.infinity)
+        _raise_status(st)
+        return G2Affine(xy, inf)
+
+    @classmethod
+    def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g2.rs:204-240): a random r-torsion point (generator * random scalar)
+        return cls.generator(n) * engine().xoshiro_fp_soa(seed, n).T.copy()
+
+    def to_be_bytes(self):                         # g2.rs:319-359
+        return engine().g2_to_be_bytes(self.xy, self.infinity)
+
+    @classmethod
+    def from_be_bytes(cls, blobs):                 # g2.rs:361-433 (decode + on-curve + subgroup)
+        xy, inf, st = engine().g2_from_be_bytes(list(blobs))
+        _raise_status(st)
+        return cls(xy, inf)
 
 
 G2Projective = G2Affine
@@ -222,6 +271,19 @@ class Fr:
     def inv(self): return Fr(engine().fr_inv(self.v))
     def __eq__(self, o): return (self.v == o.v).all(axis=1)
 
+    @classmethod
+    def from_be_bytes(cls, blobs):                 # Fr::from_be_bytes (fp.rs:746-778): none for v >= r
+        v, st = engine().fr_from_be_bytes(list(blobs))
+        _raise_status(st)
+        return cls(v)
+
+    def to_be_bytes(self):
+        return engine().fr_to_be_bytes(self.v)
+
+    @classmethod
+    def rand(cls, n=1, seed=0):                    # FieldExtensionTrait::rand, seeded: a uniform Fp draw reduced mod r
+        return cls(engine().fr_add(engine().xoshiro_fp_soa(seed, n).T.copy(), np.zeros((n, 4), dtype=np.uint64)))
+
 
 def aggregate(points: "G1Affine", weights: "Fr", n_jobs: int, n_terms: int) -> "G1Affine":
     """sum_i weights[j,i] * points[j,i] per job (examples/threshold_signing.rs:124-143); rows are term-major
@@ -237,8 +299,10 @@ class G2PreComputed:
         self.q = q
         self.coeffs = engine().g2_precompute(q.xy)
 
-    def miller_loop(self, g1: G1Affine) -> MillerLoopResult:     # pairing.rs:590-619
-        return MillerLoopResult(engine().miller_loop(g1.xy, self.q.xy))
+    def miller_loop(self, g1: G1Affine, table_idx=None) -> MillerLoopResult:     # pairing.rs:590-619
+        """Consumes the cached tables (no G2 arithmetic): element i pairs g1[i] with table table_idx[i] (default: table i), so
+        ONE precomputed key serves any number of G1 points."""
+        return MillerLoopResult(engine().miller_loop_precomputed(self.coeffs, g1.xy, table_idx))
 
 
 def glued_miller_loop(g2s, g1s: G1Affine, offsets=None) -> MillerLoopResult:
@@ -247,6 +311,8 @@ def glued_miller_loop(g2s, g1s: G1Affine, offsets=None) -> MillerLoopResult:
     q = g2s.q if isinstance(g2s, G2PreComputed) else g2s
     if offsets is None:
         offsets = [0, min(len(g1s), len(q))]               # zip truncates (pairing.rs:975)
+    if isinstance(g2s, G2PreComputed) and len(g1s) == len(q):          # the cached tables are consumed as they are
+        return MillerLoopResult(engine().glued_miller_loop_precomputed(g2s.coeffs, g1s.xy, offsets))
     return MillerLoopResult(engine().glued_miller_loop(g1s.xy, q.xy, offsets))
 
 
@@ -270,6 +336,19 @@ def verify_same_signer(pubkey: G2Affine, msgs, sig: G1Affine) -> np.ndarray:
     """examples/verify_multiple_messages_same_signer.rs:41-60: one key, many (message, signature) pairs."""
     assert len(pubkey) == 1
     return engine().bls_verify_same_signer(pubkey.xy, list(msgs), sig.xy, pubkey.infinity, sig.infinity).astype(bool)
+
+
+class KeyTable:
+    """One signer's `G2PreComputed` kept ON THE DEVICE across calls (examples/verify_multiple_messages_same_signer.rs:41-60):
+    built once, then every `verify` is two table-driven Miller loops with no G2 arithmetic."""
+
+    def __init__(self, pubkey: G2Affine):
+        assert len(pubkey) == 1
+        self.infinity = pubkey.infinity
+        self.table = engine().g2_line_table(pubkey.xy)
+
+    def verify(self, msgs, sig: G1Affine) -> np.ndarray:
+        return engine().bls_verify_line_table(self.table, list(msgs), sig.xy, self.infinity, sig.infinity).astype(bool)
 
 
 def sign(k, msgs) -> G1Affine:

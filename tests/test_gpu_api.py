@@ -119,3 +119,51 @@ def test_bilinearity(api):
     t = api.fp([R.R_ORDER - 1] * n)                                                       # -Fr::ONE
     assert not (a == api.Gt.identity(n)).any()
     assert (((a * t) + a) == api.Gt.identity(n)).all()
+
+
+def test_rand_endomorphism_and_wire_formats(api):
+    """GroupTrait::{rand, endomorphism} and the wire formats through the API mirror: g2.rs:140-152 (psi(Q) = [p]Q on the
+    r-torsion), g1.rs:151-280 / g2.rs:319-433 round trips, fp.rs:686-778 rejections (the shapes of groups/mod.rs's
+    `test_g1_serialisation` / `test_g2_serialisation` and fp.rs:821-826)."""
+    from helpers import P
+    from oracle import pyref as R
+    n = 24
+    p, q = api.G1Projective.rand(n, seed=11), api.G2Projective.rand(n, seed=12)
+    assert not p.is_zero().any() and not q.is_zero().any()
+    assert (api.G1Projective.rand(n, seed=11) == p).all() and not (api.G1Projective.rand(n, seed=13) == p).all()
+    assert len(api.G2Affine.new(q.xy)) == n                                            # rand lands in the r-torsion (g2.rs:204-240)
+    assert (q.endomorphism() == q * api.fp([P % R.R_ORDER] * n)).all()                 # psi acts as multiplication by p mod r
+    assert (api.G2Affine.zero(3).endomorphism().is_zero()).all()                       # psi(identity) = identity (g2.rs:141-143)
+    assert (api.G1Affine.from_be_bytes(p.to_be_bytes()) == p).all()
+    assert (api.G2Affine.from_be_bytes(q.to_be_bytes()) == q).all()
+    blob = bytearray(p.to_be_bytes()[0]); blob[63] ^= 1                                # y + 1: off the curve
+    with pytest.raises(api.GroupError, match="NotOnCurve"):
+        api.G1Affine.from_be_bytes([bytes(blob)])
+    with pytest.raises(api.GroupError, match="DecodeError"):
+        api.G1Affine.from_be_bytes([P.to_bytes(32, "big") + (2).to_bytes(32, "big")])   # x = p: not a canonical residue
+    v, is_some = api.fp_from_be_bytes([P.to_bytes(32, "big"), (P - 1).to_bytes(32, "big")])
+    assert is_some.tolist() == [False, True] and api.fp_to_be_bytes(v) == [(0).to_bytes(32, "big"), (P - 1).to_bytes(32, "big")]
+    with pytest.raises(api.GroupError, match="DecodeError"):
+        api.Fr.from_be_bytes([R.R_ORDER.to_bytes(32, "big")])                          # the case reth_bn128.rs:150 unwraps
+    s = api.Fr.rand(n, seed=5)
+    assert (api.Fr.from_be_bytes(s.to_be_bytes()) == s).all()
+
+
+def test_key_table_and_cached_precompute(api):
+    """examples/verify_multiple_messages_same_signer.rs:41-60 with the key's table cached across calls, and one cached
+    G2PreComputed serving many G1 points (pairing.rs:556-619)."""
+    rng = Xoshiro(SEED + 57)
+    sk = api.fp([rng.fp()])
+    pk = api.G2Projective.generator(1) * sk
+    key = api.KeyTable(pk)
+    for rnd in range(2):
+        msgs = [bytes([rnd, i]) for i in range(9)]
+        sig = api.sign(np.repeat(sk, 9, 0), msgs)
+        assert key.verify(msgs, sig).all()
+        assert not key.verify(msgs[::-1], sig)[:4].any()
+    pre = pk.precompute()
+    p = api.G1Projective.rand(7, seed=3)
+    ml = pre.miller_loop(p, table_idx=np.zeros(7, dtype=np.uint64))
+    assert (ml.final_exponentiation() == api.pairing(p, api.G2Affine(np.repeat(pk.xy, 7, 0)))).all()
+    g = api.glued_miller_loop(api.G2Affine(np.repeat(pk.xy, 7, 0)).precompute(), p)
+    assert (g.final_exponentiation() == api.glued_pairing(p, api.G2Affine(np.repeat(pk.xy, 7, 0)))).all()
