@@ -133,24 +133,49 @@ __global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* 
 }
 
 // ------------------------------------------------------------------ Gt * Fr ---------------------------------------------------
-// Mul<&Fr> for &Gt (gt.rs:161-187): the reference's 256-step signed-digit square-and-multiply on generic Fp12 squares and
-// products (exact for any input), negative digits multiply by the conjugate.  Wave-uniform: every step squares; a step
-// multiplies when any lane of the wavefront has a non-zero digit, lanes with a zero digit multiply by one.
+// Mul<&Fr> for &Gt (gt.rs:161-187): the reference walks the 256 signed digits of fp.rs:653-662 MSB first, squaring every step and
+// multiplying by g (digit +1) or conj(g) (digit -1).  Fp12 is commutative, so its result is exactly g^(K+) * conj(g)^(K-) with
+// K+ / K- the integers formed by the +1 / -1 digits -- for ANY input, unitary or not.  That value is computed here with fixed
+// 4-digit windows: a window of a non-adjacent form holds at most two non-zero digits, 21 patterns in all, so the table is
+// {1, g^1, g^2, g^4, g^5, g^8, g^9, g^10}, their conjugates, and six mixed entries g^i conj(g)^j (3 squarings + 6 products, the
+// rest are conjugations); then 63 x (4 squarings + 1 product), every lane multiplying at every window (no divergence).  256 squarings
+// + 63 + 9 products instead of a wave-uniform product at nearly every one of the 256 steps.
+BN_DEV int gt_window_slot(u32 wp, u32 wm) {
+  // slot of g^wp alone: wp in {0,1,2,4,5,8,9,10} -> 0..7 (nibble table); conj(g)^wm alone -> 7 + that; mixed patterns 15..20
+  const u64 nib = 0x0000076500430210ull;                           // nibble v = slot of g^v: 1->1 2->2 4->3 5->4 8->5 9->6 10->7
+  const u32 sp = (u32)((nib >> (4 * wp)) & 15u), sm = (u32)((nib >> (4 * wm)) & 15u);
+  int slot = wm == 0 ? (int)sp : (int)(7u + sm);
+  if (wp != 0 && wm != 0) {
+    slot = (wp == 8 && wm == 2) ? 15 : (wp == 8 && wm == 1) ? 16 : (wp == 4 && wm == 1) ? 17 : (wp == 2 && wm == 8) ? 18 : (wp == 1 && wm == 8) ? 19 : 20;   // (1, 4)
+  }
+  return slot;
+}
 __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
-  S12 sa;
-  load_s12(sa, g, n, ii, odd);
-  W12 a, na, one, res;
-  w12_from_s12(a, sa);
-  na = w12_conj(a);
+  W12 tab[21];
   {
-    S12 so = s12_one();
-    w12_from_s12(one, so);
+    S12 sa, so = s12_one();
+    load_s12(sa, g, n, ii, odd);
+    w12_from_s12(tab[0], so);
+    w12_from_s12(tab[1], sa);
   }
-  res = one;
+  tab[2] = w12_sqr(tab[1]);                  // g^2
+  tab[3] = w12_sqr(tab[2]);                  // g^4
+  w12_mul_nl(tab[4], tab[3], tab[1]);        // g^5
+  tab[5] = w12_sqr(tab[3]);                  // g^8
+  w12_mul_nl(tab[6], tab[5], tab[1]);        // g^9
+  w12_mul_nl(tab[7], tab[5], tab[2]);        // g^10
+#pragma unroll 1
+  for (int j = 1; j <= 7; ++j) tab[7 + j] = w12_conj(tab[j]);
+  w12_mul_nl(tab[15], tab[5], tab[9]);       // g^8 conj(g)^2
+  w12_mul_nl(tab[16], tab[5], tab[8]);       // g^8 conj(g)^1
+  w12_mul_nl(tab[17], tab[3], tab[8]);       // g^4 conj(g)^1
+  tab[18] = w12_conj(tab[15]);               // g^2 conj(g)^8
+  tab[19] = w12_conj(tab[16]);               // g^1 conj(g)^8
+  tab[20] = w12_conj(tab[17]);               // g^1 conj(g)^4
   // digits of fp.rs:653-662 on the raw 256-bit scalar
   u32 k[8], xh[8], x3[8], np[8], nm[8];
   {
@@ -165,20 +190,19 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
   for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
-#pragma unroll 1
-  for (int b = 255; b >= 0; --b) {
-    res = w12_sqr(res);
-    const bool bp = (np[b >> 5] >> (b & 31)) & 1, bm = (nm[b >> 5] >> (b & 31)) & 1;
-    if (__any(bp || bm)) {
-      W12 m;
-      W2* mc[6] = {&m.c0.c0, &m.c0.c1, &m.c0.c2, &m.c1.c0, &m.c1.c1, &m.c1.c2};
-      const W2* ac[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
-      const W2* nc[6] = {&na.c0.c0, &na.c0.c1, &na.c0.c2, &na.c1.c0, &na.c1.c1, &na.c1.c2};
-      const W2* oc[6] = {&one.c0.c0, &one.c0.c1, &one.c0.c2, &one.c1.c0, &one.c1.c1, &one.c1.c2};
+  auto window = [&](int w) {
+    u32 wp = 0, wm = 0;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) *mc[q] = w2_select(w2_select(*oc[q], *nc[q], bm), *ac[q], bp);
-      w12_mul_nl(res, res, m);
-    }
+    for (int j = 0; j < 8; ++j) if (j == (w >> 3)) { wp = (np[j] >> (4 * (w & 7))) & 15u; wm = (nm[j] >> (4 * (w & 7))) & 15u; }
+    return gt_window_slot(wp, wm);
+  };
+  W12 res = tab[window(63)];
+#pragma unroll 1
+  for (int w = 62; w >= 0; --w) {
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) res = w12_sqr(res);
+    const W12 m = tab[window(w)];
+    w12_mul_nl(res, res, m);
   }
   S12 sr;
   w12_to_s12(sr, res);

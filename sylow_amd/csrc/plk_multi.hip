@@ -31,7 +31,7 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 #pragma unroll 1
   while (wave_max(next < hi ? 1 : 0)) {
     int k = 0;
-#pragma unroll 1
+#pragma unroll(KMAX == 2 ? 2 : 1)
     for (int slot = 0; slot < KMAX; ++slot) {
       bool have = false;
       size_t idx = 0;
@@ -69,35 +69,55 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
       const bool lv = s.live;
       f = w12_sparse_mul(f, w2_select(w_one, l0, lv), w2_select(w_zero, w2_scale(l1, s.py), lv), w2_select(w_zero, w2_scale(l2, s.px), lv));
     };
+    // per-pair bodies.  KMAX == 2 (the BLS / ecPairing shape) spells the two slots out, so that their states are plain values the
+    // register allocator can keep in VGPRs (spilling only the once-per-step operands); larger KMAX walks the slots in the stack frame
+    auto step_dbl = [&](PairStateW& s) { g2_doubling_step29(s.r, l0, l1, l2, twist_b); apply(s); };
+    auto step_add = [&](PairStateW& s, bool neg) {
+      const W2 by = neg ? w2_neg(s.qy) : s.qy;
+      g2_addition_step29(s.r, s.qx, by, l0, l1, l2);
+      apply(s);
+    };
+    auto step_frob = [&](PairStateW& s, int step) {
+      S2 q1x, q1y, q2x, q2y;
+      g2_psi_affine(q1x, q1y, s.qxs, s.qys);
+      g2_psi_affine(q2x, q2y, q1x, q1y);
+      const bool qi = s.qinf;
+      q1x = s2_select(q1x, s.qxs, qi); q1y = s2_select(q1y, s.qys, qi);
+      q2x = s2_select(q2x, s.qxs, qi); q2y = s2_select(q2y, s.qys, qi);
+      if (step == 0) g2_addition_step29(s.r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+      else g2_addition_step29(s.r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+      apply(s);
+    };
 #pragma unroll 1
     for (int i = 0; i < 64; ++i) {
       f = w12_sqr(f);
+      if constexpr (KMAX == 2) {
+        step_dbl(st[0]);
+        if (kw > 1) step_dbl(st[1]);
+      } else {
 #pragma unroll 1
-      for (int j = 0; j < kw; ++j) { g2_doubling_step29(st[j].r, l0, l1, l2, twist_b); apply(st[j]); }
+        for (int j = 0; j < kw; ++j) step_dbl(st[j]);
+      }
       if ((nz >> (63 - i)) & 1) {
         const bool neg = (ng >> (63 - i)) & 1;
+        if constexpr (KMAX == 2) {
+          step_add(st[0], neg);
+          if (kw > 1) step_add(st[1], neg);
+        } else {
 #pragma unroll 1
-        for (int j = 0; j < kw; ++j) {
-          const W2 by = neg ? w2_neg(st[j].qy) : st[j].qy;
-          g2_addition_step29(st[j].r, st[j].qx, by, l0, l1, l2);
-          apply(st[j]);
+          for (int j = 0; j < kw; ++j) step_add(st[j], neg);
         }
       }
     }
     // the two Frobenius additions; endomorphism() returns self for the identity (g2.rs:141-143)
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
+      if constexpr (KMAX == 2) {
+        step_frob(st[0], step);
+        if (kw > 1) step_frob(st[1], step);
+      } else {
 #pragma unroll 1
-      for (int j = 0; j < kw; ++j) {
-        S2 q1x, q1y, q2x, q2y;
-        g2_psi_affine(q1x, q1y, st[j].qxs, st[j].qys);
-        g2_psi_affine(q2x, q2y, q1x, q1y);
-        const bool qi = st[j].qinf;
-        q1x = s2_select(q1x, st[j].qxs, qi); q1y = s2_select(q1y, st[j].qys, qi);
-        q2x = s2_select(q2x, st[j].qxs, qi); q2y = s2_select(q2y, st[j].qys, qi);
-        if (step == 0) g2_addition_step29(st[j].r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
-        else g2_addition_step29(st[j].r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
-        apply(st[j]);
+        for (int j = 0; j < kw; ++j) step_frob(st[j], step);
       }
     }
     w12_mul_nl(acc, acc, f);
@@ -247,6 +267,9 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
+  // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
+  // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
+  if (n_pairs <= 2 * n_jobs) { plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED(); }
   plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
 }
 int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
@@ -361,6 +384,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
     if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
+    else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
   }
   if (rc == SYLOW_HIP_OK) k_evm_pair_finalize<<<GRID(n_jobs)>>>(pst, pair_offsets, n_jobs, isone, result, status);

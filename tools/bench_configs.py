@@ -6,9 +6,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sylow_amd
-from bench import limbs_row, rand_scalars_soa, make_points, G1, G2
+from bench import limbs_row, make_points, G1, G2
 
 eng = sylow_amd.Engine(0)
+rand_scalars_soa = lambda seed, n: eng.xoshiro_fp_soa(seed, n)
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,6 +52,12 @@ for k in (2, 4):
     # pairs laid out with SoA stride = n (>= nj*k): reuse p, q
     t = timed(lambda: eng._call("sylow_hip_multi_pairing_batch", p.ptr, None, q.ptr, None, off.ptr, nj, n, 1, None, iso.ptr), 2)
     res[f"ecpairing_2^16_k{k}"] = {"jobs_per_s": nj / t, "pairs_per_s": nj * k / t}
+# Gt * Fr (gt.rs:161-187), 2^18 elements
+ng = 1 << 18
+gk = eng.empty((4, ng)).upload(rand_scalars_soa(77, ng)); go = eng.empty((48, ng))
+gin = eng.empty((48, ng)).upload(np.ascontiguousarray(gt.download()[:, :ng]))
+t = timed(lambda: eng._call("sylow_hip_gt_pow_batch", gin.ptr, gk.ptr, go.ptr, ng), 2)
+res["gt_pow_2^18"] = {"per_s": ng / t}
 # hash / sign / verify 2^18
 nv = 1 << 18
 rng = np.random.default_rng(3)

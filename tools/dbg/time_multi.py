@@ -1,0 +1,24 @@
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch, sylow_amd
+from bench import make_points
+eng = sylow_amd.Engine(0)
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+n = 1 << 18
+p, q, ka, kb = make_points(eng, n, 5)
+gt = eng.empty((48, n)); iso = eng.empty((n,), np.uint8)
+print("pairing 2^18: %.2f ms" % timed(lambda: eng._call("sylow_hip_pairing_batch", p.ptr, None, q.ptr, None, gt.ptr, n)))
+for k in (1, 2, 3, 4):
+    nj = n // k
+    off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
+    t = timed(lambda: eng._call("sylow_hip_multi_pairing_batch", p.ptr, None, q.ptr, None, off.ptr, nj, nj * k, 1, gt.ptr, iso.ptr))
+    print("multi k=%d jobs=%d (n_pairs=%d): %.2f ms  -> %.2f M jobs/s, per 2^18 jobs %.1f ms" % (k, nj, nj * k, t, nj / t / 1e3, t * n / nj))
+    if k == 2:   # force the 4-slot instantiation through a larger declared stride
+        t = timed(lambda: eng._call("sylow_hip_multi_pairing_batch", p.ptr, None, q.ptr, None, off.ptr, nj, n, 1, gt.ptr, iso.ptr))
+        print("multi k=2 via <4> (stride %d): %.2f ms" % (n, t))
