@@ -64,11 +64,17 @@ BN_DEV F29 f29_norm(const F29& a) {
 }
 
 // ---- Montgomery product, R' = 2^261 ----------------------------------------------------------------------
-// Column sums are split over two accumulators (merged once per column) so that consecutive multiply-adds are
-// independent (a dependent v_mad_*64 chain issues at 4.75 instead of 4.19 cycles at 2 waves/SIMD).
+// ONE 64-bit accumulator is carried through all 17 columns: every partial product is a v_mad_i64_i32 whose addend is the running
+// sum, the carry of a column (acc >> 29) is the addend of the next column's first product.  Left to itself the compiler starts
+// each column from zero and merges the carry with an extra 64-bit add (17 x v_lshl_add_u64, quarter rate); BN_CHAIN -- an empty,
+// input-only volatile asm: the running value must exist at that point, no instruction is emitted -- pins the chain.  Measured on
+// the lane-pair product leaf at 2 waves/SIMD (tools/ubench/dot2_bench.hip, alternating A/B): 4-5 % faster than the two-accumulator
+// column form, whose point was instruction-level parallelism the two resident waves already provide (schedules with 4..24-long
+// dependent runs time the same).
 // History: on the one-element-per-lane kernels this core executed 27 % fewer VALU instructions in the f^x loops but ran only
 // 4.5 % faster -- those kernels were bound by scratch traffic (an Fp12 on this core is 108 VGPRs), not by issue; on lane
 // pairs (bn254_pair29.hpp) the kernel is issue-bound and the instruction saving shows up in full.
+#define BN_CHAIN(x) asm volatile("" ::"v"(x))
 // requires L(a) L(b) <= 2.5; output normalized
 BN_DEV F29 f29_mul(const F29& a, const F29& b) {
   i32 p[9]; f29_p(p);
@@ -77,19 +83,17 @@ BN_DEV F29 f29_mul(const F29& a, const F29& b) {
   i64 acc = 0;
 #pragma unroll
   for (int k = 0; k < 17; ++k) {
-    i64 x = acc, y = 0;
     const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
 #pragma unroll
-    for (int i = lo; i <= hi; ++i) { if ((i - lo) & 1) y += (i64)a.v[i] * b.v[k - i]; else x += (i64)a.v[i] * b.v[k - i]; }
+    for (int i = lo; i <= hi; ++i) { acc += (i64)a.v[i] * b.v[k - i]; BN_CHAIN(acc); }
 #pragma unroll
     for (int i = lo; i <= hi; ++i) {
       if (k < 9 && i == k) continue;                   // m[k] is not known yet
-      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+      acc += (i64)m[i] * p[k - i]; BN_CHAIN(acc);
     }
-    acc = x + y;
     if (k < 9) {
       m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
-      acc += (i64)m[k] * p[0];
+      acc += (i64)m[k] * p[0]; BN_CHAIN(acc);
     } else {
       r.v[k - 9] = (i32)((u32)acc & BN_M29);
     }
@@ -107,19 +111,20 @@ BN_DEV F29 f29_dot2(const F29& a, const F29& b, const F29& c, const F29& d) {
   i64 acc = 0;
 #pragma unroll
   for (int k = 0; k < 17; ++k) {
-    i64 x = acc, y = 0;
     const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
 #pragma unroll
-    for (int i = lo; i <= hi; ++i) { x += (i64)a.v[i] * b.v[k - i]; y += (i64)c.v[i] * d.v[k - i]; }
+    for (int i = lo; i <= hi; ++i) {
+      acc += (i64)a.v[i] * b.v[k - i]; BN_CHAIN(acc);
+      acc += (i64)c.v[i] * d.v[k - i]; BN_CHAIN(acc);
+    }
 #pragma unroll
     for (int i = lo; i <= hi; ++i) {
       if (k < 9 && i == k) continue;
-      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+      acc += (i64)m[i] * p[k - i]; BN_CHAIN(acc);
     }
-    acc = x + y;
     if (k < 9) {
       m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
-      acc += (i64)m[k] * p[0];
+      acc += (i64)m[k] * p[0]; BN_CHAIN(acc);
     } else {
       r.v[k - 9] = (i32)((u32)acc & BN_M29);
     }
@@ -249,20 +254,18 @@ BN_DEV F29 f29_sqr(const F29& a) {
   i64 acc = 0;
 #pragma unroll
   for (int k = 0; k < 17; ++k) {
-    i64 x = acc, y = 0;
     const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
 #pragma unroll
-    for (int i = lo; 2 * i < k; ++i) { if ((i - lo) & 1) y += (i64)a.v[i] * a2[k - i]; else x += (i64)a.v[i] * a2[k - i]; }
-    if ((k & 1) == 0) y += (i64)a.v[k / 2] * a.v[k / 2];
+    for (int i = lo; 2 * i < k; ++i) { acc += (i64)a.v[i] * a2[k - i]; BN_CHAIN(acc); }
+    if ((k & 1) == 0) { acc += (i64)a.v[k / 2] * a.v[k / 2]; BN_CHAIN(acc); }
 #pragma unroll
     for (int i = lo; i <= hi; ++i) {
       if (k < 9 && i == k) continue;
-      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+      acc += (i64)m[i] * p[k - i]; BN_CHAIN(acc);
     }
-    acc = x + y;
     if (k < 9) {
       m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
-      acc += (i64)m[k] * p[0];
+      acc += (i64)m[k] * p[0]; BN_CHAIN(acc);
     } else {
       r.v[k - 9] = (i32)((u32)acc & BN_M29);
     }

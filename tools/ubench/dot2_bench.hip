@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #include "bn254_pair29.hpp"
 using namespace bn254;
 using namespace bn254::pl;
@@ -106,6 +107,129 @@ BN_DEV F29 dot2_v3(const F29& a, const F29& b, const F29& c, const F29& d) {
   return r;
 }
 
+// ---- V4: ONE accumulator carried through all 17 columns (no per-column merge add): every multiply-add is written as inline
+// asm so that the compiler cannot restart each column from zero; 17 x v_lshl_add_u64 fewer, but one long dependent chain
+#define MADI(acc, x, y) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
+#define MADU(acc, x, y) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(y) : "vcc")
+BN_DEV F29 dot2_v4(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { MADI(acc, a.v[i], b.v[k - i]); MADI(acc, c.v[i], d.v[k - i]); }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      MADU(acc, m[i], p[k - i]);
+    }
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      MADU(acc, m[k], p[0]);
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+// ---- V5: two chains in asm (even / odd products), merged once per column: the shipped structure without relying on the compiler
+BN_DEV F29 dot2_v5(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+    i64 y = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { MADI(acc, a.v[i], b.v[k - i]); MADI(y, c.v[i], d.v[k - i]); }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      if ((i - lo) & 1) MADU(acc, m[i], p[k - i]); else MADU(y, m[i], p[k - i]);
+    }
+    acc += y;
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      MADU(acc, m[k], p[0]);
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+
+// ---- V6: V4 with the multiply-add's carry-out sent to a scratch SGPR pair the compiler allocates (no vcc clobber: the compiler
+// pads every vcc-clobbering asm statement with s_nop)
+#define MADI6(acc, x, y) asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(x), "v"(y))
+#define MADU6(acc, x, y) asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(x), "s"(y))
+BN_DEV F29 dot2_v6(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+  u64 sink;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { MADI6(acc, a.v[i], b.v[k - i]); MADI6(acc, c.v[i], d.v[k - i]); }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      MADU6(acc, m[i], p[k - i]);
+    }
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      MADU6(acc, m[k], p[0]);
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+
+// ---- V7: one accumulator carried through all columns, plain C multiply-adds, an EMPTY input-only volatile asm after each (the
+// value must exist at that point; an in/out operand instead makes the compiler pad every fence with s_nop) so that the compiler
+// can neither re-associate the sum nor restart a column from zero (no instruction is emitted for a fence)
+#define FENCE(x) asm volatile("" :: "v"(x))
+BN_DEV F29 dot2_v7(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { acc += (i64)a.v[i] * b.v[k - i]; FENCE(acc); acc += (i64)c.v[i] * d.v[k - i]; FENCE(acc); }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      acc += (i64)m[i] * p[k - i]; FENCE(acc);
+    }
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      acc += (i64)m[k] * p[0]; FENCE(acc);
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+
 template <int V>
 BN_NOINLINE F29 leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
                      i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
@@ -118,6 +242,10 @@ BN_NOINLINE F29 leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32
   if (V == 0) return f29_dot2(a, B0, x2, B1);
   if (V == 1) return dot2_v1(a, B0, x2, B1);
   if (V == 2) return dot2_v2(a, B0, x2, B1);
+  if (V == 4) return dot2_v4(a, B0, x2, B1);
+  if (V == 5) return dot2_v5(a, B0, x2, B1);
+  if (V == 6) return dot2_v6(a, B0, x2, B1);
+  if (V == 7) return dot2_v7(a, B0, x2, B1);
   return dot2_v3(a, B0, x2, B1);
 }
 
@@ -162,15 +290,26 @@ int main() {
   u32 *din, *dout; hipMalloc(&din, h.size() * 4); hipMalloc(&dout, 9 * (size_t)n * 4);
   hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   std::vector<u32> r0, r;
-  for (int rep = 0; rep < 2; ++rep) {
-    run<0, 1>("V0 shipped column form", din, dout, n, r0);
-    run<1, 1>("V1 two accumulators kept apart", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
-    run<2, 1>("V2 products first, then reduction", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
-    run<3, 1>("V3 three accumulators", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
-    run<0, 0>("V0 shipped column form", din, dout, n, r0);
-    run<1, 0>("V1 two accumulators kept apart", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
-    run<2, 0>("V2 products first, then reduction", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
-    run<3, 0>("V3 three accumulators", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  // correctness of every variant against the shipped form
+  run<0, 1>("V0 shipped column form", din, dout, n, r0);
+  run<1, 1>("V1 two accumulators kept apart", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  run<2, 1>("V2 products first, then reduction", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  run<3, 1>("V3 three accumulators", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  run<4, 1>("V4 one chained accumulator (asm)", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  run<7, 1>("V7 one chained accumulator, fences", din, dout, n, r); printf("   equal=%d\n", (int)(r == r0));
+  // A/B: alternate the variants 12 times (the clock drifts with load: compare minima and medians, not single runs)
+  const int R = 12;
+  std::vector<double> t[2][4];
+  for (int rep = 0; rep < R; ++rep) {
+    t[1][0].push_back(run<0, 1>("V0", din, dout, n, r)); t[1][1].push_back(run<2, 1>("V2", din, dout, n, r));
+    t[1][2].push_back(run<4, 1>("V4", din, dout, n, r)); t[1][3].push_back(run<7, 1>("V7", din, dout, n, r));
+    t[0][0].push_back(run<0, 0>("V0", din, dout, n, r)); t[0][1].push_back(run<2, 0>("V2", din, dout, n, r));
+    t[0][2].push_back(run<4, 0>("V4", din, dout, n, r)); t[0][3].push_back(run<7, 0>("V7", din, dout, n, r));
+  }
+  const char* nm[4] = {"V0 shipped", "V2 products first", "V4 chained (asm)", "V7 chained (fences)"};
+  for (int dep = 1; dep >= 0; --dep) for (int v = 0; v < 4; ++v) {
+    std::sort(t[dep][v].begin(), t[dep][v].end());
+    printf("SUMMARY dep=%d %-22s min %7.1f  median %7.1f ns per leaf call per SIMD\n", dep, nm[v], t[dep][v][0], t[dep][v][R / 2]);
   }
   return 0;
 }
