@@ -38,7 +38,11 @@ BN_DEV F29 sel9(bool odd, const F29& if_even, const F29& if_odd) {
   for (int i = 0; i < 9; ++i) r.v[i] = odd ? if_odd.v[i] : if_even.v[i];
   return r;
 }
-BN_DEV F29 f29_reduce(const F29& a) { return f29_reduce_from([&](int i) { return (i64)a.v[i]; }); }
+BN_DEV F29 f29_reduce(const F29& a) {
+  const F29* const x[1] = {&a};
+  const i32 k[1] = {bn_keep(1)};
+  return f29_reduce_terms(x, k);
+}
 
 // ---- leaves: 18 scalar ABI arguments (two 9-limb structs would travel through the stack) -----------------------------
 // even lane: a0 b0 - a1 b1;  odd lane: a1 b0 + a0 b1.  Operands R / N / D.  Output N, |V| < (VaVb + Va'Vb')/169 + 1.
@@ -120,8 +124,14 @@ BN_DEV W2 w2_lin2(const W2& a, int ka, const W2& b, int kb) { return W2{f29_lin2
 // reduce(k xi x + m y): this lane's coordinate of xi x is 9 x -/+ (partner's x)
 BN_DEV W2 w2_xi_lin(const W2& x, int k, const W2& y, int m) {
   const F29 xo = xchg9(x.c);
-  const i32 s = lane_odd() ? 1 : -1;
-  return W2{f29_reduce_from([&](int i) { return ((i64)x.c.v[i] * 9 + (i64)xo.v[i] * s) * k + (i64)y.c.v[i] * m; })};
+  if (m == 0) {                                   // a compile-time constant at every call site
+    const F29* const t[2] = {&x.c, &xo};
+    const i32 c[2] = {bn_keep(9 * k), bn_keep_v(lane_odd() ? k : -k)};
+    return W2{f29_reduce_terms(t, c)};
+  }
+  const F29* const t[3] = {&x.c, &xo, &y.c};
+  const i32 c[3] = {bn_keep(9 * k), bn_keep_v(lane_odd() ? k : -k), bn_keep(m)};
+  return W2{f29_reduce_terms(t, c)};
 }
 
 // ---- conversions (saturated lane-pair <-> carry-free lane-pair) ---------------------------------------------------
@@ -236,7 +246,9 @@ BN_DEV W12 w12_sparse_mul(const W12& f, const W2& x0, const W2& x4, const W2& x2
   o.c1.c1 = w2_xi_lin(p52, 1, w2_sub(w2_sub(q04, d0), d4), 1);                               // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
   {                                                                                          // (z1+z3+z5)(x0+x2+x4) - all six cross products
     const W2 sa = w2_add(w2_add(p12, p54), p10), sb = w2_add(w2_add(p34, p30), p52);         // each < 3 * 2^29: fits int32
-    o.c1.c2 = W2{f29_reduce_from([&](int i) { return (i64)qs.c.v[i] - sa.c.v[i] - sb.c.v[i]; })};
+    const F29* const t[3] = {&qs.c, &sa.c, &sb.c};
+    const i32 c[3] = {bn_keep(1), bn_keep(-1), bn_keep(-1)};
+    o.c1.c2 = W2{f29_reduce_terms(t, c)};
   }
   return o;
 }
