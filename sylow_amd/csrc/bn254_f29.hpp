@@ -75,6 +75,10 @@ BN_DEV F29 f29_norm(const F29& a) {
 // 4.5 % faster -- those kernels were bound by scratch traffic (an Fp12 on this core is 108 VGPRs), not by issue; on lane
 // pairs (bn254_pair29.hpp) the kernel is issue-bound and the instruction saving shows up in full.
 #define BN_CHAIN(x) asm volatile("" ::"v"(x))
+// the same pin for code that is inlined next to loads / stores: a volatile asm orders memory operations around it (scratch and
+// LDS reads could no longer be hoisted across the chain), an in/out operand does not -- at the price of an s_nop the compiler
+// adds after each one
+#define BN_CHAIN_NV(x) asm("" : "+v"(x))
 // requires L(a) L(b) <= 2.5; output normalized
 BN_DEV F29 f29_mul(const F29& a, const F29& b) {
   i32 p[9]; f29_p(p);
@@ -125,6 +129,39 @@ BN_DEV F29 f29_dot2(const F29& a, const F29& b, const F29& c, const F29& d) {
     if (k < 9) {
       m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
       acc += (i64)m[k] * p[0]; BN_CHAIN(acc);
+    } else {
+      r.v[k - 9] = (i32)((u32)acc & BN_M29);
+    }
+    acc >>= 29;
+  }
+  r.v[8] = (i32)acc;
+  return r;
+}
+
+// The two-accumulator column form of the same pass (the column's products are split over two sums that are merged once per column,
+// the carry joins at the end): 16 more instructions than the chained form but short dependent runs.  The chained form wins wherever
+// both resident waves spend their time in product leaves (the pairing kernels: -3.6 %); the G2 group law (few leaf calls between
+// carry normalisations, waves out of step) measured 5 % FASTER on this form, so OpsW2 keeps it (plk_group.hip).
+BN_DEV F29 f29_dot2_ilp(const F29& a, const F29& b, const F29& c, const F29& d) {
+  i32 p[9]; f29_p(p);
+  i32 m[9];
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+    i64 x = acc, y = 0;
+    const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) { x += (i64)a.v[i] * b.v[k - i]; y += (i64)c.v[i] * d.v[k - i]; }
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      if (k < 9 && i == k) continue;
+      if ((i - lo) & 1) x += (i64)m[i] * p[k - i]; else y += (i64)m[i] * p[k - i];
+    }
+    acc = x + y;
+    if (k < 9) {
+      m[k] = (i32)(((u32)acc * BN_PINV29) & BN_M29);
+      acc += (i64)m[k] * p[0];
     } else {
       r.v[k - 9] = (i32)((u32)acc & BN_M29);
     }

@@ -102,6 +102,17 @@ BN_NOINLINE F29 w2_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 
   // even: a0 b0 + (-a1) b1;  odd: a1 b0 + a0 b1
   return f29_dot2(a, B0, x2, B1);
 }
+// the same product on the two-accumulator column form (f29_dot2_ilp): used by the G2 group law
+BN_NOINLINE F29 w2_mul_ilp_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
+                                i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
+  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
+  const i32 m = lane_odd() ? 0 : -1;
+  const F29 B0 = dpp_pick9(b, false), B1 = dpp_pick9(b, true);
+  F29 x2 = dpp_xor9(a, m);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x2.v[i] -= m;
+  return f29_dot2_ilp(a, B0, x2, B1);
+}
 // even lane: (a0 + a1)(a0 - a1);  odd lane: a0 * 2 a1.  Operand limbs non-negative (R / N).  Output N.
 BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8) {
   const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
@@ -110,6 +121,7 @@ BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 
   return f29_mul(sel9(odd, f29_add(a, o), o), sel9(odd, f29_sub(a, o), f29_dbl(a)));   // L(x) L(y) = 2
 }
 BN_DEV W2 w2_mul(const W2& a, const W2& b) { return W2{w2_mul_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
+BN_DEV W2 w2_mul_ilp(const W2& a, const W2& b) { return W2{w2_mul_ilp_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
 BN_DEV W2 w2_sqr(const W2& a) { return W2{w2_sqr_leaf(W_ARGS(a.c))}; }
 BN_DEV W2 w2_scale(const W2& a, const F29& k) { return W2{f29_mul_leaf(W_ARGS(a.c), W_ARGS(k))}; }
 

@@ -13,12 +13,12 @@ struct OpsW2 {
   static BN_DEV F add(const F& a, const F& b) { return w2_norm(w2_add(a, b)); }
   static BN_DEV F sub(const F& a, const F& b) { return w2_norm(w2_sub(a, b)); }
   static BN_DEV F neg(const F& a) { return w2_norm(w2_neg(a)); }
-  static BN_DEV F mul(const F& a, const F& b) { return w2_mul(a, b); }
+  static BN_DEV F mul(const F& a, const F& b) { return w2_mul_ilp(a, b); }       // two-accumulator leaf: 5 % faster here (bn254_f29.hpp)
   static BN_DEV F zero() { return W2{OpsF29::zero()}; }
   static BN_DEV F one() { return W2{sel9(lane_odd(), OpsF29::one(), OpsF29::zero())}; }
   static BN_DEV bool is_zero(const F& a) { return s2_is_zero(w2_to_s2(a)); }
   static BN_DEV F select(const F& a, const F& b, bool c) { return w2_select(a, b, c); }
-  static BN_DEV F mul_b3(const F& a) { return w2_mul(a, w2_const(C_TWIST_B3)); }
+  static BN_DEV F mul_b3(const F& a) { return w2_mul_ilp(a, w2_const(C_TWIST_B3)); }
 };
 typedef Proj<W2> G2Q;
 BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
