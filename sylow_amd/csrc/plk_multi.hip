@@ -20,7 +20,6 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
   size_t next = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
-  const W2 twist_b = w2_const(C_TWIST_B);
   W12 acc;
   {
     S12 one = s12_one();
@@ -71,7 +70,7 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
     };
     // per-pair bodies.  KMAX == 2 (the BLS / ecPairing shape) spells the two slots out, so that their states are plain values the
     // register allocator can keep in VGPRs (spilling only the once-per-step operands); larger KMAX walks the slots in the stack frame
-    auto step_dbl = [&](PairStateW& s) { g2_doubling_step29(s.r, l0, l1, l2, twist_b); apply(s); };
+    auto step_dbl = [&](PairStateW& s) { g2_doubling_step29(s.r, l0, l1, l2); apply(s); };
     auto step_add = [&](PairStateW& s, bool neg) {
       const W2 by = neg ? w2_neg(s.qy) : s.qy;
       g2_addition_step29(s.r, s.qx, by, l0, l1, l2);

@@ -32,7 +32,6 @@ __global__ void k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
   if (qxy) { qxs = load_s2(qxy, n, idx, 0, odd); qys = load_s2(qxy, n, idx, 8, odd); }
   i32* tb = table;
   const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
-  const W2 twist_b = w2_const(C_TWIST_B);
   G2W r{qx, qy, w2_from_s2(s2_one())};
   W2 l0, l1, l2;
   int at = 0;
@@ -44,7 +43,7 @@ __global__ void k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
-    g2_doubling_step29(r, l0, l1, l2, twist_b); put();
+    g2_doubling_step29(r, l0, l1, l2); put();
     if ((nz >> (63 - i)) & 1) { g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(); }
   }
   S2 q1x, q1y, q2x, q2y;
@@ -141,7 +140,6 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const S2 qys = (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd);
   const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
-  const W2 twist_b = w2_const(C_TWIST_B);
   G2W r{qx, qy, w_one};
   W12 f;
   {
@@ -163,7 +161,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   for (int it = 0; it < 64; ++it) {
     f = w12_sqr(f);
     lineA();
-    if (!PK_TABLE) g2_doubling_step29(r, l0, l1, l2, twist_b);
+    if (!PK_TABLE) g2_doubling_step29(r, l0, l1, l2);
     lineB();
     ++idx;
     if ((nz >> (63 - it)) & 1) {
