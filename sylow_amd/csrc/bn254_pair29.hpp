@@ -455,7 +455,7 @@ BN_NOINLINE void miller_loop29(S12& fout, const Fp& pxs, const Fp& pys, const S2
   w12_to_s12(fout, f);
 }
 
-// ---- final exponentiation: easy part saturated (one inversion), hard part carry-free ------------------------------
+// ---- final exponentiation, all of it on the carry-free core (one Fp inversion inside the easy part) -----------------------
 BN_NOINLINE void w12_mul_nl(W12& r, const W12& a, const W12& b) { r = w12_mul(a, b); }
 BN_NOINLINE void w12_cyclotomic_sqr_nl(W12& r, const W12& a) { r = w12_cyclotomic_sqr(a); }
 template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) { r = w12_frobenius<E>(a); }
@@ -490,14 +490,44 @@ BN_NOINLINE void exp_by_neg_z29(W12& r, const W12& f) {
   }
   r = w12_conj(res);
 }
+// ---- inversion on the carry-free lane-pair core (the easy part's f^-1): fp2.rs:355-360, fp6.rs:415-423, fp12.rs:281-286 -------------
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2): each lane squares its coordinate, the pair's sum is inverted in Fp (safegcd on the
+// saturated Montgomery form: f29_to_fp / f29_from_fp only change the Montgomery factor), each lane scales its coordinate, the odd lane
+// negates.  Input R / N, output N.  inv(0) = 0 like the reference.
+BN_DEV W2 w2_inv(const W2& a) {
+  const F29 t = f29_mul_leaf(W_ARGS(a.c), W_ARGS(a.c));
+  const F29 n = f29_norm(f29_add(t, xchg9(t)));                       // a0^2 + a1^2 on both lanes, |V| < 2.1
+  const F29 i = f29_reduce(f29_from_fp(fp_inv(f29_to_fp(n))));
+  const F29 r = f29_mul_leaf(W_ARGS(a.c), W_ARGS(i));
+  return W2{sel9(lane_odd(), r, f29_norm(f29_neg(r)))};
+}
+BN_DEV W2 w2_mul_xi(const W2& a) { return w2_xi_lin(a, 1, a, 0); }     // R
+BN_DEV W6 w6_inv(const W6& a) {                                          // input R / N, output N
+  const W2 t0 = w2_sub(w2_sqr(a.c0), w2_mul(a.c1, w2_mul_xi(a.c2)));    // D-class differences of two N values: fine as product operands
+  const W2 t1 = w2_sub(w2_mul_xi(w2_sqr(a.c2)), w2_mul(a.c0, a.c1));
+  const W2 t2 = w2_sub(w2_sqr(a.c1), w2_mul(a.c0, a.c2));
+  const W2 d = w2_xi_lin(w2_add(w2_mul(a.c2, t1), w2_mul(a.c1, t2)), 1, w2_mul(a.c0, t0), 1);
+  const W2 di = w2_inv(d);
+  return W6{w2_mul(di, t0), w2_mul(di, t1), w2_mul(di, t2)};
+}
+BN_NOINLINE void w12_inv_nl(W12& r, const W12& a) {
+  const W6 s0 = w6_mul(a.c0, a.c0), s1 = w6_mul(a.c1, a.c1);           // R
+  // c0^2 - v c1^2 with v (x0, x1, x2) = (xi x2, x0, x1); normalised: w6_inv squares its coefficients
+  const W6 d{w2_norm(w2_sub(s0.c0, w2_mul_xi(s1.c2))), w2_norm(w2_sub(s0.c1, s1.c0)), w2_norm(w2_sub(s0.c2, s1.c1))};
+  const W6 t = w6_inv(d);
+  r.c0 = w6_mul(a.c0, t);
+  const W6 m = w6_mul(a.c1, t);
+  r.c1 = W6{w2_norm(w2_neg(m.c0)), w2_norm(w2_neg(m.c1)), w2_norm(w2_neg(m.c2))};
+}
 BN_NOINLINE void final_exponentiation29(S12& out, const S12& fin) {
   W12 in, t, a, b, d, e, g;
-  {
-    S12 sa = s12_conj(fin), sb = s12_inv(fin), st, su;
-    s12_mul_nl(st, sa, sb);
-    s12_frobenius_nl<2>(sa, st);
-    s12_mul_nl(su, sa, st);
-    w12_from_s12(in, su);
+  {   // easy part (pairing.rs:410-430): f^(p^6 - 1) = conj(f) f^-1, then ^(p^2 + 1) = frobenius^2(.) * (.)
+    w12_from_s12(t, fin);
+    w12_inv_nl(b, t);
+    a = w12_conj(t);
+    w12_mul_nl(d, a, b);
+    w12_frobenius_nl<2>(a, d);
+    w12_mul_nl(in, a, d);
   }
   exp_by_neg_z29(a, in);
   w12_cyclotomic_sqr_nl(b, a);
