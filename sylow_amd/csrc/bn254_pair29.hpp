@@ -50,13 +50,13 @@ BN_DEV F29 f29_reduce(const F29& a) {
 //   B0 = b0 on both lanes = even ? own b : partner's b      (vcc = even lanes)
 //   B1 = b1 on both lanes = odd  ? own b : partner's b      (vcc = odd lanes)
 //   X2 = partner's a, negated on even lanes                 ((x ^ m) - m with m = even ? -1 : 0)
-// 36 instructions instead of the 54 of exchange-then-select.  s_nop 4 covers the VALU-write -> DPP-read hazards at block entry
+// 36 instructions instead of the 54 of exchange-then-select.  s_nop 1 (two wait states) covers the VALU-write -> DPP-read hazard at block entry
 // (the assembler does not see into inline asm).
 #define BN_DPP_SWAP "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 BN_DEV F29 dpp_pick9(const F29& b, bool own_on_odd) {
   F29 r;
   if (own_on_odd) {
-    asm("s_nop 4\n\ts_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+    asm("s_nop 1\n\ts_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
         "v_cndmask_b32_dpp %0, %9, %9, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %1, %10, %10, vcc " BN_DPP_SWAP "\n\t"
         "v_cndmask_b32_dpp %2, %11, %11, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %3, %12, %12, vcc " BN_DPP_SWAP "\n\t"
         "v_cndmask_b32_dpp %4, %13, %13, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %5, %14, %14, vcc " BN_DPP_SWAP "\n\t"
@@ -66,7 +66,7 @@ BN_DEV F29 dpp_pick9(const F29& b, bool own_on_odd) {
         : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8])
         : "vcc");
   } else {
-    asm("s_nop 4\n\ts_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"
+    asm("s_nop 1\n\ts_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"
         "v_cndmask_b32_dpp %0, %9, %9, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %1, %10, %10, vcc " BN_DPP_SWAP "\n\t"
         "v_cndmask_b32_dpp %2, %11, %11, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %3, %12, %12, vcc " BN_DPP_SWAP "\n\t"
         "v_cndmask_b32_dpp %4, %13, %13, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %5, %14, %14, vcc " BN_DPP_SWAP "\n\t"
@@ -81,7 +81,7 @@ BN_DEV F29 dpp_pick9(const F29& b, bool own_on_odd) {
 // (partner's a) ^ m, one instruction per limb
 BN_DEV F29 dpp_xor9(const F29& a, i32 m) {
   F29 r;
-  asm("s_nop 4\n\t"
+  asm("s_nop 1\n\t"
       "v_xor_b32_dpp %0, %9, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %1, %10, %18 " BN_DPP_SWAP "\n\t"
       "v_xor_b32_dpp %2, %11, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %3, %12, %18 " BN_DPP_SWAP "\n\t"
       "v_xor_b32_dpp %4, %13, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %5, %14, %18 " BN_DPP_SWAP "\n\t"
