@@ -49,3 +49,33 @@ def test_fuzz_target_invariants(api, coracle):
     sk = fr()
     pk = api.G2Projective.generator(N) * sk
     assert api.verify(pk, data, api.sign(sk, data)).all()
+
+
+def test_gt_pow_exact_for_any_fp12_and_every_window_pattern(engine, coracle):
+    """Mul<&Fr> for &Gt on the window-table algorithm (plk_group.hip): the reference's digit walk yields g^(K+) conj(g)^(K-) for ANY
+    Fp12 input (gt.rs:161-187 uses the conjugate as the inverse without checking that g is unitary), so random NON-unitary
+    inputs must match the oracle's 256-step walk bit for bit; scalars chosen to hit all 21 four-digit NAF patterns, the digit
+    carry out of bit 255 (dropped by the reference's 256-bit arithmetic as well) and a ragged batch size."""
+    from helpers import rand_fp_array
+    rng = Xoshiro(SEED + 81)
+    special = [0, 1, 2, 3, 5, 7, 9, 11, 13, 15, (1 << 256) - 1, 1 << 255, (1 << 255) - 1, R.R_ORDER, R.R_ORDER - 1,
+               int("a" * 64, 16), int("5" * 64, 16), int("3" * 64, 16), int("b" * 64, 16), int("d" * 64, 16), int("9" * 64, 16), int("69" * 32, 16)]
+    scalars = special + [rng.u256() for _ in range(37 + 64 - len(special))]
+    n = len(scalars)
+    g = rand_fp_array(rng, n, 12)                       # arbitrary Fp12 values: not unitary, not even in the cyclotomic subgroup
+    k = limbs(scalars)
+    got = engine.gt_pow(g, k)
+    assert np.array_equal(got, coracle.gt_pow(g, k))
+    # every pattern of the table was exercised by this scalar set
+    seen = set()
+    for x in scalars:
+        xh = x >> 1
+        x3 = (x + xh) & ((1 << 256) - 1)
+        c = xh ^ x3
+        np_, nm_ = x3 & c, xh & c
+        for w in range(64):
+            seen.add(((np_ >> (4 * w)) & 15, (nm_ >> (4 * w)) & 15))
+    assert len(seen) == 21
+    # g^0 = 1 and g^1 = g for any g
+    one = np.zeros(48, dtype=np.uint64); one[0] = 1
+    assert np.array_equal(got[0], one) and np.array_equal(got[1], g[1])
