@@ -41,6 +41,11 @@ def _worker(rank, world, port, bad_index, q):
 
     flags, (lo, hi), ok = sharding.verify_sharded(fake_verify, pk, msgs, sig, dist)
     full = sharding.gather_flags(flags, n, dist)
+    # the reduce bench.py uses on its device flag word, and its MAX-over-ranks clock
+    import torch
+    word = sharding.and_reduce_(torch.tensor([int(flags.all())], dtype=torch.int32), dist)
+    slowest = sharding.max_over_ranks(1.0 + rank, dist)
+    assert int(word.item()) == int(ok) and slowest == 2.0 and sharding.collective_device(dist).type == "cpu"
     q.put((rank, lo, hi, int(ok), bool(np.array_equal(full, truth))))
     dist.barrier()
     dist.destroy_process_group()
