@@ -139,15 +139,17 @@ __global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* 
 // 4-digit windows: a window of a non-adjacent form holds at most two non-zero digits, 21 patterns in all, so the table is
 // {1, g^1, g^2, g^4, g^5, g^8, g^9, g^10}, their conjugates, and six mixed entries g^i conj(g)^j (3 squarings + 6 products, the
 // rest are conjugations); then 63 x (4 squarings + 1 product), every lane multiplying at every window (no divergence).  256 squarings
-// + 63 + 9 products instead of a wave-uniform product at nearly every one of the 256 steps.
-BN_DEV int gt_window_slot(u32 wp, u32 wm) {
-  // slot of g^wp alone: wp in {0,1,2,4,5,8,9,10} -> 0..7 (nibble table); conj(g)^wm alone -> 7 + that; mixed patterns 15..20
+// + 63 + 6 products instead of a wave-uniform product at nearly every one of the 256 steps.
+// Only one of each conjugate pair of entries is stored (the scratch pool holds two waves per SIMD only up to 4 KB per lane, and
+// 21 Fp12 values are 4.5 KB): slot 0 = 1, slots 1..7 = g^{1,2,4,5,8,9,10}, slots 8..10 = g^8 conj(g)^2, g^8 conj(g), g^4 conj(g);
+// a pattern with the roles of g and conj(g) swapped reads the same slot and conjugates it (conj is a ring automorphism).
+BN_DEV int gt_window_slot(u32 wp, u32 wm, bool& conj) {
   const u64 nib = 0x0000076500430210ull;                           // nibble v = slot of g^v: 1->1 2->2 4->3 5->4 8->5 9->6 10->7
   const u32 sp = (u32)((nib >> (4 * wp)) & 15u), sm = (u32)((nib >> (4 * wm)) & 15u);
-  int slot = wm == 0 ? (int)sp : (int)(7u + sm);
-  if (wp != 0 && wm != 0) {
-    slot = (wp == 8 && wm == 2) ? 15 : (wp == 8 && wm == 1) ? 16 : (wp == 4 && wm == 1) ? 17 : (wp == 2 && wm == 8) ? 18 : (wp == 1 && wm == 8) ? 19 : 20;   // (1, 4)
-  }
+  conj = wp < wm;                                                    // the larger part picks the orientation (never equal unless both 0)
+  const u32 hi = conj ? wm : wp, lo = conj ? wp : wm;
+  int slot = (int)(conj ? sm : sp);
+  if (lo != 0) slot = (hi == 8 && lo == 2) ? 8 : (hi == 8 && lo == 1) ? 9 : 10;                       // (4, 1)
   return slot;
 }
 __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
@@ -155,7 +157,7 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
   const int odd = (int)(t & 1);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
-  W12 tab[21];
+  W12 tab[11];
   {
     S12 sa, so = s12_one();
     load_s12(sa, g, n, ii, odd);
@@ -168,14 +170,12 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
   tab[5] = w12_sqr(tab[3]);                  // g^8
   w12_mul_nl(tab[6], tab[5], tab[1]);        // g^9
   w12_mul_nl(tab[7], tab[5], tab[2]);        // g^10
-#pragma unroll 1
-  for (int j = 1; j <= 7; ++j) tab[7 + j] = w12_conj(tab[j]);
-  w12_mul_nl(tab[15], tab[5], tab[9]);       // g^8 conj(g)^2
-  w12_mul_nl(tab[16], tab[5], tab[8]);       // g^8 conj(g)^1
-  w12_mul_nl(tab[17], tab[3], tab[8]);       // g^4 conj(g)^1
-  tab[18] = w12_conj(tab[15]);               // g^2 conj(g)^8
-  tab[19] = w12_conj(tab[16]);               // g^1 conj(g)^8
-  tab[20] = w12_conj(tab[17]);               // g^1 conj(g)^4
+  {
+    const W12 c1 = w12_conj(tab[1]), c2 = w12_conj(tab[2]);
+    w12_mul_nl(tab[8], tab[5], c2);          // g^8 conj(g)^2
+    w12_mul_nl(tab[9], tab[5], c1);          // g^8 conj(g)
+    w12_mul_nl(tab[10], tab[3], c1);         // g^4 conj(g)
+  }
   // digits of fp.rs:653-662 on the raw 256-bit scalar
   u32 k[8], xh[8], x3[8], np[8], nm[8];
   {
@@ -190,18 +190,23 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
   for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
-  auto window = [&](int w) {
+  auto entry = [&](int w) {                  // the table value of window w: g^(K+ window) conj(g)^(K- window)
     u32 wp = 0, wm = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (j == (w >> 3)) { wp = (np[j] >> (4 * (w & 7))) & 15u; wm = (nm[j] >> (4 * (w & 7))) & 15u; }
-    return gt_window_slot(wp, wm);
+    bool cj;
+    const W12 m = tab[gt_window_slot(wp, wm, cj)];
+    const W12 mc = w12_conj(m);
+    W12 r = m;
+    r.c1.c0 = w2_select(m.c1.c0, mc.c1.c0, cj); r.c1.c1 = w2_select(m.c1.c1, mc.c1.c1, cj); r.c1.c2 = w2_select(m.c1.c2, mc.c1.c2, cj);
+    return r;
   };
-  W12 res = tab[window(63)];
+  W12 res = entry(63);
 #pragma unroll 1
   for (int w = 62; w >= 0; --w) {
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) res = w12_sqr(res);
-    const W12 m = tab[window(w)];
+    const W12 m = entry(w);
     w12_mul_nl(res, res, m);
   }
   S12 sr;

@@ -11,16 +11,16 @@ struct PairStateW { G2W r; W2 qx, qy; S2 qxs, qys; F29 px, py; bool qinf, live; 
 constexpr int KMAXW = 4;        // ecPairing / glued jobs (a few pairs each)
 constexpr int KPROD = 8;        // batch-wide product: more pairs per shared squaring
 
+// the raw glued Miller value of this lane pair's job [next, hi), any number of pairs.
+// Out of line ON PURPOSE: the stack frame of a kernel is its own frame plus the deepest callee chain, so with the Miller part
+// inlined next to the call of final_exponentiation29 the two frames ADD (4.3 - 6.1 KB per lane); as siblings they overlap
+// (max instead of sum).  That matters beyond spill traffic: the runtime's scratch pool holds 2 waves per SIMD only up to
+// 4 KB per lane (512 MB / 2048 waves / 64 lanes) -- measured: at 4.3 KB k_multi_pairing ran 89 % of k_pairing's wave
+// occupancy, the 6.1 KB product kernel 65 %.
 template <int KMAX>
-__global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
-                                             const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
-                                             u64* gout, uint8_t* is_one, int raw_miller) {
-  const size_t t = TID, job = t >> 1;
-  const int odd = (int)(t & 1);
-  const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
-  size_t next = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
+BN_NOINLINE void glued_miller_chunks(W12& acc, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                size_t next, size_t hi, size_t n_pairs, int skip_infinity, int odd) {
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
-  W12 acc;
   {
     S12 one = s12_one();
     w12_from_s12(acc, one);
@@ -121,6 +121,87 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
     }
     w12_mul_nl(acc, acc, f);
   }
+}
+
+// Jobs of at most TWO pairs (the BLS check e(sig, G2gen) e(-H, pk) and the k = 2 ecPairing shape), when every job of the wavefront
+// is that small: one chunk, so no running product, and the two pair states are plain values -- the structure of the fused
+// verifier (plk_verify.hip) with both G2 points general.  Slot A is pair `lo`, slot B pair `lo + 1`; a missing or skipped pair is
+// a dead slot (generator point, unit line), exactly like the generic schedule, so the value is the same bit for bit.
+BN_NOINLINE void glued_miller_upto2(W12& f, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                               size_t lo, size_t hi, size_t n_pairs, int skip_infinity, int odd) {
+  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  auto setup = [&](PairStateW& s, size_t idx) {
+    const bool exists = idx < hi;
+    const size_t src = exists ? idx : 0;
+    const bool pi = exists && pinf && pinf[src], qi0 = exists && qinf && qinf[src];
+    const bool have = exists && !(skip_infinity && (pi || qi0));
+    const bool ld = have && n_pairs != 0;
+    s.live = have;
+    s.qinf = have && qi0;
+    s.px = f29_reduce(f29_from_fp(ld ? load_fp(pxy, n_pairs, src, 0) : fp_one()));
+    s.py = f29_reduce(f29_from_fp(ld ? load_fp(pxy, n_pairs, src, 4) : fp_one()));
+    s.qxs = ld ? load_s2(qxy, n_pairs, src, 0, odd) : s2_g2gen_x();
+    s.qys = ld ? load_s2(qxy, n_pairs, src, 8, odd) : s2_g2gen_y();
+    s.qx = w2_from_s2(s.qxs);
+    s.qy = w2_from_s2(s.qys);
+    s.r = G2W{s.qx, s.qy, s.qinf ? w_zero : w_one};
+  };
+  PairStateW A, B;
+  setup(A, lo);
+  setup(B, lo + 1);
+  // a skipped first pair leaves slot A dead and B live: both slots are walked whenever any lane has a live B
+  const bool anyA = wave_max(A.live ? 1 : 0) != 0, anyB = wave_max(B.live ? 1 : 0) != 0;
+  if (!anyA && !anyB) return;
+  W2 l0, l1, l2;
+  auto apply = [&](const PairStateW& s) {
+    const bool lv = s.live;
+    f = w12_sparse_mul(f, w2_select(w_one, l0, lv), w2_select(w_zero, w2_scale(l1, s.py), lv), w2_select(w_zero, w2_scale(l2, s.px), lv));
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    f = w12_sqr(f);
+    if (anyA) { g2_doubling_step29(A.r, l0, l1, l2); apply(A); }
+    if (anyB) { g2_doubling_step29(B.r, l0, l1, l2); apply(B); }
+    if ((nz >> (63 - i)) & 1) {
+      const bool neg = (ng >> (63 - i)) & 1;
+      if (anyA) { g2_addition_step29(A.r, A.qx, neg ? w2_neg(A.qy) : A.qy, l0, l1, l2); apply(A); }
+      if (anyB) { g2_addition_step29(B.r, B.qx, neg ? w2_neg(B.qy) : B.qy, l0, l1, l2); apply(B); }
+    }
+  }
+  auto frob = [&](PairStateW& s, int step) {        // endomorphism() returns self for the identity (g2.rs:141-143)
+    S2 q1x, q1y, q2x, q2y;
+    g2_psi_affine(q1x, q1y, s.qxs, s.qys);
+    g2_psi_affine(q2x, q2y, q1x, q1y);
+    const bool qi = s.qinf;
+    q1x = s2_select(q1x, s.qxs, qi); q1y = s2_select(q1y, s.qys, qi);
+    q2x = s2_select(q2x, s.qxs, qi); q2y = s2_select(q2y, s.qys, qi);
+    if (step == 0) g2_addition_step29(s.r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+    else g2_addition_step29(s.r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+    apply(s);
+  };
+#pragma unroll 1
+  for (int step = 0; step < 2; ++step) {
+    if (anyA) frob(A, step);
+    if (anyB) frob(B, step);
+  }
+}
+
+template <int KMAX>
+__global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                             const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
+                                             u64* gout, uint8_t* is_one, int raw_miller) {
+  const size_t t = TID, job = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
+  const size_t lo = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
+  W12 acc;
+  if (KMAX == 2 && wave_max((int)(hi - lo > 2 ? 3 : hi - lo)) <= 2) glued_miller_upto2(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
+  else glued_miller_chunks<KMAX>(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
   S12 fin, g;
   w12_to_s12(fin, acc);
   if (raw_miller) g = fin;                     // partial Miller product for the batch-wide reduction below

@@ -10,7 +10,7 @@ def timed(fn, reps=3):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-n = 1 << 18
+n = 1 << int(os.environ.get("LOG2N", "18"))
 p, q, ka, kb = make_points(eng, n, 5)
 gt = eng.empty((48, n)); iso = eng.empty((n,), np.uint8)
 print("pairing 2^18: %.2f ms" % timed(lambda: eng._call("sylow_hip_pairing_batch", p.ptr, None, q.ptr, None, gt.ptr, n)))
