@@ -377,39 +377,74 @@ BN_DEV W12 w12_line_product(const W2& a0, const W2& a4, const W2& a2, const W2& 
 // whole Miller loop on the carry-free core (points and accumulator).  Same lines, same digit schedule and therefore the same raw
 // value as the reference's loop (pairing.rs:590-619); the first iteration, where the accumulator is still one, starts from the
 // product of its two lines (w12_line_product) instead of squaring one and multiplying it by each line.
+// Loop-invariant operands that are read once or twice per step (P's coordinates for the two line scalings, Q's for the addition
+// steps) live in LDS, [limb][thread]: 144 bytes per lane, conflict-free 4-byte reads.  Left in registers they are the values the
+// register allocator spills, and every scratch access is waited for in full: a non-kernel function begins with s_waitcnt vmcnt(0), and
+// the product leaves are called every ~100 instructions, so each spill store or reload parks the wave for its whole L2 round trip
+// (rocprofv3: SQ_WAIT_ANY 11.5 % of the Miller kernel's wave cycles for ~65 scratch instructions per pairing, ~500 cycles each).
+// The working G2 point is parked there too while the accumulator is updated (squaring + line product: the phase that needs every
+// register); an LDS access is a short lgkmcnt wait.
+constexpr int MILLER_LDS_WORDS = 63;
+BN_DEV void lds_put9(i32 (*lds)[256], int slot, const F29& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lds[9 * slot + i][threadIdx.x] = a.v[i];
+}
+BN_DEV F29 lds_get9(i32 (*lds)[256], int slot) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = lds[9 * slot + i][threadIdx.x];
+  return r;
+}
 BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys) {
-  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
-  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);          // the y of -Q is negated on the fly (a D-class product operand): 9 registers less to keep
+  __shared__ i32 lds[MILLER_LDS_WORDS][256];                       // blocks of 256 threads (BLOCK); each thread touches only its own column
+  lds_put9(lds, 0, f29_reduce(f29_from_fp(pxs)));
+  lds_put9(lds, 1, f29_reduce(f29_from_fp(pys)));
+  {
+    const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+    lds_put9(lds, 2, qx.c);
+    lds_put9(lds, 3, qy.c);
+  }
+  auto PX = [&]() { return lds_get9(lds, 0); };
+  auto PY = [&]() { return lds_get9(lds, 1); };
+  auto QX = [&]() { return W2{lds_get9(lds, 2)}; };
+  auto QY = [&](bool neg) { const W2 y{lds_get9(lds, 3)}; return neg ? w2_neg(y) : y; };      // -Q: a D-class product operand
+  auto park = [&](const G2W& r) { lds_put9(lds, 4, r.x.c); lds_put9(lds, 5, r.y.c); lds_put9(lds, 6, r.z.c); };
+  auto unpark = [&]() { return G2W{W2{lds_get9(lds, 4)}, W2{lds_get9(lds, 5)}, W2{lds_get9(lds, 6)}}; };
   W12 f;
-  G2W r{qx, qy, w2_from_s2(s2_one())};
+  G2W r{QX(), QY(false), w2_from_s2(s2_one())};
   W2 l0, l1, l2;
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
   static_assert((BN_ATE_NAF_NZ >> 63) & 1, "the first digit of 6x+2 after the leading one is non-zero");
   {   // i = 0: f = 1, so f^2 * l_dbl * l_add is the product of the two lines
     g2_doubling_step29(r, l0, l1, l2);
-    const W2 d0 = l0, d4 = w2_scale(l1, py), d2 = w2_scale(l2, px);
-    g2_addition_step29(r, qx, ((ng >> 63) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
-    f = w12_line_product(d0, d4, d2, l0, w2_scale(l1, py), w2_scale(l2, px));
+    const W2 d0 = l0, d4 = w2_scale(l1, PY()), d2 = w2_scale(l2, PX());
+    g2_addition_step29(r, QX(), QY((ng >> 63) & 1), l0, l1, l2);
+    park(r);
+    f = w12_line_product(d0, d4, d2, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
   }
 #pragma unroll 1
   for (int i = 1; i < 64; ++i) {
+    r = unpark();
     g2_doubling_step29(r, l0, l1, l2);
+    park(r);
     f = w12_sqr(f);
-    f = w12_line29(f, l0, l1, l2, px, py);
+    f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
     if ((nz >> (63 - i)) & 1) {
-      const bool neg = (ng >> (63 - i)) & 1;
-      g2_addition_step29(r, qx, neg ? w2_neg(qy) : qy, l0, l1, l2);
-      f = w12_line29(f, l0, l1, l2, px, py);
+      r = unpark();
+      g2_addition_step29(r, QX(), QY((ng >> (63 - i)) & 1), l0, l1, l2);
+      park(r);
+      f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
     }
   }
+  r = unpark();
   S2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qxs, qys);
   g2_psi_affine(q2x, q2y, q1x, q1y);
   q2y = s2_neg(q2y);
   g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
-  f = w12_line29(f, l0, l1, l2, px, py);
+  f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
   g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(q2y), l0, l1, l2);
-  f = w12_line29(f, l0, l1, l2, px, py);
+  f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
   w12_to_s12(fout, f);
 }
 
