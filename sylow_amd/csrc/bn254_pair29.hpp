@@ -384,7 +384,7 @@ BN_DEV W12 w12_line_product(const W2& a0, const W2& a4, const W2& a2, const W2& 
 // (rocprofv3: SQ_WAIT_ANY 11.5 % of the Miller kernel's wave cycles for ~65 scratch instructions per pairing, ~500 cycles each).
 // The working G2 point is parked there too while the accumulator is updated (squaring + line product: the phase that needs every
 // register); an LDS access is a short lgkmcnt wait.
-constexpr int MILLER_LDS_WORDS = 63;
+constexpr int MILLER_LDS_WORDS = 36, MILLER_LDS_WORDS_PARK = 63;
 BN_DEV void lds_put9(i32 (*lds)[256], int slot, const F29& a) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) lds[9 * slot + i][threadIdx.x] = a.v[i];
@@ -395,8 +395,11 @@ BN_DEV F29 lds_get9(i32 (*lds)[256], int slot) {
   for (int i = 0; i < 9; ++i) r.v[i] = lds[9 * slot + i][threadIdx.x];
   return r;
 }
+// PARK: also park the working point (63 words = 64.5 KB per block of 256 threads: two blocks per CU still fit the 160 KB).  Kernels
+// that stage line tables in LDS as well (plk_verify.hip) take PARK = false (36 words), or only one block per CU would be resident.
+template <bool PARK>
 BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys) {
-  __shared__ i32 lds[MILLER_LDS_WORDS][256];                       // blocks of 256 threads (BLOCK); each thread touches only its own column
+  __shared__ i32 lds[PARK ? MILLER_LDS_WORDS_PARK : MILLER_LDS_WORDS][256];   // blocks of 256 threads (BLOCK); each thread touches only its own column
   lds_put9(lds, 0, f29_reduce(f29_from_fp(pxs)));
   lds_put9(lds, 1, f29_reduce(f29_from_fp(pys)));
   {
@@ -408,8 +411,8 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   auto PY = [&]() { return lds_get9(lds, 1); };
   auto QX = [&]() { return W2{lds_get9(lds, 2)}; };
   auto QY = [&](bool neg) { const W2 y{lds_get9(lds, 3)}; return neg ? w2_neg(y) : y; };      // -Q: a D-class product operand
-  auto park = [&](const G2W& r) { lds_put9(lds, 4, r.x.c); lds_put9(lds, 5, r.y.c); lds_put9(lds, 6, r.z.c); };
-  auto unpark = [&]() { return G2W{W2{lds_get9(lds, 4)}, W2{lds_get9(lds, 5)}, W2{lds_get9(lds, 6)}}; };
+  auto park = [&](const G2W& r) { if (PARK) { lds_put9(lds, 4, r.x.c); lds_put9(lds, 5, r.y.c); lds_put9(lds, 6, r.z.c); } };
+  auto unpark = [&](const G2W& r) { return PARK ? G2W{W2{lds_get9(lds, 4)}, W2{lds_get9(lds, 5)}, W2{lds_get9(lds, 6)}} : r; };
   W12 f;
   G2W r{QX(), QY(false), w2_from_s2(s2_one())};
   W2 l0, l1, l2;
@@ -424,19 +427,19 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   }
 #pragma unroll 1
   for (int i = 1; i < 64; ++i) {
-    r = unpark();
+    r = unpark(r);
     g2_doubling_step29(r, l0, l1, l2);
     park(r);
     f = w12_sqr(f);
     f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
     if ((nz >> (63 - i)) & 1) {
-      r = unpark();
+      r = unpark(r);
       g2_addition_step29(r, QX(), QY((ng >> (63 - i)) & 1), l0, l1, l2);
       park(r);
       f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
     }
   }
-  r = unpark();
+  r = unpark(r);
   S2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qxs, qys);
   g2_psi_affine(q2x, q2y, q1x, q1y);

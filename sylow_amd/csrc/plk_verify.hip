@@ -107,7 +107,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
   } else {
     const S2 qx = load_s2(pkxy, n, i, 0, odd), qy = load_s2(pkxy, n, i, 8, odd);
     S12 f;
-    miller_loop29g(f, hx, hy, qx, qy);
+    miller_loop29g<false>(f, hx, hy, qx, qy);
     final_exponentiation29(rhs, f);
   }
   bool eq = s2_eq(lhs.c0.c0, rhs.c0.c0) && s2_eq(lhs.c0.c1, rhs.c0.c1) && s2_eq(lhs.c0.c2, rhs.c0.c2) &&

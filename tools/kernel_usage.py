@@ -24,7 +24,11 @@ for u in units:
         if m and cur:
             rows[cur][m.group(1)] = int(m.group(2))
     print(f"== {u}.hip")
-    print(f"{'kernel':58s} {'VGPR':>5s} {'spill':>6s} {'scratch B':>10s} {'LDS B':>7s} {'waves/SIMD':>10s}")
+    print(f"{'kernel':58s} {'VGPR':>5s} {'spill':>6s} {'scratch B':>10s} {'LDS B':>7s} {'waves/SIMD':>10s} {'(LDS-limited, 256-thread blocks)':>s}")
     for k, v in rows.items():
+        lds = v.get('LDS Size [bytes/block]', 0)
+        occ = v.get('Occupancy [waves/SIMD]', 0)
+        by_lds = (160 * 1024 // lds) if lds else 99          # blocks per CU the 160 KB of LDS admit; a block of 256 threads is one wave per SIMD
+        note = f"{min(occ, by_lds):d}" + ("  <-- LDS caps the occupancy" if by_lds < occ else "")
         print(f"{k[:58]:58s} {v.get('VGPRs', 0):5d} {v.get('VGPR Spill', 0):6d} {v.get('ScratchSize [bytes/lane]', 0):10d} "
-              f"{v.get('LDS Size [bytes/block]', 0):7d} {v.get('Occupancy [waves/SIMD]', 0):10d}")
+              f"{lds:7d} {occ:10d} {note}")
