@@ -264,6 +264,41 @@ BN_DEV W12 w12_sparse_mul(const W12& f, const W2& x0, const W2& x4, const W2& x2
   }
   return o;
 }
+// f * (u + x2 v^2 + x4 v w) with u in {0, 1} (a lane-dependent int): the same formulas with x0 = u, whose products are copies.
+// Ten Fp2 products: z1 x4 + z3 x2 comes from (z1 + z3)(x2 + x4) - z1 x2 - z3 x4.  f R / N, x2 / x4 R / N.  Output R.
+BN_DEV W2 w2_xi_lin_v(const W2& x, const W2& y, i32 m) {                // reduce(xi x + m y), m lane-dependent
+  const F29 xo = xchg9(x.c);
+  const F29* const t[3] = {&x.c, &xo, &y.c};
+  const i32 c[3] = {bn_keep(9), bn_keep_v(lane_odd() ? 1 : -1), bn_keep_v(m)};
+  return W2{f29_reduce_terms(t, c)};
+}
+BN_DEV W2 w2_lin_v(const W2& x, const W2& y, i32 m) {                   // reduce(x + m y)
+  const F29* const t[2] = {&x.c, &y.c};
+  const i32 c[2] = {bn_keep(1), bn_keep_v(m)};
+  return W2{f29_reduce_terms(t, c)};
+}
+BN_DEV W12 w12_sparse_mul_unit(const W12& f, i32 u, const W2& x4, const W2& x2) {
+  const W2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
+  const W2 d2 = w2_mul(z2, x2), d4 = w2_mul(z4, x4);
+  const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p34 = w2_mul(z3, x4), p52 = w2_mul(z5, x2);
+  const W2 a02 = w2_mul(z0, x2), a04 = w2_mul(z0, x4);
+  const W2 x24 = w2_norm(w2_add(x2, x4));
+  const W2 q24 = w2_mul(w2_norm(w2_add(z2, z4)), x24);
+  const W2 q13 = w2_mul(w2_norm(w2_add(z1, z3)), x24);
+  W12 o;
+  o.c0.c0 = w2_xi_lin_v(w2_add(p12, d4), z0, u);                         // xi (z1 x2 + z4 x4) + u z0
+  o.c0.c1 = w2_xi_lin_v(w2_add(p54, d2), z1, u);                         // xi (z5 x4 + z2 x2) + u z1
+  o.c0.c2 = w2_lin_v(w2_add(a02, p34), z2, u);                           // z0 x2 + z3 x4 + u z2
+  o.c1.c0 = w2_xi_lin_v(w2_sub(w2_sub(q24, d2), d4), z3, u);             // xi (z2 x4 + z4 x2) + u z3
+  {                                                                      // xi z5 x2 + z0 x4 + u z4
+    const F29 xo = xchg9(p52.c);
+    const F29* const t[4] = {&p52.c, &xo, &a04.c, &z4.c};
+    const i32 c[4] = {bn_keep(9), bn_keep_v(lane_odd() ? 1 : -1), bn_keep(1), bn_keep_v(u)};
+    o.c1.c1 = W2{f29_reduce_terms(t, c)};
+  }
+  o.c1.c2 = w2_lin_v(w2_sub(w2_sub(q13, p12), p34), z5, u);              // z1 x4 + z3 x2 + u z5
+  return o;
+}
 // pairing.rs:274-350 (Granger-Scott), input R / N with |V| <= 1.2, output R
 BN_DEV void w_fp4_square(W2& c0, W2& c1, const W2& a, const W2& b) {
   const W2 t0 = w2_sqr(a);

@@ -29,7 +29,7 @@ struct Lease {
   ~Lease() { release(); }
 };
 // per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
-int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair layout [87][3][2][9] int32
+int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair line table (plk_common.hpp: LINE_TABLE_WORDS)
 int32_t gen_lines_sat(const u32** out, hipStream_t st);         // single-lane Montgomery layout [87][48] uint32
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 }  // namespace host
@@ -64,6 +64,7 @@ int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* ou
 }  // namespace single
 namespace plkh {        // lane-pair units
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
+size_t line_table_bytes();                                                                             // plk_verify.hip
 // plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
 }  // namespace plkh

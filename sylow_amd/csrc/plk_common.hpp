@@ -24,6 +24,11 @@ BN_DEV S2 s2_g2gen_y() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[2]), fp_con
 BN_DEV W2 w2_select(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }     // c ? b : a
 
 
-// [87][3 coefficients][2 coordinates][9 limbs] int32, R-class: G2Affine::precompute (pairing.rs:676-708) of one point
-constexpr int LINE_TABLE_WORDS = 87 * 54;
+// Line table of one G2 point (G2Affine::precompute, pairing.rs:676-708) for the verification kernels, which only need the pairing
+// up to factors the final exponentiation removes: every line (l0, l1, l2) is stored divided by l0 -- any Fp2 factor dies in the
+// easy part -- as (l1 / l0, l2 / l0) plus a unit word (1; 0 for a line whose l0 is zero, stored undivided), so the accumulator
+// update is a 10-product multiplication by (unit + x2 v^2 + x4 v w) instead of the 13-product mul_by_024.
+// Layout: [87][2 coefficients][2 coordinates][9 limbs] int32 R-class digits, then [87] unit words.
+constexpr int LINE_TABLE_LINES = 87;
+constexpr int LINE_TABLE_WORDS = LINE_TABLE_LINES * 36 + LINE_TABLE_LINES;
 }  // namespace plk

@@ -45,7 +45,8 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
 // test hook: the lane-pair Fp12 layer one operation at a time (ops 16.. of sylow_hip_fp12_hook_batch); `b` carries the second
 // operand, or the three line coefficients (ell_0, ell_vw, ell_vv) in its first 24 words for the sparse product
 enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 = 20, OPW_FROB2 = 21, OPW_FROB3 = 22, OPW_EXPZ = 23,
-       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28, OPW_LAST = 28 };
+       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28,
+       OPW_SPARSE_UNIT = 29, OPW_LAST = 29 };   // 29: first line coefficient = (element index & 1), the other two from `b` as for 18
 __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
@@ -71,6 +72,7 @@ __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* o
       case OPW_FROB2: w12_frobenius_nl<2>(r, x); break;
       case OPW_FROB3: w12_frobenius_nl<3>(r, x); break;
       case OPW_CONJ: r = w12_conj(x); break;
+      case OPW_SPARSE_UNIT: r = w12_sparse_mul_unit(x, (i32)(i & 1), y.c0.c1, y.c0.c2); break;
       default: exp_by_neg_z29(r, x); break;
     }
     w12_to_s12(sr, r);
@@ -96,7 +98,7 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
   plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
 }
 // test hook: raw Fp12 selector.  0..11: the single-lane layer (single.hip: 8 product on the carry-free core, 9 cyclotomic square on
-// it, 10 / 11 exp_by_neg_z on the carry-free / saturated core); 16..28: the lane-pair Fp12 layer (plk::k_w12_op)
+// it, 10 / 11 exp_by_neg_z on the carry-free / saturated core); 16..29: the lane-pair Fp12 layer (plk::k_w12_op)
 int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && out && op >= 0 && (op <= 11 || (op >= 16 && op <= plk::OPW_LAST))); if (!n) return SYLOW_HIP_OK;
   if (op < 16) return single::fp12_hook(op, a, b, out, n, stream);

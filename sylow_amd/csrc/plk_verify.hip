@@ -23,43 +23,65 @@ BN_DEV bool hash_to_g1_pair(Fp& hx, Fp& hy, bool& hinf, const uint8_t* msg, size
 }
 
 // ------------------------------------------------------------------ G2 line tables on the carry-free core ---------------
-// [87][3 coefficients][2 coordinates][9 limbs] int32, R-class: G2Affine::precompute (pairing.rs:676-708) of one point
-// launched with ONE lane pair: the generator (qxy == nullptr) or element idx of an SoA G2 array
-__global__ void k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
-  if (TID >= 2) return;
-  const int odd = (int)(TID & 1);
-  S2 qxs = s2_g2gen_x(), qys = s2_g2gen_y();
-  if (qxy) { qxs = load_s2(qxy, n, idx, 0, odd); qys = load_s2(qxy, n, idx, 8, odd); }
-  i32* tb = table;
-  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
-  G2W r{qx, qy, w2_from_s2(s2_one())};
-  W2 l0, l1, l2;
-  int at = 0;
-  auto put = [&]() {
-    const W2 c[3] = {l0, w2_reduce(l1), w2_reduce(l2)};
-    for (int k = 0; k < 3; ++k) for (int j = 0; j < 9; ++j) tb[((at * 3 + k) * 2 + odd) * 9 + j] = c[k].c.v[j];
-    ++at;
-  };
-  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+// Layout and normalisation: plk_common.hpp (LINE_TABLE_WORDS).  One block of LINES_BLOCK threads: lane pair 0 walks the point
+// through the 87 steps of G2Affine::precompute (pairing.rs:676-708) and leaves the raw lines in LDS, then lane pair j divides
+// line j by its first coefficient (87 independent Fp2 inversions side by side instead of 87 in a row).
+// The generator (qxy == nullptr) or element idx of an SoA G2 array.
+constexpr int LINES_BLOCK = 192;
+__global__ void __launch_bounds__(LINES_BLOCK) k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
+  __shared__ i32 raw[LINE_TABLE_LINES][3][2][9];
+  const int odd = (int)(threadIdx.x & 1);
+  if (threadIdx.x < 2) {
+    S2 qxs = s2_g2gen_x(), qys = s2_g2gen_y();
+    if (qxy) { qxs = load_s2(qxy, n, idx, 0, odd); qys = load_s2(qxy, n, idx, 8, odd); }
+    const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
+    G2W r{qx, qy, w2_from_s2(s2_one())};
+    W2 l0, l1, l2;
+    int at = 0;
+    auto put = [&]() {
+      const W2 c[3] = {l0, w2_reduce(l1), w2_reduce(l2)};
+      for (int k = 0; k < 3; ++k) for (int j = 0; j < 9; ++j) raw[at][k][odd][j] = c[k].c.v[j];
+      ++at;
+    };
+    const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    g2_doubling_step29(r, l0, l1, l2); put();
-    if ((nz >> (63 - i)) & 1) { g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(); }
+    for (int i = 0; i < 64; ++i) {
+      g2_doubling_step29(r, l0, l1, l2); put();
+      if ((nz >> (63 - i)) & 1) { g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? nqy : qy, l0, l1, l2); put(); }
+    }
+    S2 q1x, q1y, q2x, q2y;
+    g2_psi_affine(q1x, q1y, qxs, qys);
+    g2_psi_affine(q2x, q2y, q1x, q1y);
+    g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2); put();
+    g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2); put();
   }
-  S2 q1x, q1y, q2x, q2y;
-  g2_psi_affine(q1x, q1y, qxs, qys);
-  g2_psi_affine(q2x, q2y, q1x, q1y);
-  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2); put();
-  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2); put();
+  __syncthreads();
+  const int line = (int)(threadIdx.x >> 1);
+  if (line >= LINE_TABLE_LINES) return;
+  auto get = [&](int k) {
+    const i32* t = raw[line][k][odd];
+    return W2{F29{{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]}}};
+  };
+  const W2 l0 = get(0), l1 = get(1), l2 = get(2);
+  u32 nzero = 0;                                           // R-class digits are unique: the value is zero iff every limb is
+  for (int j = 0; j < 9; ++j) nzero |= (u32)l0.c.v[j];
+  nzero |= swap_u32(nzero);
+  const bool unit = nzero != 0;
+  const W2 inv = w2_inv(l0);
+  const W2 c[2] = {unit ? w2_reduce(w2_mul(l1, inv)) : l1, unit ? w2_reduce(w2_mul(l2, inv)) : l2};
+  for (int k = 0; k < 2; ++k) for (int j = 0; j < 9; ++j) table[((line * 2 + k) * 2 + odd) * 9 + j] = c[k].c.v[j];
+  if (!odd) table[LINE_TABLE_LINES * 36 + line] = unit ? 1 : 0;
 }
 // block-cooperative copy of a line table into LDS
 BN_DEV void stage_table(i32* lds, const i32* src) {
   for (int k = threadIdx.x; k < LINE_TABLE_WORDS; k += blockDim.x) lds[k] = src[k];
 }
+// coefficient c (0: l1 / l0, 1: l2 / l0) of line `at`, and its unit word
 BN_DEV W2 table_w2(const i32* tab, int at, int c, int odd) {
-  const i32* t = tab + ((at * 3 + c) * 2 + odd) * 9;
+  const i32* t = tab + ((at * 2 + c) * 2 + odd) * 9;
   return W2{F29{{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]}}};
 }
+BN_DEV i32 table_unit(const i32* tab, int at) { return tab[LINE_TABLE_LINES * 36 + at]; }
 
 // ------------------------------------------------------------------ BLS verification ----------------------------------------
 // lib.rs:223-236 as written: pairing(sig, G2gen) == pairing(H(msg), pk), two Miller loops and two final exponentiations
@@ -77,7 +99,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
   if (siginf && siginf[i]) {
     lhs = s12_one();
   } else {
-    // G2PreComputed::miller_loop (pairing.rs:590-619) against the generator's line table
+    // G2PreComputed::miller_loop (pairing.rs:590-619) against the generator's line table (lines divided by their first
+    // coefficient: the value differs from the reference's raw Miller value by an Fp2 factor, the pairing does not)
     const F29 sx = f29_reduce(f29_from_fp(load_fp(sigxy, n, i, 0))), sy = f29_reduce(f29_from_fp(load_fp(sigxy, n, i, 4)));
     W12 f;
     {
@@ -87,7 +110,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
     const u64 nz = BN_ATE_NAF_NZ;
     int idx = 0;
     auto line = [&]() {
-      f = w12_sparse_mul(f, table_w2(tabA, idx, 0, odd), w2_scale(table_w2(tabA, idx, 1, odd), sy), w2_scale(table_w2(tabA, idx, 2, odd), sx));
+      f = w12_sparse_mul_unit(f, table_unit(tabA, idx), w2_scale(table_w2(tabA, idx, 0, odd), sy), w2_scale(table_w2(tabA, idx, 1, odd), sx));
       ++idx;
     };
 #pragma unroll 1
@@ -131,16 +154,34 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
   Fp hxs, hys; bool hinf;
   hash_to_g1_pair(hxs, hys, hinf, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
-  const F29 hx = f29_reduce(f29_from_fp(hxs)), hy = f29_reduce(f29_from_fp(fp_neg(hys)));   // pair B is (-H, pk)
+  // Loop invariants that are read once or twice per step live in LDS, [limb][thread] (see miller_loop29g): the signature's and
+  // -H(m)'s coordinates for the line scalings and, without a key table, the key's for the addition steps.
+  __shared__ i32 lds[PK_TABLE ? 36 : 54][256];
   const bool liveA = !(siginf && siginf[ii]);
   const bool liveB = !(hinf || (pkinf && pkinf[PK_TABLE ? 0 : ii]));
-  const F29 sx = f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))), sy = f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4)));
+  lds_put9(lds, 0, f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))));
+  lds_put9(lds, 1, f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4))));
+  lds_put9(lds, 2, f29_reduce(f29_from_fp(hxs)));
+  lds_put9(lds, 3, f29_reduce(f29_from_fp(fp_neg(hys))));                  // pair B is (-H, pk)
+  auto SX = [&]() { return lds_get9(lds, 0); };
+  auto SY = [&]() { return lds_get9(lds, 1); };
+  auto HX = [&]() { return lds_get9(lds, 2); };
+  auto HY = [&]() { return lds_get9(lds, 3); };
   // a dead pair B steps the generator instead (any curve point keeps the arithmetic defined) and multiplies by the unit line
-  const S2 qxs = (PK_TABLE || !liveB) ? s2_g2gen_x() : load_s2(pkxy, n, ii, 0, odd);
-  const S2 qys = (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd);
-  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
+  auto key_x = [&]() { return (PK_TABLE || !liveB) ? s2_g2gen_x() : load_s2(pkxy, n, ii, 0, odd); };
+  auto key_y = [&]() { return (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd); };
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
-  G2W r{qx, qy, w_one};
+  G2W r;
+  {
+    const W2 qx = w2_from_s2(key_x()), qy = w2_from_s2(key_y());
+    if (!PK_TABLE) { lds_put9(lds, 4, qx.c); lds_put9(lds, 5, qy.c); }
+    r = G2W{qx, qy, w_one};
+  }
+  auto QX = [&]() { return W2{lds_get9(lds, PK_TABLE ? 0 : 4)}; };
+  auto QY = [&](bool neg) {
+    const W2 y{lds_get9(lds, PK_TABLE ? 0 : 5)};
+    return neg ? w2_neg(y) : y;                                             // -Q: a D-class product operand
+  };
   W12 f;
   {
     S12 one = s12_one();
@@ -149,12 +190,16 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   W2 l0, l1, l2;
   int idx = 0;
   auto lineA = [&]() {
-    const W2 a0 = table_w2(tabA, idx, 0, odd), a1 = w2_scale(table_w2(tabA, idx, 1, odd), sy), a2 = w2_scale(table_w2(tabA, idx, 2, odd), sx);
-    f = w12_sparse_mul(f, w2_select(w_one, a0, liveA), w2_select(w_zero, a1, liveA), w2_select(w_zero, a2, liveA));
+    const W2 a1 = w2_scale(table_w2(tabA, idx, 0, odd), SY()), a2 = w2_scale(table_w2(tabA, idx, 1, odd), SX());
+    f = w12_sparse_mul_unit(f, liveA ? table_unit(tabA, idx) : 1, w2_select(w_zero, a1, liveA), w2_select(w_zero, a2, liveA));
   };
   auto lineB = [&]() {
-    if (PK_TABLE) { l0 = table_w2(tabB, idx, 0, odd); l1 = table_w2(tabB, idx, 1, odd); l2 = table_w2(tabB, idx, 2, odd); }
-    f = w12_sparse_mul(f, w2_select(w_one, l0, liveB), w2_select(w_zero, w2_scale(l1, hy), liveB), w2_select(w_zero, w2_scale(l2, hx), liveB));
+    if (PK_TABLE) {
+      const W2 b1 = w2_scale(table_w2(tabB, idx, 0, odd), HY()), b2 = w2_scale(table_w2(tabB, idx, 1, odd), HX());
+      f = w12_sparse_mul_unit(f, liveB ? table_unit(tabB, idx) : 1, w2_select(w_zero, b1, liveB), w2_select(w_zero, b2, liveB));
+    } else {
+      f = w12_sparse_mul(f, w2_select(w_one, l0, liveB), w2_select(w_zero, w2_scale(l1, HY()), liveB), w2_select(w_zero, w2_scale(l2, HX()), liveB));
+    }
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
@@ -166,13 +211,13 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
     ++idx;
     if ((nz >> (63 - it)) & 1) {
       lineA();
-      if (!PK_TABLE) g2_addition_step29(r, qx, ((ng >> (63 - it)) & 1) ? nqy : qy, l0, l1, l2);
+      if (!PK_TABLE) g2_addition_step29(r, QX(), QY(((ng >> (63 - it)) & 1) != 0), l0, l1, l2);
       lineB();
       ++idx;
     }
   }
   S2 q1x, q1y, q2x, q2y;
-  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, qxs, qys); g2_psi_affine(q2x, q2y, q1x, q1y); }
+  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, key_x(), key_y()); g2_psi_affine(q2x, q2y, q1x, q1y); }   // the key is read again: 64 B instead of 16 live registers
   lineA();
   if (!PK_TABLE) g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
   lineB();
@@ -189,8 +234,9 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
 }  // namespace plk
 
 namespace plkh {
+size_t line_table_bytes() { return plk::LINE_TABLE_WORDS * sizeof(bn254::i32); }
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream) {
-  plk::k_g2_lines29<<<1, 64, 0, (hipStream_t)stream>>>(q_xy, n, idx, table); LAUNCHED();
+  plk::k_g2_lines29<<<1, plk::LINES_BLOCK, 0, (hipStream_t)stream>>>(q_xy, n, idx, table); LAUNCHED();
 }
 }  // namespace plkh
 
@@ -227,7 +273,7 @@ int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint
   host::Lease ws;
   if ((rc = ws.acquire(plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st)) != SYLOW_HIP_OK) return rc;
   bn254::i32* table = (bn254::i32*)ws.p;
-  plk::k_g2_lines29<<<1, 64, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
+  plk::k_g2_lines29<<<1, plk::LINES_BLOCK, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
   plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n);
   const hipError_t e = hipGetLastError();
   rc = ws.release();

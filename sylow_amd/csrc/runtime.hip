@@ -293,7 +293,7 @@ int32_t gen_lines29(const bn254::i32** out, hipStream_t st) {
   DevState& D = g_dev[d];
   if (!D.gen29) {
     bn254::i32* t = nullptr;
-    HIPCHK(hipMalloc((void**)&t, 87 * 54 * sizeof(bn254::i32)));
+    HIPCHK(hipMalloc((void**)&t, plkh::line_table_bytes()));
     rc = plkh::build_lines29(nullptr, 0, 0, t, st);
     // one-time: later calls may run on other streams, so the table must be complete before it is published
     hipError_t e = (rc == SYLOW_HIP_OK) ? hipStreamSynchronize(st) : hipSuccess;

@@ -1,5 +1,5 @@
 """The lane-pair Fp12 layer (bn254_pair.hpp saturated, bn254_pair29.hpp carry-free) one operation at a time through the
-fp12 hook (ops 16..28), on random inputs and on inputs crafted so that the INTERNAL 29-bit digits are extreme."""
+fp12 hook (ops 16..29), on random inputs and on inputs crafted so that the INTERNAL 29-bit digits are extreme."""
 import numpy as np
 import pytest
 
@@ -8,8 +8,16 @@ from oracle import pyref as R
 
 pytestmark = pytest.mark.gpu
 OP = {"mul": 16, "sqr": 17, "sparse": 18, "cycsqr": 19, "frob1": 20, "frob2": 21, "frob3": 22, "expz": 23,
-      "s_mul": 24, "s_sqr": 25, "s_inv": 26, "s_cycsqr": 27, "conj": 28}
+      "s_mul": 24, "s_sqr": 25, "s_inv": 26, "s_cycsqr": 27, "conj": 28, "sparse_unit": 29}
 RP_INV = pow(pow(2, 261, P), P - 2, P)           # the carry-free core holds x * 2^261 mod p
+
+
+def unit_lines(coracle, b):
+    """the line operand of op 29: first coefficient (row & 1) in Fp2, the other two as given (normalised line tables)"""
+    u = b[:, :24].copy()
+    u[:, :8] = 0
+    u[1::2, 0] = 1
+    return u
 
 
 def crafted_values():
@@ -43,6 +51,7 @@ def test_lane_pair_fp12_ops_random(engine, coracle):
     assert np.array_equal(engine.fp12_hook(OP["s_inv"], a), coracle.fp12_op("inv", a))
     assert np.array_equal(engine.fp12_hook(OP["conj"], a), coracle.fp12_op("conj", a))
     assert np.array_equal(engine.fp12_hook(OP["sparse"], a, b), coracle.fp12_sparse_mul(a, b[:, :24]))
+    assert np.array_equal(engine.fp12_hook(OP["sparse_unit"], a, b), coracle.fp12_sparse_mul(a, unit_lines(coracle, b)))
     for e in (1, 2, 3):
         assert np.array_equal(engine.fp12_hook(OP["frob%d" % e], a), coracle.fp12_op("frobenius", a, arg=e))
 
@@ -63,6 +72,7 @@ def test_lane_pair_fp12_ops_extreme_digits(engine, coracle):
     assert np.array_equal(engine.fp12_hook(OP["sqr"], a), coracle.fp12_op("sqr", a))
     assert np.array_equal(engine.fp12_hook(OP["cycsqr"], a), coracle.fp12_op("cyclotomic_squared", a))
     assert np.array_equal(engine.fp12_hook(OP["sparse"], a, b), coracle.fp12_sparse_mul(a, b[:, :24]))
+    assert np.array_equal(engine.fp12_hook(OP["sparse_unit"], a, b), coracle.fp12_sparse_mul(a, unit_lines(coracle, b)))
     for e in (1, 2, 3):
         assert np.array_equal(engine.fp12_hook(OP["frob%d" % e], a), coracle.fp12_op("frobenius", a, arg=e))
     # chains: outputs fed back as inputs keep the invariants (40 dependent squarings / products)
