@@ -400,6 +400,9 @@ BN_NOINLINE Fp fp_inv_safegcd(Fp a) {
   i32 zeta = -1;
 #pragma unroll 1
   for (int it = 0; it < 20; ++it) {
+    // g = 0 is a fixed point (f and d no longer change): random inputs get there after ~512 divsteps, so the last one or two
+    // batches are usually idle for the whole wavefront
+    if (it >= 16 && !__any((g[0] | g[1] | g[2] | g[3] | g[4] | g[5] | g[6] | g[7] | g[8]) != 0)) break;
     // 30 divsteps on the low limbs -> t = [[u, v], [q, r]] (entries in (-2^30, 2^30])
     u32 u = 1, v = 0, q = 0, r = 1, ff = (u32)f[0], gg = (u32)g[0];
 #pragma unroll 5

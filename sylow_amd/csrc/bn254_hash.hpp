@@ -141,7 +141,7 @@ __device__ inline Fp fp_from_be48(const uint8_t* b) {
 }
 
 // is_square (fp.rs:625-631: a^((p-1)/2) in {0, 1}) as a Jacobi symbol: the binary algorithm with a FIXED trip count and no
-// data-dependent branches (every lane of the wavefront runs the same 508 steps), ~60 cheap instructions per step against
+// lane-dependent branches (every lane of the wavefront runs the same steps: at most 508, in blocks of 4 until all lanes are done), ~60 cheap instructions per step against
 // the ~320-product power.  Invariant: n odd, 0 <= a; each step either halves an even a (sign flips when n = 3, 5 mod 8) or,
 // for odd a, orders the pair (quadratic reciprocity: flip when both are 3 mod 4), subtracts and halves.  bits(a) + bits(n)
 // drops every step, so 2 * 254 steps always reach a = 0 with n = gcd.  The Montgomery factor R = (2^128)^2 is a square, so
@@ -151,8 +151,13 @@ BN_NOINLINE bool fp_is_square(Fp x) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = x.v[i];
   u32 t = 0;
+#pragma unroll 1
+  for (int blk = 0; blk < 508 / 4; ++blk) {
+    // every lane whose a has reached 0 only idles from here on (t and n are final): leave as soon as the whole wavefront is there
+    // (random inputs need ~360 steps, the slowest of 64 lanes ~380; the 508 bound is for the worst case)
+    if (!__any((a[0] | a[1] | a[2] | a[3] | a[4] | a[5] | a[6] | a[7]) != 0u)) break;
 #pragma unroll 2
-  for (int it = 0; it < 508; ++it) {
+  for (int it = 0; it < 4; ++it) {
     const u32 odd = 0u - (a[0] & 1u);
     // d = a - n, lt = (a < n)
     u32 d[8];
@@ -176,6 +181,7 @@ BN_NOINLINE bool fp_is_square(Fp x) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
     a[7] >>= 1;
+  }
   }
   const bool n_is_one = (n[0] == 1u) && ((n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]) == 0u);
   return !(n_is_one && (t & 1u));
