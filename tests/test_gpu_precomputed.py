@@ -74,3 +74,30 @@ def test_same_signer_with_cached_line_table(engine):
     assert engine.bls_verify_line_table(table, msgs[:5], sig[:5]).tolist() == [1] * 5
     # identity key: pairing() semantics, the pair contributes 1 -> only e(sig, G2gen) == 1 could pass
     assert engine.bls_verify_line_table(table, msgs[:5], sig[:5], pk_inf=[1]).tolist() == [0] * 5
+
+
+def test_line_table_is_the_precompute_divided_by_its_first_coefficient(engine, coracle):
+    """The device-internal key table (sylow_hip_g2_line_table) against the oracle's G2Affine::precompute (pairing.rs:676-708):
+    every line (ell_0, ell_vw, ell_vv) is stored as (ell_vw / ell_0, ell_vv / ell_0) in 9 x 29-bit digits of v * 2^261 mod p,
+    followed by one unit word per line (1: the first coefficient is the field's one)."""
+    from helpers import P
+    rinv = pow(pow(2, 261, P), P - 2, P)
+    rng = Xoshiro(SEED + 83)
+    for trial in range(2):
+        pk, _ = engine.g2_scalar_mul(pack(G2, 16), limbs([rng.fp()]))
+        words = engine.g2_line_table(pk).download().astype(np.int64)
+        assert words.shape == (87 * 37,)
+        assert words[87 * 36:].tolist() == [1] * 87
+        got = words[:87 * 36].reshape(87, 2, 2, 9)
+        ells = coracle.from_limbs(coracle.g2_precompute(pk)[0])             # 87 x (ell_0, ell_vw, ell_vv) x (c0, c1)
+        for line in range(87):
+            e = ells[6 * line: 6 * line + 6]
+            inv = R.fp2_inv((e[0], e[1]))
+            for k in range(2):
+                want = R.fp2_mul((e[2 + 2 * k], e[3 + 2 * k]), inv)
+                for c in range(2):
+                    digits = [int(d) for d in got[line, k, c]]
+                    assert all(0 <= d < (1 << 29) for d in digits[:8])
+                    v = sum(d << (29 * j) for j, d in enumerate(digits))
+                    assert abs(v) < 0.51 * P
+                    assert v * rinv % P == want[c], (trial, line, k, c)
