@@ -244,7 +244,7 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n):
         res[f"C5_ecpairing_bytes_2^{int(np.log2(njk))}_k{k}"] = {
             "units_per_s": njk / t, "pairs_per_s": k * njk / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS,
             "pattern_ok": int(np.array_equal(r, (~spoil).astype(np.uint8)) and not d_st.download().any()),
-            "kernel": "k_evm_decode_pairs + plk::k_multi_pairing<4>"}
+            "kernel": "k_evm_decode_pairs + plk::k_multi_pairing<%d>" % (2 if k == 2 else 4)}
     return res
 
 
