@@ -237,16 +237,20 @@ int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offs
 /* sign(&Fp, &[u8]) (lib.rs:179-187): sig_i = sk_i * H(msg_i), affine out */
 int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                  uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream);
-/* verify(&G2Projective, &[u8], &G1Projective) (lib.rs:223-236): ok_i = e(sig_i, G2gen) == e(H(msg_i), pk_i) */
+/* verify(&G2Projective, &[u8], &G1Projective) (lib.rs:223-236): ok_i = [ e(sig_i, G2gen) == e(H(msg_i), pk_i) ]; identity inputs
+ * as pairing() treats them (that pairing is Gt::identity()).  Evaluated as e(sig_i, G2gen) * e(-H(msg_i), pk_i) == 1 with one
+ * shared-squaring 2-pair Miller loop and ONE final exponentiation per element (the shape of
+ * examples/verify_multiple_messages_same_signer.rs:41-60, threshold_signing.rs:92-121): FE(a) == FE(b) <=> FE(a conj(b)) == 1 and
+ * conj(miller(H, pk)) = miller(-H, pk) exactly, so the boolean is the reference's for EVERY input.  _fused_ is the same
+ * kernel under its round-1 name. */
 int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                    const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
-/* The batch-verify shape of sylow's examples (examples/verify_multiple_messages_same_signer.rs:41-60,
- * threshold_signing.rs:92-121): ok_i = [ e(sig_i, G2gen) * e(-H(msg_i), pk_i) == Gt::identity() ], one
- * shared-squaring 2-pair Miller loop and ONE final exponentiation per element; identity inputs are treated
- * as pairing() treats them (the pair contributes 1).  Same boolean as sylow_hip_bls_verify_batch for
- * points in G1 x G2 (subgroup-checked keys); ~1.5x faster. */
 int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                          const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
+/* The same boolean evaluated literally as lib.rs:223-236 writes it: two Miller loops, two final exponentiations, compare
+ * (~1.5x the time; kept as the second implementation the first is tested against, and to price the reference's shape). */
+int32_t sylow_hip_bls_verify_two_pairings_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
 /* ---- wire formats: G1Affine/G2Affine::{to,from}_be_bytes (g1.rs:151-280, g2.rs:319-433) -------------- */
 /* G1: 64 bytes x | y big-endian; G2: 128 bytes x.c1 | x.c0 | y.c1 | y.c0; bit 7 of byte 0 is the infinity flag and
  * the identity is written as (0, 1) + flag.  from_be_bytes masks the flag, then: a coordinate >= p, or a set flag

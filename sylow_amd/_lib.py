@@ -65,6 +65,7 @@ SIGNATURES = {
     "sylow_hip_hash_to_g1_batch": [c_u8p, c_u64p, ctypes.c_char_p, c_sz, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_bls_sign_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_bls_verify_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
+    "sylow_hip_bls_verify_two_pairings_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_bls_verify_fused_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_evm_ecadd_batch": [c_u8p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_evm_ecmul_batch": [c_u8p, c_u8p, c_u8p, c_sz, c_vp],

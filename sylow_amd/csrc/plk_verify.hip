@@ -241,18 +241,12 @@ int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* ta
 }  // namespace plkh
 
 extern "C" {
-int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
-  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::bls_verify(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
-  DstPrime dp; host::dst_arg(dp, nullptr, 0);
-  const bn254::i32* gen = nullptr;
-  int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
-  if (rc != SYLOW_HIP_OK) return rc;
-  plk::k_bls_verify<<<GRID(2 * n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
-}
-int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+// verify (lib.rs:223-236): pairing(sig, G2gen) == pairing(H(msg), pk).  The default entry point answers with ONE final
+// exponentiation: FE(a) == FE(b) <=> FE(a conj(b)) == 1 (FE is a homomorphism onto unitary elements, FE(conj b) = FE(b)^-1), and
+// conj(miller(H, pk)) = miller(-H, pk) line by line (negating P negates exactly the line's odd-in-w coefficient) -- for every
+// input, in the subgroup or not.  The literal two-pairing evaluation stays available as *_two_pairings_batch.
+static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                    const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::bls_verify_fused(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
@@ -260,6 +254,24 @@ int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* p
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
   if (rc != SYLOW_HIP_OK) return rc;
   plk::k_bls_verify_fused<false><<<GRID(2 * n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+}
+int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  return verify_one_final_exp(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+}
+int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  return verify_one_final_exp(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+}
+int32_t sylow_hip_bls_verify_two_pairings_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
+  ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::bls_verify(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  const bn254::i32* gen = nullptr;
+  int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_bls_verify<<<GRID(2 * n)>>>(pk_xy, pk_inf, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
 }
 int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {

@@ -488,14 +488,16 @@ class Engine:
         self._call("sylow_hip_bls_sign_batch", dsk.ptr, dm.ptr, doff.ptr, do.ptr, doi.ptr, n)
         return self.from_device_soa(do), doi.download()
 
-    def bls_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None, fused=False):
+    def bls_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None, fused=False, two_pairings=False):
+        """verify (lib.rs:223-236).  Default and `fused`: one final exponentiation per element; `two_pairings`: the literal form."""
         pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
         n = len(msgs)
         dm, doff = self._msgs(msgs)
         dpk, dsig = self.to_device_soa(pk_xy, 16), self.to_device_soa(sig_xy, 8)
         dpi, dsi = self._flags(pk_inf, n), self._flags(sig_inf, n)
         dok = self.empty((n,), np.uint8)
-        self._call("sylow_hip_bls_verify_fused_batch" if fused else "sylow_hip_bls_verify_batch", dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
+        name = "sylow_hip_bls_verify_two_pairings_batch" if two_pairings else "sylow_hip_bls_verify_fused_batch" if fused else "sylow_hip_bls_verify_batch"
+        self._call(name, dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
         return dok.download()
 
     def bls_verify_same_signer(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None):

@@ -31,14 +31,14 @@ def test_two_rank_bench_all_valid():
     assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak"
     assert out["config"]["batch_per_gpu"] == 4096 and out["value"] > 0
     aux = out["aux"]
-    assert aux["bls_all_valid"] == 1 and aux["bls_all_valid_fused"] == 1 and aux["aggregate_all_valid"] == 1
+    assert aux["bls_all_valid"] == 1 and aux["bls_all_valid_two_pairings"] == 1 and aux["aggregate_all_valid"] == 1
     assert aux["bls_verify_batch_per_gpu"] == 4096 and aux["bad_flags_this_rank"] == 0
 
 
 def test_two_rank_bench_planted_bad_signature_on_rank_1():
     out = run_bench(["--plant-bad", "1"])
     aux = out["aux"]
-    assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_fused"] == 0      # rank 0 sees rank 1's failure through the reduce
+    assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_two_pairings"] == 0      # rank 0 sees rank 1's failure through the reduce
     assert aux["bad_flags_this_rank"] == 0                                       # ... although all of rank 0's own flags are set
 
 

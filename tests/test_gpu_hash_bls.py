@@ -42,23 +42,25 @@ def test_sign_verify_vs_oracle(engine, coracle):
     exp_xy, exp_inf = coracle.g1_to_affine(coracle.sign(sk, msgs))
     assert np.array_equal(sig_xy, exp_xy) and np.array_equal(sig_inf, exp_inf)
     pk_xy, pk_inf = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
-    assert engine.bls_verify(pk_xy, msgs, sig_xy).tolist() == [1] * n              # lib.rs:29-42 round trip
-    # planted corruption pattern: wrong message, sig + G1gen, wrong key
     bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
     plant = np.zeros(n, dtype=bool)
     plant[[1, 7, 13]] = True
     mixed = np.where(plant[:, None], bad_sig, sig_xy)
-    got = engine.bls_verify(pk_xy, msgs, mixed)
-    assert got.tolist() == (~plant).astype(int).tolist()
     pk_proj = np.concatenate([pk_xy, np.repeat(pack([1, 0], 8), n, 0)], axis=1)
     sig_proj = np.concatenate([mixed, np.repeat(limbs([1]), n, 0)], axis=1)
-    assert np.array_equal(got, coracle.verify(pk_proj[:8], msgs[:8], sig_proj[:8]).tolist() + got[8:].tolist())
-    assert engine.bls_verify(pk_xy, msgs[::-1], sig_xy).sum() <= 1                 # only a palindromic position could match
-    assert engine.bls_verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy).tolist() == [0] * n
-    # infinity signature / key: pairing() maps them to the identity (pairing.rs:876-886) -> both sides must be 1 to pass
     inf = np.ones(n, dtype=np.uint8)
-    assert engine.bls_verify(pk_xy, msgs, sig_xy, sig_inf=inf).tolist() == [0] * n
-    assert engine.bls_verify(pk_xy, msgs, sig_xy, pk_inf=inf, sig_inf=inf).tolist() == [1] * n
+    for two in (False, True):        # the default entry point (one final exponentiation) and the literal two-pairing form
+        verify = lambda *a, **k: engine.bls_verify(*a, two_pairings=two, **k)
+        assert verify(pk_xy, msgs, sig_xy).tolist() == [1] * n                         # lib.rs:29-42 round trip
+        # planted corruption pattern: wrong message, sig + G1gen, wrong key
+        got = verify(pk_xy, msgs, mixed)
+        assert got.tolist() == (~plant).astype(int).tolist()
+        assert np.array_equal(got, coracle.verify(pk_proj[:8], msgs[:8], sig_proj[:8]).tolist() + got[8:].tolist())
+        assert verify(pk_xy, msgs[::-1], sig_xy).sum() <= 1                            # only a palindromic position could match
+        assert verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy).tolist() == [0] * n
+        # infinity signature / key: pairing() maps them to the identity (pairing.rs:876-886) -> both sides must be 1 to pass
+        assert verify(pk_xy, msgs, sig_xy, sig_inf=inf).tolist() == [0] * n
+        assert verify(pk_xy, msgs, sig_xy, pk_inf=inf, sig_inf=inf).tolist() == [1] * n
 
 
 def test_verify_batch_planted_pattern_large(engine):
@@ -81,31 +83,49 @@ def test_verify_batch_planted_pattern_large(engine):
     assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1
 
 
-def test_fused_verify_equals_reference_shape(engine):
-    """sylow_hip_bls_verify_fused_batch: e(sig, G2gen) * e(-H, pk) == 1 (the shape of the reference's
-    examples) must give the same booleans as the two-pairing verify() on G1 x G2 inputs, incl. planted
-    corruption and identity inputs."""
+def test_one_final_exponentiation_verify_equals_the_two_pairing_form(engine, coracle):
+    """sylow_hip_bls_verify_batch (= _fused_: e(sig, G2gen) * e(-H, pk) == 1, one final exponentiation) gives the booleans of
+    lib.rs:223-236 evaluated literally (sylow_hip_bls_verify_two_pairings_batch): planted corruption, identity inputs, and keys
+    OUTSIDE the r-torsion (conj(miller(H, pk)) = miller(-H, pk) holds line by line, for any twist point)."""
+    from test_gpu_groups import fp2_sqrt
     rng = Xoshiro(SEED + 31)
     msgs = messages() * 7                                    # 147 elements: spans three wavefronts with a ragged tail
     n = len(msgs)
     sk = limbs([rng.fp() for _ in range(n)])
     sig_xy, _ = engine.bls_sign(sk, msgs)
     pk_xy, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
-    assert engine.bls_verify(pk_xy, msgs, sig_xy, fused=True).tolist() == [1] * n
+    for fused in (False, True):
+        assert engine.bls_verify(pk_xy, msgs, sig_xy, fused=fused).tolist() == [1] * n
     bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
     plant = np.random.default_rng(9).random(n) < 0.2
     mixed = np.where(plant[:, None], bad_sig, sig_xy)
-    got = engine.bls_verify(pk_xy, msgs, mixed, fused=True)
+    got = engine.bls_verify(pk_xy, msgs, mixed)
     assert np.array_equal(got.astype(bool), ~plant)
-    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed))
-    assert engine.bls_verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy, fused=True).sum() == 0
+    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed, two_pairings=True))
+    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed, fused=True))
+    assert engine.bls_verify(np.roll(pk_xy, 1, axis=0), msgs, sig_xy).sum() == 0
     # identity handling equals pairing()'s: random flags on both sides
     g = np.random.default_rng(10)
     pinf, sinf = (g.random(n) < 0.3).astype(np.uint8), (g.random(n) < 0.3).astype(np.uint8)
-    a = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf, fused=True)
-    b = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf)
+    a = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf)
+    b = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf, two_pairings=True)
     assert np.array_equal(a, b)
     assert a[(pinf & sinf).astype(bool)].all()               # both sides identity -> 1 == 1
+    # keys that are twist points outside G2, and signatures that are arbitrary curve points: same answers from both forms
+    wild = []
+    while len(wild) < 12:
+        x = (rng.fp(), rng.fp())
+        y = fp2_sqrt(R.fp2_add(R.fp2_mul(R.fp2_square(x), x), R.TWIST_B))
+        if y is not None:
+            wild.append(list(x) + list(y))
+    wild = pack([v for q in wild for v in q], 16)
+    assert engine.g2_subgroup_check(wild).tolist() == [2] * 12
+    a = engine.bls_verify(wild, msgs[:12], sig_xy[:12])
+    b = engine.bls_verify(wild, msgs[:12], sig_xy[:12], two_pairings=True)
+    assert np.array_equal(a, b) and not a.any()
+    wild_proj = np.concatenate([wild, np.repeat(pack([1, 0], 8), 12, 0)], axis=1)
+    sig_proj = np.concatenate([sig_xy[:12], np.repeat(limbs([1]), 12, 0)], axis=1)
+    assert np.array_equal(a[:4], coracle.verify(wild_proj[:4], msgs[:4], sig_proj[:4]))
 
 
 def test_same_signer_and_precompute(engine, coracle):

@@ -26,7 +26,7 @@ def timed(fn, reps=3):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-tv = timed(lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv))
+tv = timed(lambda: eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv))
 assert ok.download().all()
 tf = timed(lambda: eng._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv))
 assert ok.download().all()

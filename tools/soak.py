@@ -64,8 +64,8 @@ while time.time() - t0 < budget:
     for i in badi: sigb[i] = sig[(i + 1) % nv] if nv > 1 else P_all[0]
     want = [0 if (i in badi and nv > 1) else 1 for i in range(nv)]
     if nv == 1: want = [0] if badi else [1]
-    for fused in (False, True):
-        v1 = eng.bls_verify(pk, msgs, sigb, fused=fused); v2 = eng.bls_verify(pk, msgs, sigb, fused=fused)
+    for fused in (False, True):       # False: the literal two-pairing form, True: the default (one final exponentiation)
+        v1 = eng.bls_verify(pk, msgs, sigb, two_pairings=not fused); v2 = eng.bls_verify(pk, msgs, sigb, two_pairings=not fused)
         assert np.array_equal(v1, v2), ("verify nondeterministic", fused, n)
         assert v1.tolist() == want or nv == 1, ("verify flags", fused, n, v1.tolist()[:8], want[:8])
     rounds += 1; checks += 8
