@@ -28,6 +28,7 @@ struct OpsFp {
   static BN_DEV F sub(const F& a, const F& b) { return fp_sub(a, b); }
   static BN_DEV F neg(const F& a) { return fp_neg(a); }
   static BN_DEV F mul(const F& a, const F& b) { return fp_mul(a, b); }
+  static BN_DEV F sqr(const F& a) { return fp_mul(a, a); }
   static BN_DEV F zero() { return fp_zero(); }
   static BN_DEV F one() { return fp_one(); }
   static BN_DEV bool is_zero(const F& a) { return fp_is_zero(a); }
@@ -41,6 +42,7 @@ struct OpsFp2 {
   static BN_DEV F sub(const F& a, const F& b) { return fp2_sub(a, b); }
   static BN_DEV F neg(const F& a) { return fp2_neg(a); }
   static BN_DEV F mul(const F& a, const F& b) { return fp2_mul(a, b); }
+  static BN_DEV F sqr(const F& a) { return fp2_mul(a, a); }
   static BN_DEV F zero() { return fp2_zero(); }
   static BN_DEV F one() { return fp2_one(); }
   static BN_DEV bool is_zero(const F& a) { return fp2_is_zero(a); }
@@ -54,12 +56,12 @@ template <class O> BN_DEV Proj<typename O::F> proj_zero() { return Proj<typename
 template <class O>
 BN_DEV Proj<typename O::F> proj_double(const Proj<typename O::F>& p) {
   typedef typename O::F F;
-  F t0 = O::mul(p.y, p.y);
+  F t0 = O::sqr(p.y);
   F z3 = O::add(t0, t0);
   z3 = O::add(z3, z3);
   z3 = O::add(z3, z3);
   F t1 = O::mul(p.y, p.z);
-  F t2 = O::mul(p.z, p.z);
+  F t2 = O::sqr(p.z);
   t2 = O::mul_b3(t2);
   F x3 = O::mul(t2, z3);
   F y3 = O::add(t0, t2);
@@ -176,6 +178,7 @@ struct OpsF29 {
   static BN_DEV F sub(const F& a, const F& b) { return f29_norm(f29_sub(a, b)); }
   static BN_DEV F neg(const F& a) { return f29_norm(f29_neg(a)); }
   static BN_DEV F mul(const F& a, const F& b) { return f29_mul_leaf(W_ARGS(a), W_ARGS(b)); }
+  static BN_DEV F sqr(const F& a) { return f29_mul_leaf(W_ARGS(a), W_ARGS(a)); }
   static BN_DEV F zero() { return F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
   // 2^261 mod p, the Montgomery one of the core
   static BN_DEV F one() { return F29{{0x157ccc21, 0x141c2758, 0x185230d3, 0x014c0419, 0x0aa36fb9, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836}}; }

@@ -14,11 +14,17 @@ struct OpsW2 {
   static BN_DEV F sub(const F& a, const F& b) { return w2_norm(w2_sub(a, b)); }
   static BN_DEV F neg(const F& a) { return w2_norm(w2_neg(a)); }
   static BN_DEV F mul(const F& a, const F& b) { return w2_mul_ilp(a, b); }       // two-accumulator leaf: 5 % faster here (bn254_f29.hpp)
+  static BN_DEV F sqr(const F& a) { return w2_sqr(a); }                          // coordinates are N-class: non-negative limbs
   static BN_DEV F zero() { return W2{OpsF29::zero()}; }
   static BN_DEV F one() { return W2{sel9(lane_odd(), OpsF29::one(), OpsF29::zero())}; }
   static BN_DEV bool is_zero(const F& a) { return s2_is_zero(w2_to_s2(a)); }
   static BN_DEV F select(const F& a, const F& b, bool c) { return w2_select(a, b, c); }
-  static BN_DEV F mul_b3(const F& a) { return w2_mul_ilp(a, w2_const(C_TWIST_B3)); }
+  // 3 b' as R-class lane-pair digits (3 b' 2^261 mod p, balanced), one select per limb where it is used -- see w2_twist_b()
+  static BN_DEV F mul_b3(const F& a) {
+    const F29 k0{{0x10dfc87a, 0x0066b592, 0x16ad88c7, 0x02c15844, 0x158f2f8c, 0x09ad0e4d, 0x137cf714, 0x14872cdb, -1389659}};
+    const F29 k1{{0x01e5cc12, 0x15bda508, 0x18588eb7, 0x00f3e938, 0x18f2b0b4, 0x03bffebe, 0x13752c37, 0x0ec49a37, 0x0017dd10}};
+    return w2_mul_ilp(a, W2{sel9(lane_odd(), k0, k1)});
+  }
 };
 typedef Proj<W2> G2Q;
 BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
