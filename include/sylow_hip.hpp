@@ -149,14 +149,15 @@ inline std::vector<G1Affine> mul(const std::vector<G1Affine>& p, const std::vect
   fetch_flags(inf_out, dinf, n);
   return from_device_soa<G1Affine>(dout, n);
 }
+// in_subgroup: every p[i] is in the r-torsion (what G2Projective::new guarantees upstream): the endomorphism-split product
 inline std::vector<G2Affine> mul(const std::vector<G2Affine>& p, const std::vector<Fp>& k, std::vector<uint8_t>* inf_out = nullptr,
-                                 const std::vector<uint8_t>* p_inf = nullptr) {
+                                 const std::vector<uint8_t>* p_inf = nullptr, bool in_subgroup = false) {
   if (p.size() != k.size()) throw Error("G2 * Fp: length mismatch");
   const size_t n = p.size();
   auto dp = to_device_soa(p); auto dk = to_device_soa(k);
   Flags dpi(p_inf, n);
   DeviceBuffer dout(n * sizeof(G2Affine) + 8), dinf(n + 8);
-  check(sylow_hip_g2_scalar_mul_batch(dp.as<uint64_t>(), dpi.ptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
+  check((in_subgroup ? sylow_hip_g2_scalar_mul_subgroup_batch : sylow_hip_g2_scalar_mul_batch)(dp.as<uint64_t>(), dpi.ptr, dk.as<uint64_t>(), dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "g2_scalar_mul");
   fetch_flags(inf_out, dinf, n);
   return from_device_soa<G2Affine>(dout, n);
 }

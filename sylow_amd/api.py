@@ -15,6 +15,7 @@ import numpy as np
 from .engine import Engine
 
 P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001      # fp.rs:60-65
 _M64 = (1 << 64) - 1
 _G2 = (0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
        0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2,
@@ -146,14 +147,19 @@ G1Projective = G1Affine   # results are compared after normalisation (SURVEY.md 
 
 class G2Affine(_Points):
     WIDTH = 16
+    in_subgroup = False                            # set on values whose r-torsion membership is established
+
+    def _checked(self, flag=True):
+        self.in_subgroup = bool(flag)
+        return self
 
     @classmethod
     def generator(cls, n=1):                       # g2.rs:47-77
-        return cls(np.repeat(_row(_G2), n, 0))
+        return cls(np.repeat(_row(_G2), n, 0))._checked()
 
     @classmethod
     def zero(cls, n=1):
-        return cls(np.repeat(_row([0, 0, 1, 0]), n, 0), np.ones(n, dtype=np.uint8))
+        return cls(np.repeat(_row([0, 0, 1, 0]), n, 0), np.ones(n, dtype=np.uint8))._checked()
 
     @classmethod
     def new(cls, xy):                              # G2Projective::new (g2.rs:460-525): on-curve + subgroup
@@ -163,23 +169,25 @@ class G2Affine(_Points):
             raise GroupError(GroupError.NOT_ON_CURVE)
         if (st == 2).any():
             raise GroupError(GroupError.NOT_IN_SUBGROUP)
-        return pts
+        return pts._checked()
 
     def __mul__(self, k):
-        xy, inf = engine().g2_scalar_mul(self.xy, k, self.infinity)
-        return G2Affine(xy, inf)
+        # values built the way the reference allows (generator, new, from_be_bytes, and what the group law makes of them) are in
+        # the r-torsion and take the endomorphism-split product; a raw G2Affine(xy) is treated as an arbitrary twist point
+        xy, inf = engine().g2_scalar_mul(self.xy, k, self.infinity, subgroup=self.in_subgroup)
+        return G2Affine(xy, inf)._checked(self.in_subgroup)
 
     def __neg__(self):
         y = np.concatenate([engine().fp_neg(self.xy[:, 8:12]), engine().fp_neg(self.xy[:, 12:16])], axis=1)
-        return G2Affine(np.concatenate([self.xy[:, :8], y], axis=1), self.infinity)
+        return G2Affine(np.concatenate([self.xy[:, :8], y], axis=1), self.infinity)._checked(self.in_subgroup)
 
     def __add__(self, other):
         xy, inf = engine().g2_add(self.xy, other.xy, self.infinity, other.infinity)
-        return G2Affine(xy, inf)
+        return G2Affine(xy, inf)._checked(self.in_subgroup and other.in_subgroup)
 
     def double(self):
         xy, inf = engine().g2_double(self.xy, self.infinity)
-        return G2Affine(xy, inf)
+        return G2Affine(xy, inf)._checked(self.in_subgroup)
 
     def precompute(self) -> "G2PreComputed":        # pairing.rs:676
         return G2PreComputed(self)
@@ -187,7 +195,7 @@ class G2Affine(_Points):
     def endomorphism(self) -> "G2Affine":           # GroupTrait::endomorphism = psi (g2.rs:140-152); panics upstream if the image is off-curve
         xy, inf, st = engine().g2_psi(self.xy, self.infinity)
         _raise_status(st)
-        return G2Affine(xy, inf)
+        return G2Affine(xy, inf)._checked(self.in_subgroup)
 
     @classmethod
     def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g2.rs:204-240): a random r-torsion point (generator * random scalar)
@@ -200,7 +208,7 @@ class G2Affine(_Points):
     def from_be_bytes(cls, blobs):                 # g2.rs:361-433 (decode + on-curve + subgroup)
         xy, inf, st = engine().g2_from_be_bytes(list(blobs))
         _raise_status(st)
-        return cls(xy, inf)
+        return cls(xy, inf)._checked()
 
 
 G2Projective = G2Affine
@@ -349,6 +357,27 @@ class KeyTable:
 
     def verify(self, msgs, sig: G1Affine) -> np.ndarray:
         return engine().bls_verify_line_table(self.table, list(msgs), sig.xy, self.infinity, sig.infinity).astype(bool)
+
+
+class KeyPair:
+    """KeyPair (lib.rs:105-137), a batch of them: secret_key = Fp::new(Fr::rand().value()) -- a scalar below r held as an Fp --
+    and public_key = G2Projective::generator() * secret_key."""
+
+    def __init__(self, secret_key: np.ndarray, public_key: "G2Affine"):
+        self.secret_key, self.public_key = secret_key, public_key
+
+    @classmethod
+    def generate(cls, n=1, seed=None):
+        """`seed` None: the operating system's generator like the reference's OsRng; an int: reproducible (tests)."""
+        if seed is None:
+            import secrets
+            sk = fp([secrets.randbelow(R_ORDER) for _ in range(n)])
+        else:
+            sk = Fr.rand(n, seed).v
+        return cls(sk, G2Affine.generator(n) * sk)
+
+    def __len__(self):
+        return self.secret_key.shape[0]
 
 
 def sign(k, msgs) -> G1Affine:

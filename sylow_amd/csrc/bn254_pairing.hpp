@@ -262,6 +262,74 @@ BN_DEV void glv_decompose(u32 (&m1)[4], bool& n1, u32 (&m2)[4], bool& n2, const 
   mag(m1, n1, v1);
   mag(m2, n2, v2);
 }
+// ---- 4-dimensional GLS on G2: psi (untwist-Frobenius-twist) is multiplication by lam = p mod r = 6 x^2 on the r-torsion, and
+// lam^4 - lam^2 + 1 = 0 mod r, so k = k0 + k1 lam + k2 lam^2 + k3 lam^3 (mod r) with |k_i| < 2^64 (tools/gls4_model.py: LLL basis, the
+// rounding constants, the bound, and a limb-exact replay of this routine on 30 000 scalars).  With the basis rows
+//   (2x+1, 0, 2x, 1), (2x, x+1, -x, x), (x+1, x, x, -2x), (2x+1, -x, -(x+1), -x)
+// and c_j = round(k g_j / 2^320) (g_j = round(2^320 cofactor_j / r), all positive), everything modulo 2^96:
+//   k0 = k - (2 a0 + c0) - 2 a1 - (a2 + c2) - (2 a3 + c3)      a_j = c_j x
+//   k1 =   - (a1 + c1) - a2 + a3
+//   k2 =   - 2 a0 + a1 - a2 + (a3 + c3)
+//   k3 =   - c0 - a1 + 2 a2 + a3
+// Out: magnitudes (two limbs) and signs.
+BN_DEV void gls4_decompose(u32 (&m)[4][2], bool (&neg)[4], const u32 (&kin)[8]) {
+  u32 k[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = kin[i];
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);   // k mod r (k < p < 2r)
+  const u32 g0[8] = {0xe558c73cu, 0x353ccca0u, 0x32e42728u, 0x2dff2915u, 0xa3e5577fu, 0x55b4ca7bu, 0xb0d92b95u, 0x9e80318au};
+  const u32 g1[8] = {0x5ce18e26u, 0x7d1fff2eu, 0x95d51bb1u, 0x46f4bda9u, 0xfc7184aeu, 0x08e5da66u, 0xb0d92b93u, 0x9e80318au};
+  const u32 g2[5] = {0x773a6ef3u, 0x6eb9c714u, 0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};
+  const u32 g3[8] = {0xbb8bb500u, 0x23038c29u, 0xcef3cd3fu, 0xc170977du, 0xa3e5577du, 0x55b4ca7bu, 0xb0d92b95u, 0x9e80318au};
+  const u32 bx[2] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32)};
+  u32 c[4][3], a[4][3];
+  auto top = [](u32 (&out)[3], const u32 (&t)[13]) {      // (t + 2^319) >> 320, low three limbs
+    u64 cy = ((u64)t[9] + 0x80000000u) >> 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cy += t[10 + i]; out[i] = (u32)cy; cy >>= 32; }
+  };
+  {
+    u32 t[13];
+    mp_mul_lo<8, 8, 13>(t, k, g0); top(c[0], t);
+    mp_mul_lo<8, 8, 13>(t, k, g1); top(c[1], t);
+    mp_mul_lo<8, 5, 13>(t, k, g2); top(c[2], t);
+    mp_mul_lo<8, 8, 13>(t, k, g3); top(c[3], t);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mp_mul_lo<3, 2, 3>(a[j], c[j], bx);
+  // signed small-coefficient combinations modulo 2^96
+  const int ca[4][4] = {{-2, -2, -1, -2}, {0, -1, -1, 1}, {-2, 1, -1, 1}, {0, -1, 2, 1}};    // coefficient of a_j in k_i
+  const int cc[4][4] = {{-1, 0, -1, -1}, {0, -1, 0, 0}, {0, 0, 0, 1}, {-1, 0, 0, 0}};        // coefficient of c_j in k_i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32 v[3];
+    i64 cy = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      cy += (i == 0) ? (i64)k[l] : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cy += (i64)a[j][l] * ca[i][j] + (i64)c[j][l] * cc[i][j];
+      v[l] = (u32)cy;
+      cy >>= 32;
+    }
+    neg[i] = (v[2] >> 31) != 0;
+    const u32 sgn = neg[i] ? 0xffffffffu : 0u;
+    u64 cm = sgn & 1u;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) { cm += (u64)(v[l] ^ sgn); m[i][l] = (u32)cm; cm >>= 32; }
+  }
+}
+// signed 4-bit digits of a 64-bit magnitude: 17 digits (the last one is the carry)
+BN_DEV void gls4_digits(signed char (&dig)[17], const u32 (&m)[2]) {
+  int carry = 0;
+#pragma unroll 1
+  for (int i = 0; i < 16; ++i) {
+    int d = (int)((m[i >> 3] >> (4 * (i & 7))) & 15) + carry;
+    carry = d >= 8;
+    dig[i] = (signed char)(d - (carry << 4));
+  }
+  dig[16] = (signed char)carry;
+}
 // signed 4-bit digits of a 128-bit magnitude: m = sum d_i 16^i, d_i in [-8, 7], 33 digits (the last one is the carry)
 BN_DEV void glv_digits(signed char (&dig)[33], const u32 (&m)[4]) {
   int carry = 0;

@@ -33,6 +33,72 @@ BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int n
   out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
                                  [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin);
 }
+// k * Q for Q in the r-torsion (G2 proper): the 4-dimensional GLS split of bn254_pairing.hpp (gls4_decompose) -- four 64-bit
+// sub-scalars against Q, psi Q, psi^2 Q, psi^3 Q on one shared window schedule: 17 windows of 4 doublings and 4 complete additions
+// (68 + 68 group operations instead of 256 + 64), ONE table of 1Q..8Q; the psi^i image of a table entry is taken when it is used:
+//   psi (X:Y:Z) = (e0 conj X : e1 conj Y : conj Z),  psi^2 = (beta X : -Y : Z) with beta in Fp,  psi^3 = (e3 conj X : -e1 conj Y : conj Z)
+// (conj is a field automorphism, so the maps act on projective coordinates; the minus signs fold into the digit's sign).
+// Only valid on the r-torsion: elsewhere psi is not multiplication by lam -- callers with arbitrary twist points use g2q_scalar_mul.
+BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
+  u32 m[4][2];
+  bool neg[4];
+  gls4_decompose(m, neg, k);
+  signed char dig[4][17];
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) gls4_digits(dig[i], m[i]);
+  G2Q T[9];
+  T[0] = proj_zero<OpsW2>();
+  T[1] = p;
+  {
+    // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0) (see g1_scalar_mul)
+    const bool pinf = OpsW2::is_zero(T[1].z);
+    T[1].x = OpsW2::select(T[1].x, OpsW2::zero(), pinf);
+    T[1].y = OpsW2::select(T[1].y, OpsW2::one(), pinf);
+    T[1].z = OpsW2::select(T[1].z, OpsW2::zero(), pinf);
+  }
+  g2q_double(T[2], T[1]);
+  g2q_add(T[3], T[2], T[1]);
+  g2q_double(T[4], T[2]);
+  g2q_add(T[5], T[4], T[1]);
+  g2q_double(T[6], T[3]);
+  g2q_add(T[7], T[6], T[1]);
+  g2q_double(T[8], T[4]);
+  // R-class lane-pair digits of the constants (value 2^261 mod p, balanced): e0 = xi^((p-1)/3), e1 = xi^((p-1)/2), e3 = e0 conj(e0 conj e0), beta = e0 conj e0
+  const F29 e0a{{0x0c289449, 0x05f0a422, 0x0f85cd6c, 0x144ada8b, 0x053ef805, 0x01e2f615, 0x0b280ae6, 0x0c277edf, -774555}};
+  const F29 e0b{{0x11142ef1, 0x0b31acc7, 0x1d5818bc, 0x180afc17, 0x1a63177e, 0x15765b3b, 0x118f742e, 0x063a509a, 0x00135e4e}};
+  const F29 e1a{{0x02a20931, 0x026f9a50, 0x16a46c6e, 0x158851e6, 0x0cbb39a7, 0x14064374, 0x1e4cd58d, 0x139448ce, -1252754}};
+  const F29 e1b{{0x19a647d5, 0x19fdefab, 0x1d925d1a, 0x0d1f6c5f, 0x08ac6cc5, 0x1fa5621a, 0x134f06fe, 0x09a72816, 0x0015871d}};
+  const F29 e3a{{0x136caecd, 0x19c70818, 0x1dae30d1, 0x028eb786, 0x0bee8f49, 0x1a51d4be, 0x135c7d00, 0x11fdec39, 0x000cad5f}};
+  const F29 e3b{{0x0e67888f, 0x1909bbf8, 0x1437ee3c, 0x018c6b33, 0x1225801f, 0x14b58183, 0x0624ca44, 0x108b53c5, -654776}};
+  const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};
+  const bool odd = lane_odd();
+  G2Q res = proj_zero<OpsW2>();
+#pragma unroll 1
+  for (int w = 16; w >= 0; --w) {
+    if (w != 16) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) g2q_double(res, res);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int d = dig[i][w], mag = d < 0 ? -d : d;
+      G2Q q = T[mag];
+      bool flip = (d < 0) != neg[i];
+      if (i == 2) {
+        q.x = w2_scale(q.x, beta);
+        flip = !flip;
+      } else if (i != 0) {
+        q.x = w2_mul(W2{sel9(odd, i == 1 ? e0a : e3a, i == 1 ? e0b : e3b)}, w2_conj(q.x));
+        q.y = w2_mul(W2{sel9(odd, e1a, e1b)}, w2_conj(q.y));
+        q.z = w2_conj(q.z);
+        if (i == 3) flip = !flip;
+      }
+      q.y = OpsW2::select(q.y, OpsW2::neg(q.y), flip);
+      g2q_add(res, res, q);
+    }
+  }
+  out = res;
+}
 // group.rs:475-495 (through the saturated core: one Fp2 inversion)
 BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
   const S2 zi = s2_inv(w2_to_s2(p.z));
@@ -85,6 +151,17 @@ __global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf
   load_scalar(k, ks, n, i);
   G2Q r;
   g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k);
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+// the same for inputs in the r-torsion (G2Projective values of the reference are: G2Projective::new checks, g2.rs:460-525)
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  G2Q r;
+  g2q_scalar_mul_gls(r, load_g2q(pxy, pinf, n, i, odd), k);
   store_g2q_affine(oxy, oinf, n, i, odd, r);
 }
 __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
@@ -317,6 +394,11 @@ int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
   plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
+  plk::k_g2_scalar_mul_gls<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;

@@ -225,7 +225,9 @@ class Engine:
         return self.from_device_soa(do), doi.download()
 
     def g1_scalar_mul(self, p_xy, k, p_inf=None): return self._scalar_mul("sylow_hip_g1_scalar_mul_batch", 8, p_xy, p_inf, k)
-    def g2_scalar_mul(self, p_xy, k, p_inf=None): return self._scalar_mul("sylow_hip_g2_scalar_mul_batch", 16, p_xy, p_inf, k)
+    def g2_scalar_mul(self, p_xy, k, p_inf=None, subgroup=False):
+        """k * P on the twist; subgroup=True: P is known to be in the r-torsion (4-way endomorphism split, ~1.8x faster)."""
+        return self._scalar_mul("sylow_hip_g2_scalar_mul_subgroup_batch" if subgroup else "sylow_hip_g2_scalar_mul_batch", 16, p_xy, p_inf, k)
 
     def g1_add(self, a_xy, b_xy, a_inf=None, b_inf=None):
         a_xy, b_xy = _aos(a_xy, 8), _aos(b_xy, 8)

@@ -2,6 +2,7 @@
 // (pairing.rs:1052-1072, lib.rs:29-42) on small batches.  Prints results for the pytest wrapper
 // (tests/test_gpu_cpp_host.py), which compares them with the golden fixtures and the oracle.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 
 #include "sylow_hip.hpp"
@@ -23,6 +24,12 @@ int main() {
     std::vector<std::vector<uint8_t>> msgs(4, std::vector<uint8_t>{0, 0, 0, 20});
     auto sig = sign(sk, msgs);
     auto pk = mul(std::vector<G2Affine>(4, g2_generator()), sk);
+    {   // the endomorphism-split product on r-torsion inputs gives the same keys
+        auto pk_split = mul(std::vector<G2Affine>(4, g2_generator()), sk, nullptr, nullptr, /*in_subgroup=*/true);
+        bool same = true;
+        for (int i = 0; i < 4; ++i) same = same && std::memcmp(&pk[i], &pk_split[i], sizeof(G2Affine)) == 0;
+        std::printf("G2SPLIT %d\n", same ? 1 : 0);
+    }
     auto ok = verify(pk, msgs, sig);
     msgs[2] = {1, 2, 3};
     auto bad = verify(pk, msgs, sig);

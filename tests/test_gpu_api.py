@@ -167,3 +167,18 @@ def test_key_table_and_cached_precompute(api):
     assert (ml.final_exponentiation() == api.pairing(p, api.G2Affine(np.repeat(pk.xy, 7, 0)))).all()
     g = api.glued_miller_loop(api.G2Affine(np.repeat(pk.xy, 7, 0)).precompute(), p)
     assert (g.final_exponentiation() == api.glued_pairing(p, api.G2Affine(np.repeat(pk.xy, 7, 0)))).all()
+
+
+def test_keypair_sign_verify_round_trip(api):
+    """lib.rs:29-42 (`KeyPair::generate` -> `sign` -> `verify`) on a batch, both generators"""
+    from helpers import ints
+    for seed in (7, None):
+        kp = api.KeyPair.generate(9, seed=seed)
+        assert len(kp) == 9 and all(0 <= k < api.R_ORDER for k in ints(kp.secret_key))
+        assert np.array_equal(kp.public_key.xy, (api.G2Projective.generator(9) * kp.secret_key).xy)
+        msgs = [bytes([i]) * (i + 1) for i in range(9)]
+        sig = api.sign(kp.secret_key, msgs)
+        assert api.verify(kp.public_key, msgs, sig).all()
+        assert not api.verify(kp.public_key, msgs[::-1], sig)[:4].any()
+    a, b = api.KeyPair.generate(3, seed=11), api.KeyPair.generate(3, seed=11)
+    assert np.array_equal(a.secret_key, b.secret_key)

@@ -34,6 +34,7 @@ def test_cpp_host_layer_runs(kats, coracle):
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
     assert [int(x, 16) for x in lines["GT"].split()] == [int(x, 16) for x in kats["gt_generator"]["value"]]
     assert lines["VERIFY"] == "1111 1101"
+    assert lines["G2SPLIT"] == "1"
     assert lines["BILINEAR"] == "1" and lines["GLUED"] == "1"
     assert lines["GTPOW"] == "1" and lines["FRINV"] == "1" and lines["AGG"] == "1"
     # identity operands travel as flags: sk = 0 -> identity signature and key (flags 1,0); verify(identity, identity) = true,

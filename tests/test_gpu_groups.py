@@ -213,3 +213,32 @@ def test_g1_affine_new_check(engine):
     exp = [0 if (y * y - x * x * x - 3) % P == 0 else 1 for x, y in [(0, 0), (1, 2), (1, P - 2), (0, 1), (P - 1, 5)]]
     exp[3] = 0
     assert engine.g1_on_curve(extra, inf).tolist() == exp
+
+
+def test_g2_scalar_mul_subgroup_split_vs_generic_and_oracle(engine, coracle):
+    """sylow_hip_g2_scalar_mul_subgroup_batch (4-way split along psi, tools/gls4_model.py) == the generic window product == the
+    oracle's double-and-add on r-torsion points, for edge scalars (0, 1, r-1, r, r+1, p-1, lambda and its powers, 2^k) and random ones."""
+    from helpers import P
+    r = R.R_ORDER
+    lam = P % r
+    rng = Xoshiro(SEED + 27)
+    edge = [0, 1, 2, r - 1, r, r + 1, P - 1, lam, lam + 1, r - lam, lam * lam % r, pow(lam, 3, r), 1 << 253, (1 << 254) - 1, R.BLS_X, 6 * R.BLS_X ** 2,
+            (1 << 64) - 1, 1 << 64, (1 << 128) + 5, 7 << 190]
+    ks = [k % P for k in edge] + [rng.fp() for _ in range(90 - len(edge))]            # scalars are Fp values (N4)
+    n = len(ks)
+    base, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    base[0] = pack(G2, 16)[0]
+    got, got_inf = engine.g2_scalar_mul(base, limbs(ks), subgroup=True)
+    ref, ref_inf = engine.g2_scalar_mul(base, limbs(ks))
+    assert np.array_equal(got, ref) and np.array_equal(got_inf, ref_inf)
+    assert got_inf.tolist() == [1 if k % r == 0 else 0 for k in ks]
+    exp, exp_inf = coracle.g2_to_affine(coracle.g2_scalar_mul(g2_proj(base[:24]), limbs(ks[:24])))
+    assert np.array_equal(got[:24], exp) and np.array_equal(got_inf[:24], exp_inf)
+    # identity in, identity out; and the eigenvalue itself: lambda * Q == psi(Q)
+    inf = np.zeros(n, dtype=np.uint8); inf[::3] = 1
+    a, ai = engine.g2_scalar_mul(base, limbs(ks), inf, subgroup=True)
+    b, bi = engine.g2_scalar_mul(base, limbs(ks), inf)
+    assert np.array_equal(a, b) and np.array_equal(ai, bi) and ai[::3].all()
+    psi_xy, _, _ = engine.g2_psi(base[:8])
+    lam_q, _ = engine.g2_scalar_mul(base[:8], limbs([lam] * 8), subgroup=True)
+    assert np.array_equal(lam_q, psi_xy)

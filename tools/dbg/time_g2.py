@@ -20,3 +20,4 @@ for rep in range(2):
     print("g1_scalarmul %.2f ms" % timed(lambda: eng._call("sylow_hip_g1_scalar_mul_batch", p.ptr, None, ka.ptr, o1.ptr, o1i.ptr, n)))
     print("miller       %.2f ms" % timed(lambda: eng._call("sylow_hip_miller_loop_batch", p.ptr, q.ptr, gt.ptr, n)))
     print("subgroup     %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_subgroup_check_batch", q.ptr, None, ok.ptr, n)))
+    print("g2_mul_subgr %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", q.ptr, None, kb.ptr, o2.ptr, o2i.ptr, n)))
