@@ -317,6 +317,24 @@ int32_t sylow_hip_all_valid(const uint8_t* flags, size_t n, void* comm, int32_t*
 int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, size_t n_pairs,
                                       int32_t skip_infinity, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream);
 
+/* Aggregate verification -- "are ALL n signatures valid?" as ONE Gt comparison, the batch shape of
+ * examples/verify_multiple_messages_same_signer.rs:41-60 and threshold_signing.rs:92-121, where the reference glues the 2n pairs
+ * (sig_i, G2gen), (-H(msg_i), pk_i) into one product:  gt_out [48][1] = that product after the final exponentiation,
+ * is_one[0] = (gt_out == Gt::identity()).  Evaluated through bilinearity: prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen), so the
+ * G2gen half costs n G1 additions and ONE Miller loop; with one key for the whole batch (n_pk = 1) the other half collapses the
+ * same way, prod_i e(-H(msg_i), pk) = e(-sum_i H(msg_i), pk), and the check is n hashes + two sums + a two-pair product.  The Gt
+ * value is the same group element as the reference's 2n-pair product, hence the same words.  n_pk = n: pk_xy [16][n] one key per
+ * message; n_pk = 1: pk_xy [16][1].  Identity signatures / keys contribute 1 (pairing() semantics).  n = 0 gives the identity.
+ * (As in the reference's example there are no random weights: it answers "is the PRODUCT the identity".)
+ *   _partial_: f_out [48][1] = this shard's raw Miller product (for hosts that combine shards themselves,
+ *              with sylow_hip_fp12_product_final_exp);
+ *   _verify_:  the whole check; comm = the host's ncclComm_t for a batch sharded over the GPUs of a node (every rank passes its
+ *              shard and receives the same answer; 384 bytes per rank are all-gathered), NULL = this process alone. */
+int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                              const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, uint64_t* f_out, void* stream);
+int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                             const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream);
+
 /* ---- test hooks (stable enough for the repo's own tests; not part of the drop-in surface) ------------------------------------
  * Granger-Scott cyclotomic square (pairing.rs:309-350) and the raw Fp12 selector: 0..7 single-lane tower ops, 8 / 9 product /
  * cyclotomic square on the carry-free core, 10 / 11 exp_by_neg_z (carry-free / saturated), 16..29 the lane-pair Fp12 layer. */

@@ -75,6 +75,8 @@ SIGNATURES = {
     "sylow_hip_g1_from_be_bytes_batch": [c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_to_be_bytes_batch": [c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_from_be_bytes_batch": [c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
+    "sylow_hip_bls_aggregate_partial_batch": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_u64p, c_vp],
+    "sylow_hip_bls_aggregate_verify_batch": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp, c_u64p, c_u8p, c_vp],
     "sylow_hip_bls_verify_same_signer_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_precompute_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_f29_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],

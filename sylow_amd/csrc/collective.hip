@@ -81,4 +81,36 @@ int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf
   return rc != SYLOW_HIP_OK ? rc : rc2;
 }
 
+// Aggregate verification over a batch sharded across the ranks of `comm` (NULL = this process alone): every rank reduces its shard to
+// one raw Miller product (sylow_hip_bls_aggregate_partial_batch), the 384-byte partials are all-gathered, and each rank finishes
+// product + final exponentiation: one boolean on every rank.
+int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                             const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK(gt_out || is_one);
+  hipStream_t st = (hipStream_t)stream;
+  int world = 1;
+  const Rccl* r = nullptr;
+  if (comm) {
+    r = rccl();
+    if (!r) { snprintf(sylow_g_err, sizeof(sylow_g_err), "librccl.so.1 not found: %s", dlerror()); return SYLOW_HIP_E_HIP; }
+    ncclResult_t e = r->comm_count((ncclComm_t)comm, &world);
+    if (e != ncclSuccess || world < 1) return nccl_fail(r, e, "ncclCommCount");
+  }
+  host::Lease ws;
+  int32_t rc = ws.acquire((size_t)(48 + 96 * (size_t)world) * sizeof(u64), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  u64 *mine = (u64*)ws.p, *all = mine + 48, *soa = all + 48 * (size_t)world;
+  rc = sylow_hip_bls_aggregate_partial_batch(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, n, mine, stream);
+  if (rc == SYLOW_HIP_OK && comm) {
+    ncclResult_t e = r->all_gather(mine, all, 48, ncclUint64, (ncclComm_t)comm, st);                 // 384 bytes per rank
+    if (e != ncclSuccess) rc = nccl_fail(r, e, "ncclAllGather");
+    if (rc == SYLOW_HIP_OK) rc = sylow_hip_aos_to_soa(all, soa, 48, (size_t)world, stream);
+    if (rc == SYLOW_HIP_OK) rc = sylow_hip_fp12_product_final_exp(soa, (size_t)world, gt_out, is_one, stream);
+  } else if (rc == SYLOW_HIP_OK) {
+    rc = sylow_hip_fp12_product_final_exp(mine, 1, gt_out, is_one, stream);
+  }
+  const int32_t rc2 = ws.release();
+  return rc != SYLOW_HIP_OK ? rc : rc2;
+}
+
 }  // extern "C"

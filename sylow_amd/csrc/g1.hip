@@ -64,14 +64,46 @@ __global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* ox
   oinf[i] = rinf ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ sum of a batch of G1 points ----------
+// sum_i P_i as a log-depth tree of complete additions on a projective scratch array acc [12][n] (canonical words): the G1 side of
+// aggregate verification (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen)).  init: affine + flags -> projective; level: element t
+// absorbs element t + h, in place (nobody else touches either); finish: element 0 -> affine, written to column `col` of an SoA
+// array of stride `stride`, optionally negated.
+__global__ void __launch_bounds__(BLOCK) k_g1_sum_init(const u64* pxy, const uint8_t* pinf, u64* acc, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const bool inf = pinf && pinf[i];
+  store_fp(acc, n, i, 0, inf ? fp_zero() : load_fp(pxy, n, i, 0));
+  store_fp(acc, n, i, 4, inf ? fp_one() : load_fp(pxy, n, i, 4));
+  store_fp(acc, n, i, 8, inf ? fp_zero() : fp_one());
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_sum_level(u64* acc, size_t n, size_t m, size_t h) {
+  size_t t = TID;
+  if (t + h >= m) return;
+  const G1P a{load_fp(acc, n, t, 0), load_fp(acc, n, t, 4), load_fp(acc, n, t, 8)};
+  const G1P b{load_fp(acc, n, t + h, 0), load_fp(acc, n, t + h, 4), load_fp(acc, n, t + h, 8)};
+  const G1P r = g1_add(a, b);
+  store_fp(acc, n, t, 0, r.x); store_fp(acc, n, t, 4, r.y); store_fp(acc, n, t, 8, r.z);
+}
+__global__ void k_g1_sum_finish(const u64* acc, size_t n, u64* oxy, uint8_t* oinf, size_t stride, size_t col, int negate) {
+  if (TID != 0) return;
+  const G1P p = n ? G1P{load_fp(acc, n, 0, 0), load_fp(acc, n, 0, 4), load_fp(acc, n, 0, 8)} : G1P{fp_zero(), fp_one(), fp_zero()};
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, p);
+  if (negate && !inf) y = fp_neg(y);
+  store_fp(oxy, stride, col, 0, x); store_fp(oxy, stride, col, 4, y);
+  oinf[col] = inf ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ hash / BLS kernels ----------
-__global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
+__global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n, int negate) {
   size_t i = TID;
   if (i >= n) return;
   G1P h;
   bool ok = hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
   Fp x, y; bool inf;
   g1_to_affine(x, y, inf, h);
+  if (negate && !inf) y = fp_neg(y);                     // -H(m): the G1 side of the e(sig, G2gen) e(-H, pk) == 1 shapes
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
   oinf[i] = inf ? 1 : 0;
   if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
@@ -202,6 +234,23 @@ __global__ void __launch_bounds__(BLOCK) k_g1_double(const u64* axy, const uint8
 }
 
 // ================================================================== C ABI ======================
+namespace g1h {
+int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate); LAUNCHED();
+}
+int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
+  if (n) k_g1_sum_init<<<GRID(n)>>>(p_xy, p_inf, acc, n);
+  size_t m = n;
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    k_g1_sum_level<<<GRID(m - h)>>>(acc, n, m, h);
+    m = h;
+  }
+  k_g1_sum_finish<<<1, 64, 0, (hipStream_t)stream>>>(acc, n, out_xy, out_inf, stride, col, negate); LAUNCHED();
+}
+}  // namespace g1h
+
 extern "C" {
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
@@ -226,7 +275,7 @@ int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offs
                                    uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
-  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n); LAUNCHED();
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, 0); LAUNCHED();
 }
 int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
                                       uint64_t* out_u, size_t n, void* stream) {

@@ -62,6 +62,12 @@ int32_t bls_verify_same_signer(const uint64_t* pk_xy, const uint8_t* pk_inf, con
 int32_t build_gen_lines(u32* table, void* stream);              // k_g2_lines on the generator
 int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);   // k_fp12_op selectors 0..11
 }  // namespace single
+namespace g1h {         // g1.hip
+// H(m_i) (or -H(m_i)) affine with the library DST, SoA stride n
+int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream);
+// sum_i P_i (or its negative) -> column `col` of an affine SoA array of stride `stride`; acc: scratch of 12 n words
+int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream);
+}  // namespace g1h
 namespace plkh {        // lane-pair units
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
 size_t line_table_bytes();                                                                             // plk_verify.hip

@@ -248,6 +248,30 @@ __global__ void k_fp12_set_one(u64* out) {
   if (TID >= 2) return;
   store_s12(out, 1, 0, (int)(TID & 1), s12_one());
 }
+// out = a * b, all SoA stride 1 (two raw Miller products)
+__global__ void HEAVY_BOUNDS k_fp12_mul_pair(const u64* a, const u64* b, u64* out) {
+  const size_t t = TID;
+  const int odd = (int)(t & 1);
+  if (t >= 2) return;
+  S12 sa, sb;
+  load_s12(sa, a, 1, 0, odd);
+  load_s12(sb, b, 1, 0, odd);
+  W12 x, y, r;
+  w12_from_s12(x, sa);
+  w12_from_s12(y, sb);
+  w12_mul_nl(r, x, y);
+  w12_to_s12(sa, r);
+  store_s12(out, 1, 0, odd, sa);
+}
+// column `col` of a G2 pair array (stride `stride`) <- the generator (src NULL) or element 0 of a one-key array
+__global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t col, const u64* src_xy, const uint8_t* src_inf) {
+  const size_t t = TID;
+  const int odd = (int)(t & 1);
+  if (t >= 2) return;
+  store_s2(qxy, stride, col, 0, odd, src_xy ? load_s2(src_xy, 1, 0, 0, odd) : s2_g2gen_x());
+  store_s2(qxy, stride, col, 8, odd, src_xy ? load_s2(src_xy, 1, 0, 8, odd) : s2_g2gen_y());
+  if (!odd) qinf[col] = (src_xy && src_inf && src_inf[0]) ? 1 : 0;
+}
 __global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one) {
   const size_t t = TID;
   const int odd = (int)(t & 1);
@@ -422,6 +446,54 @@ int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint
   hipError_t e = hipMemcpyAsync(f_out, prod, 48 * sizeof(u64), hipMemcpyDeviceToDevice, st);
   rc = finish(ws);
   return e != hipSuccess ? host::fail(e, "hipMemcpyAsync(partial product)") : rc;
+}
+// Aggregate verification (examples/verify_multiple_messages_same_signer.rs:41-60, threshold_signing.rs:92-121): the reference
+// glues the 2n pairs (sig_i, G2gen), (-H(m_i), pk_i) into one product and compares it with the identity.  Bilinearity collapses the
+// G2gen half: prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen) -- n additions in G1 instead of n Miller loops -- and, for ONE key, the
+// other half too: prod_i e(-H(m_i), pk) = e(-sum_i H(m_i), pk).  The Gt value is the same group element either way, so gt_out and
+// the boolean are the reference's.  This entry leaves the shard's raw Miller product (for the cross-GPU aggregate, collective.hip).
+int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                              const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, uint64_t* f_out, void* stream) {
+  ARGCHK(f_out && (n == 0 || (pk_xy && msgs && msg_offsets && sig_xy && (n_pk == 1 || n_pk == n))));
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) { plk::k_fp12_set_one<<<1, 64, 0, st>>>(f_out); LAUNCHED(); }
+  // scratch (u64 words): H or -H [8][n], the summation tree [12][n], the two collapsed pairs G1 [8][2] / G2 [16][2], one product, flags
+  const size_t w_h = 8 * n, w_acc = 12 * n, w_flags = (n + 4 + 7) / 8;
+  host::Lease ws;
+  int32_t rc = ws.acquire((w_h + w_acc + 16 + 32 + 48 + w_flags) * sizeof(u64), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  u64 *hxy = (u64*)ws.p, *acc = hxy + w_h, *p2 = acc + w_acc, *q2 = p2 + 16, *prod_b = q2 + 32;
+  uint8_t *hinf = (uint8_t*)(prod_b + 48), *p2inf = hinf + n, *q2inf = p2inf + 2;
+  const bool one_key = n_pk == 1 && n != 1;
+  host::Lease wa, wb;
+  u64 *pa = nullptr, *pb = nullptr;
+  rc = g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
+  if (rc == SYLOW_HIP_OK && !one_key) {
+    // e(sum sig, G2gen) as a one-pair product (stride 1 arrays = column 0 of stride-1 views), prod_i e(-H_i, pk_i) over the batch
+    rc = g1h::sum(sig_xy, sig_inf, n, acc, p2, p2inf, 1, 0, 0, stream);
+    if (rc == SYLOW_HIP_OK) { plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 1, 0, nullptr, nullptr); }
+    if (rc == SYLOW_HIP_OK) rc = miller_product_tree(hxy, hinf, pk_xy, pk_inf, n, 1, wa, &pa, stream);
+    if (rc == SYLOW_HIP_OK) rc = miller_product_tree(p2, p2inf, q2, q2inf, 1, 1, wb, &pb, stream);
+    if (rc == SYLOW_HIP_OK) plk::k_fp12_mul_pair<<<1, 64, 0, st>>>(pa, pb, f_out);
+  } else if (rc == SYLOW_HIP_OK) {
+    // one key: two pairs in all, (sum sig, G2gen) and (-sum H, pk), SoA stride 2
+    rc = g1h::sum(sig_xy, sig_inf, n, acc, p2, p2inf, 2, 0, 0, stream);
+    if (rc == SYLOW_HIP_OK) rc = g1h::sum(hxy, hinf, n, acc, p2, p2inf, 2, 1, /*negate=*/1, stream);
+    if (rc == SYLOW_HIP_OK) {
+      plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 2, 0, nullptr, nullptr);
+      plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 2, 1, pk_xy, pk_inf);
+      rc = miller_product_tree(p2, p2inf, q2, q2inf, 2, 1, wa, &pa, stream);
+    }
+    if (rc == SYLOW_HIP_OK) {
+      const hipError_t e = hipMemcpyAsync(f_out, pa, 48 * sizeof(u64), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) rc = host::fail(e, "hipMemcpyAsync(aggregate product)");
+    }
+  }
+  const hipError_t e = hipGetLastError();
+  const int32_t r1 = wa.release(), r2 = wb.release(), r3 = ws.release();
+  if (rc != SYLOW_HIP_OK) return rc;
+  if (e != hipSuccess) return host::fail(e, "kernel launch");
+  return r1 != SYLOW_HIP_OK ? r1 : r2 != SYLOW_HIP_OK ? r2 : r3;
 }
 int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK((gt_out || is_one) && (parts || !k));

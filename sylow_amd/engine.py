@@ -502,6 +502,20 @@ class Engine:
         self._call(name, dpk.ptr, self._ptr(dpi), dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dok.ptr, n)
         return dok.download()
 
+    def bls_aggregate_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None, comm=None):
+        """One boolean for the whole batch: prod_i e(sig_i, G2gen) e(-H(msg_i), pk_i) == 1 (one key row = the same signer).
+        Returns (gt [48] words, is_one)."""
+        pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
+        n, n_pk = len(msgs), pk_xy.shape[0]
+        assert sig_xy.shape[0] == n and (n_pk in (1, n) or n == 0)
+        dm, doff = self._msgs(msgs)
+        dpk = self.to_device_soa(pk_xy, 16) if n_pk else None
+        dsig = self.to_device_soa(sig_xy, 8) if n else None
+        dpi, dsi = (self._flags(pk_inf, n_pk) if n_pk else None), (self._flags(sig_inf, n) if n else None)
+        dgt, done = self.empty((48, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_bls_aggregate_verify_batch", self._ptr(dpk), self._ptr(dpi), n_pk, dm.ptr, doff.ptr, self._ptr(dsig), self._ptr(dsi), n, comm, dgt.ptr, done.ptr)
+        return self.from_device_soa(dgt)[0], int(done.download()[0])
+
     def bls_verify_same_signer(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None):
         pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
         assert pk_xy.shape[0] == 1

@@ -99,6 +99,82 @@ def test_rccl_entry_points_one_rank_communicator(engine, pairs):
         gt, one = engine.pairing_product_all(p[:77], q[:77], comm=comm.value)
         ref, _ = engine.pairing_product(p[:77], q[:77])
         assert np.array_equal(gt, ref) and not one
+        # aggregate verification through the communicator (all-gather of one partial) == the local answer
+        pk, msgs, sig = signed_batch(engine, 40, same_signer=False)
+        gt_c, ok_c = engine.bls_aggregate_verify(pk, msgs, sig, comm=comm.value)
+        gt_l, ok_l = engine.bls_aggregate_verify(pk, msgs, sig)
+        assert ok_c == ok_l == 1 and np.array_equal(gt_c, gt_l)
     finally:
         engine.sync()
         lib.ncclCommDestroy(comm)
+
+
+def signed_batch(engine, n, same_signer, seed=SEED + 91):
+    rng = Xoshiro(seed)
+    sk = limbs([rng.fp()] * n) if same_signer else limbs([rng.fp() for _ in range(n)])
+    msgs = [bytes([i % 251, i // 251]) * (1 + i % 11) for i in range(n)]
+    sig, _ = engine.bls_sign(sk, msgs)
+    pk, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), 1 if same_signer else n, 0), sk[:1] if same_signer else sk, subgroup=True)
+    return pk, msgs, sig
+
+
+def reference_shape(engine, pk, msgs, sig, pk_inf=None, sig_inf=None):
+    """the 2n pairs (sig_i, G2gen), (-H(m_i), pk_i) as the reference's example builds them, through the generic glued product"""
+    from helpers import P as PMOD, ints
+    n = len(msgs)
+    h, _ = engine.hash_to_g1(msgs)
+    hneg = np.concatenate([h[:, :4], limbs([(PMOD - y) % PMOD for y in ints(h[:, 4:8])])], axis=1)
+    pkn = np.repeat(pk, n, 0) if pk.shape[0] == 1 else pk
+    pin = np.zeros(n, np.uint8) if pk_inf is None else (np.repeat(np.asarray(pk_inf, np.uint8), n) if pk.shape[0] == 1 else np.asarray(pk_inf, np.uint8))
+    sin = np.zeros(n, np.uint8) if sig_inf is None else np.asarray(sig_inf, np.uint8)
+    p = np.concatenate([sig, hneg]); q = np.concatenate([np.repeat(pack(G2, 16), n, 0), pkn])
+    return engine.pairing_product(p, q, p_inf=np.concatenate([sin, np.zeros(n, np.uint8)]), q_inf=np.concatenate([np.zeros(n, np.uint8), pin]), skip_infinity=1)
+
+
+@pytest.mark.parametrize("same_signer", [False, True])
+def test_aggregate_verify_equals_the_glued_product_of_the_reference_shape(engine, coracle, same_signer):
+    """sylow_hip_bls_aggregate_verify_batch (signatures summed in G1 first; one key: hashes summed too) yields the Gt value and the
+    boolean of the reference's 2n-pair glued product (examples/verify_multiple_messages_same_signer.rs:41-60) -- valid batches,
+    a wrong signature, a swapped message, identity signatures / keys, n = 1 and n = 0; and the oracle's glued_pairing."""
+    n = 77                                                              # ragged: tree levels with odd counts
+    pk, msgs, sig = signed_batch(engine, n, same_signer)
+    gt, ok = engine.bls_aggregate_verify(pk, msgs, sig)
+    ref, ref_ok = reference_shape(engine, pk, msgs, sig)
+    assert ok == 1 and ref_ok and np.array_equal(gt, ref[0] if ref.ndim == 2 else ref)
+    one = np.zeros(48, dtype=np.uint64); one[0] = 1
+    assert np.array_equal(gt, one)
+    # one wrong signature: sig_5 <- sig_6 (a valid point, the wrong signature)
+    bad = sig.copy(); bad[5] = sig[6]
+    gt_b, ok_b = engine.bls_aggregate_verify(pk, msgs, bad)
+    ref_b, refok_b = reference_shape(engine, pk, msgs, bad)
+    assert ok_b == 0 and not refok_b and np.array_equal(gt_b, np.asarray(ref_b).reshape(-1))
+    # the oracle on the same 2n pairs (first 6 messages)
+    from helpers import P as PMOD, ints
+    m = 6
+    h, _ = engine.hash_to_g1(msgs[:m])
+    hneg = np.concatenate([h[:, :4], limbs([(PMOD - y) % PMOD for y in ints(h[:, 4:8])])], axis=1)
+    pkm = np.repeat(pk, m, 0) if same_signer else pk[:m]
+    exp = coracle.glued_pairing(proj1(np.concatenate([bad[:m], hneg])), proj2(np.concatenate([np.repeat(pack(G2, 16), m, 0), pkm])), np.array([0, 2 * m], dtype=np.uint64))
+    gt_m, ok_m = engine.bls_aggregate_verify(pk if same_signer else pk[:m], msgs[:m], bad[:m])
+    assert np.array_equal(gt_m, exp[0]) and ok_m == 0
+    # swapped messages
+    sw = list(msgs); sw[3], sw[4] = sw[4], sw[3]
+    # (under ONE key the product does not see the order -- neither does the reference's 2n-pair product)
+    assert engine.bls_aggregate_verify(pk, sw, sig)[1] == (1 if same_signer else 0) == int(reference_shape(engine, pk, sw, sig)[1])
+    assert engine.bls_aggregate_verify(pk, [b"other"] + msgs[1:], sig)[1] == 0
+    # identity flags: pairing() semantics on both sides, against the generic product with the same flags
+    g = np.random.default_rng(12)
+    sinf = (g.random(n) < 0.2).astype(np.uint8)
+    pinf = np.array([0], np.uint8) if same_signer else (g.random(n) < 0.2).astype(np.uint8)
+    gt_i, ok_i = engine.bls_aggregate_verify(pk, msgs, sig, pk_inf=pinf, sig_inf=sinf)
+    ref_i, refok_i = reference_shape(engine, pk, msgs, sig, pk_inf=pinf, sig_inf=sinf)
+    assert np.array_equal(gt_i, np.asarray(ref_i).reshape(-1)) and ok_i == int(refok_i)
+    if same_signer:
+        gt_k, ok_k = engine.bls_aggregate_verify(pk, msgs, sig, pk_inf=[1])        # identity key: only e(sum sig, G2gen) is left
+        ref_k, _ = reference_shape(engine, pk, msgs, sig, pk_inf=[1])
+        assert np.array_equal(gt_k, np.asarray(ref_k).reshape(-1)) and ok_k == 0
+    # n = 1 and n = 0
+    assert engine.bls_aggregate_verify(pk[:1], msgs[:1], sig[:1])[1] == 1
+    assert engine.bls_aggregate_verify(pk[:1], msgs[:1], sig[1:2])[1] == 0
+    gt0, ok0 = engine.bls_aggregate_verify(pk[:1] if same_signer else pk[:0], [], sig[:0])
+    assert ok0 == 1 and np.array_equal(gt0, one)
