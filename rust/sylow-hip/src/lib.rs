@@ -291,6 +291,26 @@ pub fn glued_pairing_all(dev: &Device, p: &[G1Affine], q: &[G2Affine], skip_iden
     Ok((gt_from_words(&words[0]), dev.download(&one)?[0] != 0))
 }
 
+/// Aggregate verification -- the batch shape of examples/verify_multiple_messages_same_signer.rs:41-60 and
+/// threshold_signing.rs:92-121: is the product of the 2n pairs (sig_i, G2gen), (-H(msg_i), pk_i) the identity?  The signatures are
+/// summed in G1 first (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen)); `pk` holds one key per message, or ONE key for the whole
+/// batch (then the hashes are summed as well).  Returns the Gt value of the product and the boolean.  `comm`: as for `all_valid`
+/// (every rank passes its shard of a batch spread over the GPUs of the node; null = this process alone).
+pub fn aggregate_verify(dev: &Device, pk: &[G2Affine], msgs: &[&[u8]], sig: &[G1Affine], comm: *mut c_void) -> Result<(GtOut, bool), HipError> {
+    assert!(sig.len() == msgs.len() && (pk.len() == msgs.len() || pk.len() == 1));
+    let n = msgs.len();
+    let (dpk, dsig) = (upload_g2(dev, pk)?, upload_g1(dev, sig)?);
+    let (d_msgs, d_off) = messages(dev, msgs)?;
+    let (gt, one) = (dev.alloc::<u64>(48)?, dev.alloc::<u8>(1)?);
+    // SAFETY: pk.len() keys, n signatures, n + 1 offsets; gt 48 words; one 1 byte; comm null or a live communicator.
+    device::check(unsafe {
+        ffi::sylow_hip_bls_aggregate_verify_batch(dpk.xy.as_ptr(), dpk.inf.as_ptr(), pk.len(), d_msgs.as_ptr(), d_off.as_ptr(),
+                                                  dsig.xy.as_ptr(), dsig.inf.as_ptr(), n, comm, gt.as_mut_ptr(), one.as_mut_ptr(), dev.stream)
+    })?;
+    let words = dev.download_aos::<48>(&gt, 1)?;
+    Ok((gt_from_words(&words[0]), dev.download(&one)?[0] != 0))
+}
+
 /// A batch of cached `G2PreComputed` tables (pairing.rs:556) resident on the device, and the two loops that consume them:
 /// `G2PreComputed::miller_loop(&G1Affine)` (pairing.rs:590-619) and `glued_miller_loop` (pairing.rs:970-1022).
 pub struct PrecomputedG2 {
