@@ -346,6 +346,13 @@ def verify_same_signer(pubkey: G2Affine, msgs, sig: G1Affine) -> np.ndarray:
     return engine().bls_verify_same_signer(pubkey.xy, list(msgs), sig.xy, pubkey.infinity, sig.infinity).astype(bool)
 
 
+def aggregate_verify(pubkey: G2Affine, msgs, sig: G1Affine) -> bool:
+    """The batch check of examples/verify_multiple_messages_same_signer.rs:41-60 / threshold_signing.rs:92-121: the product of the
+    2n pairs (sig_i, G2gen), (-H(msg_i), pk_i) == Gt::identity(), as one boolean; `pubkey` holds one key per message or ONE key."""
+    _, ok = engine().bls_aggregate_verify(pubkey.xy, list(msgs), sig.xy, pubkey.infinity, sig.infinity)
+    return bool(ok)
+
+
 class KeyTable:
     """One signer's `G2PreComputed` kept ON THE DEVICE across calls (examples/verify_multiple_messages_same_signer.rs:41-60):
     built once, then every `verify` is two table-driven Miller loops with no G2 arithmetic."""

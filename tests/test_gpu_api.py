@@ -182,3 +182,15 @@ def test_keypair_sign_verify_round_trip(api):
         assert not api.verify(kp.public_key, msgs[::-1], sig)[:4].any()
     a, b = api.KeyPair.generate(3, seed=11), api.KeyPair.generate(3, seed=11)
     assert np.array_equal(a.secret_key, b.secret_key)
+
+
+def test_aggregate_verify_api(api):
+    kp = api.KeyPair.generate(12, seed=3)
+    msgs = [bytes([i, 7]) for i in range(12)]
+    sig = api.sign(kp.secret_key, msgs)
+    assert api.aggregate_verify(kp.public_key, msgs, sig) is True
+    assert api.aggregate_verify(kp.public_key, msgs[::-1], sig) is False
+    one = api.KeyPair.generate(1, seed=4)
+    sig1 = api.sign(np.repeat(one.secret_key, 12, 0), msgs)
+    assert api.aggregate_verify(one.public_key, msgs, sig1) is True
+    assert api.aggregate_verify(one.public_key, msgs, sig) is False
