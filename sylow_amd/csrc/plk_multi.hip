@@ -191,6 +191,39 @@ BN_NOINLINE void glued_miller_upto2(W12& f, const u64* pxy, const uint8_t* pinf,
   }
 }
 
+// The same value pair by pair: prod_i miller(P_i, Q_i) with every factor from the single-pair loop (miller_loop29g: invariants
+// and the working point in LDS, no scratch access in its body) and one Fp12 product per pair.  Sharing the squarings saves 23 % of a
+// Miller loop per extra pair on paper, but the shared loop keeps two to eight pair states alive next to the accumulator and pays for
+// it in spill traffic: measured on one box per 2^18 jobs, shared 37.6 ms (k = 1) / 53.8 (k = 2) / 77.2 (k = 3) / 87.0 (k = 4)
+// against 33.1 / 50.9 / 78.8 / 88.6 ms this way -- so jobs of one or two pairs (the BLS and k = 2 ecPairing shapes) come here and
+// longer jobs keep the shared schedule.  Not for the reference-replay treatment of a G2 identity (Z = 0 walked through the
+// formulas): the caller checks.
+BN_NOINLINE void glued_miller_seq(W12& acc, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                             size_t lo, size_t hi, size_t n_pairs, int skip_infinity, int odd) {
+  {
+    S12 one = s12_one();
+    w12_from_s12(acc, one);
+  }
+  const int rounds = wave_max((int)(hi - lo));
+#pragma unroll 1
+  for (int j = 0; j < rounds; ++j) {
+    const size_t idx = lo + (size_t)j;
+    const bool exists = idx < hi;
+    const size_t src = exists ? idx : 0;
+    const bool pi = exists && pinf && pinf[src], qi = exists && qinf && qinf[src];
+    const bool live = exists && !(skip_infinity && (pi || qi));
+    const bool ld = live && n_pairs != 0;
+    const Fp px = ld ? load_fp(pxy, n_pairs, src, 0) : fp_one(), py = ld ? load_fp(pxy, n_pairs, src, 4) : fp_one();
+    const S2 qx = ld ? load_s2(qxy, n_pairs, src, 0, odd) : s2_g2gen_x(), qy = ld ? load_s2(qxy, n_pairs, src, 8, odd) : s2_g2gen_y();
+    S12 fs;
+    miller_loop29g<true>(fs, px, py, qx, qy);
+    if (!live) fs = s12_one();                       // a missing or skipped pair contributes 1
+    W12 f;
+    w12_from_s12(f, fs);
+    w12_mul_nl(acc, acc, f);
+  }
+}
+
 template <int KMAX>
 __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                              const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
@@ -200,7 +233,11 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
   const size_t lo = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
   W12 acc;
-  if (KMAX == 2 && wave_max((int)(hi - lo > 2 ? 3 : hi - lo)) <= 2) glued_miller_upto2(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
+  // reference-replay mode walks a G2 identity through the formulas: only the shared-schedule loops do that
+  bool replay_identity = false;
+  if (!skip_infinity && qinf) for (size_t idx = lo; idx < hi; ++idx) replay_identity = replay_identity || qinf[idx] != 0;
+  if (KMAX != KPROD && wave_max(replay_identity ? 1 : 0) == 0 && wave_max((int)(hi - lo > 2 ? 3 : hi - lo)) <= 2) glued_miller_seq(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
+  else if (KMAX == 2 && wave_max((int)(hi - lo > 2 ? 3 : hi - lo)) <= 2) glued_miller_upto2(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
   else glued_miller_chunks<KMAX>(acc, pxy, pinf, qxy, qinf, lo, hi, n_pairs, skip_infinity, odd);
   S12 fin, g;
   w12_to_s12(fin, acc);
