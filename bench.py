@@ -393,7 +393,8 @@ def main():
         agg()
         fence()
         dta = time.perf_counter() - ta
-        agg_ok = int(is1.download()[0])
+        # AND over ranks of the per-rank aggregate booleans (a planted bad signature on any rank must reach rank 0)
+        agg_ok = sharding.all_valid(int(is1.download()[0]), dist)
         # the same with ONE signer for the whole batch: both halves collapse (n hashes, two G1 sums, a two-pair product)
         k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
         sk1, sk1one = eng.empty((4, nv)).upload(np.repeat(k1, nv, axis=1)), eng.empty((4, 1)).upload(k1)

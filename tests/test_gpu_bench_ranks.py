@@ -39,6 +39,7 @@ def test_two_rank_bench_planted_bad_signature_on_rank_1():
     out = run_bench(["--plant-bad", "1"])
     aux = out["aux"]
     assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_two_pairings"] == 0      # rank 0 sees rank 1's failure through the reduce
+    assert aux["aggregate_all_valid"] == 0 and aux["aggregate_same_signer_all_valid"] == 1   # the aggregate check sees it too
     assert aux["bad_flags_this_rank"] == 0                                       # ... although all of rank 0's own flags are set
 
 
@@ -54,4 +55,5 @@ def test_single_rank_bench_self_check():
     cfg = out["aux"]["configs"]
     assert {"C2a_fp_mul_2^20", "C2a_fp_add_2^24", "C2b_g1_scalar_mul_2^13", "C3_pairing_2^13"} <= set(cfg)
     assert all(v["pattern_ok"] == 1 for k, v in cfg.items() if k.startswith("C5_"))
-    assert out["aux"]["bls_all_valid"] == 1
+    assert out["aux"]["bls_all_valid"] == 1 and out["aux"]["aggregate_all_valid"] == 1 and out["aux"]["aggregate_same_signer_all_valid"] == 1
+    assert "C2c_g2_scalar_mul_2^13" in cfg
