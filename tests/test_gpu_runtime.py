@@ -31,7 +31,7 @@ def _evm_blob(p, q):
 
 
 def test_two_threads_two_streams_workspace_users(engine, coracle):
-    """pairing_product_batch, evm_ecpairing_batch and bls_verify_same_signer_batch interleaved from two host threads on two
+    """pairing_product_batch, evm_ecpairing_batch, bls_verify_same_signer_batch and bls_aggregate_verify_batch interleaved from two host threads on two
     non-default streams: each call leases its own scratch block, so no result may ever differ from the oracle's."""
     import torch
 
@@ -74,6 +74,11 @@ def test_two_threads_two_streams_workspace_users(engine, coracle):
                     errors.append(("evm", tid, it))
                 if not np.array_equal(eng.bls_verify_same_signer(pk, msgs, sig_bad), exp_ver):
                     errors.append(("same_signer", tid, it))
+                # aggregate verification nests three leases (hash / sums, and the two product trees)
+                if eng.bls_aggregate_verify(pk, msgs, sig)[1] != 1 or eng.bls_aggregate_verify(pk, msgs, sig_bad)[1] != 0:
+                    errors.append(("aggregate", tid, it))
+                if eng.bls_aggregate_verify(np.repeat(pk, 40, 0), msgs, sig_bad if it % 2 else sig)[1] != (0 if it % 2 else 1):
+                    errors.append(("aggregate_keys", tid, it))
         except Exception as e:  # noqa: BLE001
             errors.append(("exception", tid, repr(e)))
 
