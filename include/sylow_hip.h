@@ -325,7 +325,8 @@ int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf
  * same way, prod_i e(-H(msg_i), pk) = e(-sum_i H(msg_i), pk), and the check is n hashes + two sums + a two-pair product.  The Gt
  * value is the same group element as the reference's 2n-pair product, hence the same words.  n_pk = n: pk_xy [16][n] one key per
  * message; n_pk = 1: pk_xy [16][1].  Identity signatures / keys contribute 1 (pairing() semantics).  n = 0 gives the identity.
- * (As in the reference's example there are no random weights: it answers "is the PRODUCT the identity".)
+ * (As in the reference's example there are no random weights: it answers "is the PRODUCT the identity" -- the product sees the
+ * signatures only through their sum, so signatures permuted among the messages still pass; per-element flags: bls_verify_batch.)
  *   _partial_: f_out [48][1] = this shard's raw Miller product (for hosts that combine shards themselves,
  *              with sylow_hip_fp12_product_final_exp);
  *   _verify_:  the whole check; comm = the host's ncclComm_t for a batch sharded over the GPUs of a node (every rank passes its

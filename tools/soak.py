@@ -68,5 +68,16 @@ while time.time() - t0 < budget:
         v1 = eng.bls_verify(pk, msgs, sigb, two_pairings=not fused); v2 = eng.bls_verify(pk, msgs, sigb, two_pairings=not fused)
         assert np.array_equal(v1, v2), ("verify nondeterministic", fused, n)
         assert v1.tolist() == want or nv == 1, ("verify flags", fused, n, v1.tolist()[:8], want[:8])
-    rounds += 1; checks += 8
+    # the endomorphism-split G2 product against the generic one, and aggregate verification against the per-element flags
+    k2 = limbs([rng.fp() for _ in range(nv)])
+    ga, gai = eng.g2_scalar_mul(pk, k2, subgroup=True); gb, gbi = eng.g2_scalar_mul(pk, k2)
+    assert np.array_equal(ga, gb) and np.array_equal(gai, gbi), ("g2 split product", n)
+    ok_all = eng.bls_aggregate_verify(pk, msgs, sig)[1]
+    ok_bad = eng.bls_aggregate_verify(pk, msgs, sigb)[1]
+    # the product only sees the SUM of the signatures (like the reference's glued product): a permutation of them still passes
+    same_multiset = sorted(map(bytes, sigb)) == sorted(map(bytes, sig))
+    assert ok_all == 1 and ok_bad == (1 if same_multiset else 0), ("aggregate", n, ok_all, ok_bad, same_multiset)
+    gt_a, _ = eng.bls_aggregate_verify(pk, msgs, sigb); gt_b, _ = eng.bls_aggregate_verify(pk, msgs, sigb)
+    assert np.array_equal(gt_a, gt_b), ("aggregate nondeterministic", n)
+    rounds += 1; checks += 12
 print(f"soak ok: {rounds} rounds, {checks} cross-checks, {time.time() - t0:.0f} s")
