@@ -284,11 +284,34 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
     r.c1.c0 = w2_select(m.c1.c0, mc.c1.c0, cj); r.c1.c1 = w2_select(m.c1.c1, mc.c1.c1, cj); r.c1.c2 = w2_select(m.c1.c2, mc.c1.c2, cj);
     return r;
   };
+  // Every Gt the reference can hand out (a pairing value, products and powers of them) lies in the cyclotomic subgroup
+  // g^(p^4 - p^2 + 1) = 1, where the Granger-Scott squaring (6 Fp2 products) IS the square (12): checked per element as
+  // frob^4(g) g == frob^2(g) (~35 Fp2 products against the ~4 000 of the power), and taken when it holds for the whole wavefront --
+  // the products and conjugates the loop forms stay in the subgroup.  Other inputs keep the generic squaring: same value either way.
+  bool cyc;
+  {
+    W12 f2, f4, lhs;
+    w12_frobenius_nl<2>(f2, tab[1]);
+    w12_frobenius_nl<2>(f4, f2);
+    w12_mul_nl(lhs, f4, tab[1]);
+    S12 a, b;
+    w12_to_s12(a, lhs);
+    w12_to_s12(b, f2);
+    const bool eq = s2_eq(a.c0.c0, b.c0.c0) && s2_eq(a.c0.c1, b.c0.c1) && s2_eq(a.c0.c2, b.c0.c2) &&
+                    s2_eq(a.c1.c0, b.c1.c0) && s2_eq(a.c1.c1, b.c1.c1) && s2_eq(a.c1.c2, b.c1.c2);
+    const bool zero = s2_is_zero(b.c0.c0) && s2_is_zero(b.c0.c1) && s2_is_zero(b.c0.c2) && s2_is_zero(b.c1.c0) && s2_is_zero(b.c1.c1) && s2_is_zero(b.c1.c2);
+    cyc = wave_max((eq && !zero) ? 0 : 1) == 0;
+  }
   W12 res = entry(63);
 #pragma unroll 1
   for (int w = 62; w >= 0; --w) {
+    if (cyc) {
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) res = w12_sqr(res);
+      for (int q = 0; q < 4; ++q) w12_cyclotomic_sqr_nl(res, res);
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) res = w12_sqr(res);
+    }
     const W12 m = entry(w);
     w12_mul_nl(res, res, m);
   }

@@ -79,3 +79,16 @@ def test_gt_pow_exact_for_any_fp12_and_every_window_pattern(engine, coracle):
     # g^0 = 1 and g^1 = g for any g
     one = np.zeros(48, dtype=np.uint64); one[0] = 1
     assert np.array_equal(got[0], one) and np.array_equal(got[1], g[1])
+    # pairing values (the cyclotomic subgroup: the kernel squares them with the Granger-Scott formulas) with the same scalars, a
+    # full wavefront and a ragged tail; and a batch that MIXES them with arbitrary Fp12 values inside one wavefront (generic squarings)
+    from test_gpu_multi_pairing import G1, G2
+    from helpers import pack
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]), subgroup=True)
+    e = engine.pairing(p, q)
+    assert np.array_equal(engine.gt_pow(e, k), coracle.gt_pow(e, k))
+    mixed = e.copy()
+    mixed[3::7] = g[3::7]
+    assert np.array_equal(engine.gt_pow(mixed, k), coracle.gt_pow(mixed, k))
+    zero = np.zeros_like(e[:5])                                              # 0 is not in the subgroup (0 * 0 == 0 passes the naive check)
+    assert np.array_equal(engine.gt_pow(zero, k[5:10]), coracle.gt_pow(zero, k[5:10]))
