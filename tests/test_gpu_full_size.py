@@ -108,3 +108,24 @@ def test_c5_ecpairing_2_16_jobs(engine, k):
     _, is_one = engine.multi_pairing(p, q, np.arange(nj + 1, dtype=np.uint64) * np.uint64(k), skip_infinity=True, want_gt=False)
     expect = np.array([0 if j % 5 == 4 else 1 for j in range(nj)], dtype=np.uint8)
     assert np.array_equal(is_one, expect)
+
+
+def test_c2c_g2_scalar_mul_2_18_split_equals_generic(engine, coracle):
+    """The endomorphism-split G2 product on 2^18 r-torsion points: identical to the generic window product everywhere, a sample
+    against the oracle, and (k1 + k2) Q == k1 Q + k2 Q through the group law."""
+    n = 1 << 18
+    g2 = np.repeat(pack(G2, 16), n, 0)
+    a, b = fast_rand_fp_array(111, n, 1), fast_rand_fp_array(112, n, 1)
+    a[:, 3] >>= np.uint64(2); b[:, 3] >>= np.uint64(2)
+    q, _ = engine.g2_scalar_mul(g2, a, subgroup=True)                  # random r-torsion points
+    s1, i1 = engine.g2_scalar_mul(q, b, subgroup=True)
+    s0, i0 = engine.g2_scalar_mul(q, b)
+    assert np.array_equal(s1, s0) and np.array_equal(i1, i0) and not i1.any()
+    idx = np.random.default_rng(3).choice(n, 256, replace=False)
+    one = np.zeros((256, 8), dtype=np.uint64); one[:, 0] = 1
+    exp, _ = coracle.g2_to_affine(coracle.g2_scalar_mul(np.concatenate([q[idx], one], axis=1), b[idx]))
+    assert np.array_equal(s1[idx], exp)
+    ab, _ = engine.g2_scalar_mul(q, engine.fp_add(a, b), subgroup=True)
+    aq, _ = engine.g2_scalar_mul(q, a, subgroup=True)
+    sum_xy, sum_inf = engine.g2_add(aq, s1)
+    assert np.array_equal(sum_xy, ab) and not sum_inf.any()
