@@ -19,7 +19,7 @@ pub use device::{Device, DeviceBuf, Error};
 use crypto_bigint::U256;
 use std::os::raw::c_void;
 use std::ptr;
-use sylow::{Fp, Fp12, Fp2, Fp6, G1Affine, G1Projective, G2Affine, GroupError};
+use sylow::{Fp, Fp12, Fp2, Fp6, G1Affine, G1Projective, G2Affine, G2Projective, GroupError, GroupTrait};
 
 #[cfg(feature = "gt-from-fp12")]
 pub type GtOut = sylow::Gt;
@@ -141,6 +141,58 @@ pub fn download_g1(dev: &Device, pts: &DeviceG1) -> Result<Vec<G1Projective>, Hi
         }
     }
     Ok(out)
+}
+
+/// Device G2 batch -> `G2Projective` (affine words -> `G2Projective::new([x, y, 1])`, identity -> default).
+pub fn download_g2(dev: &Device, pts: &DeviceG2) -> Result<Vec<G2Projective>, HipError> {
+    let xy = dev.download_aos::<16>(&pts.xy, pts.n)?;
+    let inf = dev.download(&pts.inf)?;
+    let mut out = Vec::with_capacity(pts.n);
+    for (i, w) in xy.iter().enumerate() {
+        if inf[i] != 0 {
+            out.push(G2Projective::default());
+        } else {
+            let p = G2Projective::new([fp2_from_words(&w[0..8]), fp2_from_words(&w[8..16]), Fp2::new(&[Fp::ONE, Fp::ZERO])])
+                .map_err(|error| HipError::Group { index: i, error })?;
+            out.push(p);
+        }
+    }
+    Ok(out)
+}
+
+/// Batched `Mul<&Fp> for G1Projective` (group.rs:639-667): out[i] = p[i] * k[i] (the scalar is an Fp VALUE, as upstream).
+pub fn mul_g1_batch(dev: &Device, p: &[G1Affine], k: &[Fp]) -> Result<Vec<G1Projective>, HipError> {
+    assert_eq!(p.len(), k.len());
+    let n = p.len();
+    let dp = upload_g1(dev, p)?;
+    let words: Vec<[u64; 4]> = k.iter().map(|s| s.value().to_words()).collect();
+    let dk = dev.upload_soa::<4>(&words)?;
+    let out = DeviceG1 { xy: dev.alloc::<u64>(8 * n)?, inf: dev.alloc::<u8>(n)?, n };
+    // SAFETY: n points, 4 * n scalar words, n outputs.
+    device::check(unsafe { ffi::sylow_hip_g1_scalar_mul_batch(dp.xy.as_ptr(), dp.inf.as_ptr(), dk.as_ptr(), out.xy.as_mut_ptr(), out.inf.as_mut_ptr(), n, dev.stream) })?;
+    download_g1(dev, &out)
+}
+
+/// Batched `Mul<&Fp> for G2Projective`: out[i] = q[i] * k[i].  `upload_g2` has established that every q[i] is in the r-torsion
+/// (as `G2Projective::new` does upstream), so the product takes the endomorphism-split kernel.
+pub fn mul_g2_batch(dev: &Device, q: &[G2Affine], k: &[Fp]) -> Result<Vec<G2Projective>, HipError> {
+    assert_eq!(q.len(), k.len());
+    let n = q.len();
+    let dq = upload_g2(dev, q)?;
+    let words: Vec<[u64; 4]> = k.iter().map(|s| s.value().to_words()).collect();
+    let dk = dev.upload_soa::<4>(&words)?;
+    let out = DeviceG2 { xy: dev.alloc::<u64>(16 * n)?, inf: dev.alloc::<u8>(n)?, n };
+    // SAFETY: n points in G2 proper, 4 * n scalar words, n outputs.
+    device::check(unsafe {
+        ffi::sylow_hip_g2_scalar_mul_subgroup_batch(dq.xy.as_ptr(), dq.inf.as_ptr(), dk.as_ptr(), out.xy.as_mut_ptr(), out.inf.as_mut_ptr(), n, dev.stream)
+    })?;
+    download_g2(dev, &out)
+}
+
+/// `KeyPair::generate`'s public half for a batch of secret keys (lib.rs:131-137): pk[i] = G2Projective::generator() * sk[i].
+pub fn public_keys(dev: &Device, sk: &[Fp]) -> Result<Vec<G2Projective>, HipError> {
+    let gen = G2Affine::from(G2Projective::generator());
+    mul_g2_batch(dev, &vec![gen; sk.len()], sk)
 }
 
 fn messages(dev: &Device, msgs: &[&[u8]]) -> Result<(DeviceBuf<u8>, DeviceBuf<u64>), Error> {
