@@ -150,6 +150,10 @@ int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
  * sylow_hip_g2_scalar_mul_batch, which is exact on the whole curve. */
 int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k,
                                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* G2Projective::generator() * k_i for a batch of scalars -- the public half of KeyPair::generate (lib.rs:131-137): a fixed-base
+ * table of the generator (built once per device, 590 KB) turns the product into 32 additions, no doublings; same affine result
+ * as sylow_hip_g2_scalar_mul_batch on the generator. */
+int32_t sylow_hip_g2_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 /* Add for &G1Projective (group.rs:528-599) on affine inputs, affine output */
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);

@@ -19,7 +19,7 @@ pub use device::{Device, DeviceBuf, Error};
 use crypto_bigint::U256;
 use std::os::raw::c_void;
 use std::ptr;
-use sylow::{Fp, Fp12, Fp2, Fp6, G1Affine, G1Projective, G2Affine, G2Projective, GroupError, GroupTrait};
+use sylow::{Fp, Fp12, Fp2, Fp6, G1Affine, G1Projective, G2Affine, G2Projective, GroupError};
 
 #[cfg(feature = "gt-from-fp12")]
 pub type GtOut = sylow::Gt;
@@ -191,8 +191,13 @@ pub fn mul_g2_batch(dev: &Device, q: &[G2Affine], k: &[Fp]) -> Result<Vec<G2Proj
 
 /// `KeyPair::generate`'s public half for a batch of secret keys (lib.rs:131-137): pk[i] = G2Projective::generator() * sk[i].
 pub fn public_keys(dev: &Device, sk: &[Fp]) -> Result<Vec<G2Projective>, HipError> {
-    let gen = G2Affine::from(G2Projective::generator());
-    mul_g2_batch(dev, &vec![gen; sk.len()], sk)
+    let n = sk.len();
+    let words: Vec<[u64; 4]> = sk.iter().map(|s| s.value().to_words()).collect();
+    let dk = dev.upload_soa::<4>(&words)?;
+    let out = DeviceG2 { xy: dev.alloc::<u64>(16 * n)?, inf: dev.alloc::<u8>(n)?, n };
+    // SAFETY: 4 * n scalar words, n outputs; the fixed-base table of the generator lives in the library.
+    device::check(unsafe { ffi::sylow_hip_g2_generator_mul_batch(dk.as_ptr(), out.xy.as_mut_ptr(), out.inf.as_mut_ptr(), n, dev.stream) })?;
+    download_g2(dev, &out)
 }
 
 fn messages(dev: &Device, msgs: &[&[u8]]) -> Result<(DeviceBuf<u8>, DeviceBuf<u64>), Error> {

@@ -381,7 +381,8 @@ class KeyPair:
             sk = fp([secrets.randbelow(R_ORDER) for _ in range(n)])
         else:
             sk = Fr.rand(n, seed).v
-        return cls(sk, G2Affine.generator(n) * sk)
+        xy, inf = engine().g2_generator_mul(sk)          # fixed-base table of the generator
+        return cls(sk, G2Affine(xy, inf)._checked())
 
     def __len__(self):
         return self.secret_key.shape[0]

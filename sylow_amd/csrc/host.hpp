@@ -30,7 +30,8 @@ struct Lease {
 };
 // per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
 int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair line table (plk_common.hpp: LINE_TABLE_WORDS)
-int32_t gen_lines_sat(const u32** out, hipStream_t st);         // single-lane Montgomery layout [87][48] uint32
+int32_t gen_lines_sat(const u32** out, hipStream_t st);
+int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use         // single-lane Montgomery layout [87][48] uint32
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 }  // namespace host
 
@@ -71,6 +72,8 @@ int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc,
 namespace plkh {        // lane-pair units
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
 size_t line_table_bytes();                                                                             // plk_verify.hip
+size_t g2_comb_bytes();                                                                                // plk_group.hip
+int32_t build_g2_comb(bn254::i32* table, void* stream);                                                // plk_group.hip
 // plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
 }  // namespace plkh

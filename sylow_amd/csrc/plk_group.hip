@@ -143,6 +143,63 @@ BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int od
   store_s2(oxy, n, i, 0, odd, x); store_s2(oxy, n, i, 8, odd, y);
   if (!odd) oinf[i] = rinf ? 1 : 0;
 }
+// ------------------------------------------------------------------ k * G2gen with a fixed-base table ---------------------------
+// KeyPair::generate's public half (lib.rs:131-137: G2Projective::generator() * secret_key) for a batch of keys.  The base never
+// changes, so k mod r is cut into 32 signed 8-bit digits and the product is 32 complete additions of table entries
+// T[w][j] = j 256^w G (j = 1..128, affine, R-class lane-pair digits) -- no doublings.  The table (32 x 128 x 36 words = 590 KB,
+// resident in L2 / MALL) is built once per device by 4096 lane pairs, each with the generic window product.
+constexpr int COMB_WIN = 32, COMB_ENT = 128;
+constexpr size_t COMB_WORDS = (size_t)COMB_WIN * COMB_ENT * 36;
+__global__ void HEAVY_BOUNDS k_g2_comb_table(i32* table) {
+  const size_t t = TID, e = t >> 1;
+  const int odd = (int)(t & 1);
+  if (e >= (size_t)COMB_WIN * COMB_ENT) return;
+  const int w = (int)(e / COMB_ENT), j = (int)(e % COMB_ENT) + 1;
+  u32 k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (q == (w >> 2)) k[q] = (u32)j << (8 * (w & 3));
+  const G2Q g{w2_from_s2(s2_g2gen_x()), w2_from_s2(s2_g2gen_y()), OpsW2::one()};
+  G2Q r;
+  g2q_scalar_mul(r, g, k);
+  S2 x, y; bool inf;
+  g2q_to_affine(x, y, inf, r);                      // never the identity: j 256^w < r
+  const W2 wx = w2_from_s2(x), wy = w2_from_s2(y);
+  i32* dst = table + e * 36;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { dst[odd * 9 + q] = wx.c.v[q]; dst[18 + odd * 9 + q] = wy.c.v[q]; }
+}
+__global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __restrict__ table, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);   // k mod r (k < p < 2r)
+  G2Q res = proj_zero<OpsW2>();
+  int carry = 0;
+#pragma unroll 1
+  for (int w = 0; w < COMB_WIN; ++w) {
+    u32 byte = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q == (w >> 2)) byte = (k[q] >> (8 * (w & 3))) & 255u;
+    int d = (int)byte + carry;
+    carry = d >= 128;
+    d -= carry << 8;                                  // d in [-128, 127]; k < 2^254 leaves no carry out of the last window
+    const int mag = d < 0 ? -d : d;
+    const i32* src = table + ((size_t)w * COMB_ENT + (size_t)(mag ? mag - 1 : 0)) * 36;
+    W2 ex, ey;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { ex.c.v[q] = src[odd * 9 + q]; ey.c.v[q] = src[18 + odd * 9 + q]; }
+    const bool nz = mag != 0;
+    G2Q q2;                                           // digit 0 adds the identity (0 : 1 : 0): the formulas are complete
+    q2.x = OpsW2::select(OpsW2::zero(), ex, nz);
+    q2.y = OpsW2::select(OpsW2::one(), OpsW2::select(ey, OpsW2::neg(ey), d < 0), nz);
+    q2.z = OpsW2::select(OpsW2::zero(), OpsW2::one(), nz);
+    g2q_add(res, res, q2);
+  }
+  store_g2q_affine(oxy, oinf, n, i, odd, res);
+}
+
 __global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
@@ -406,6 +463,10 @@ __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t
 }
 
 namespace plkh {
+size_t g2_comb_bytes() { return plk::COMB_WORDS * sizeof(bn254::i32); }
+int32_t build_g2_comb(bn254::i32* table, void* stream) {
+  plk::k_g2_comb_table<<<GRID(2 * (size_t)plk::COMB_WIN * plk::COMB_ENT)>>>(table); LAUNCHED();
+}
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream) {
   k_evm_decode_pairs<<<dim3((unsigned)((2 * n_pairs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream>>>(in, n_pairs, pxy, pinf, qxy, qinf, pst);
   LAUNCHED();
@@ -422,6 +483,13 @@ int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
   plk::k_g2_scalar_mul_gls<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  const bn254::i32* table = nullptr;
+  int32_t rc = host::g2_gen_comb(&table, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_g2_generator_mul<<<GRID(2 * n)>>>(k, table, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;

@@ -229,6 +229,15 @@ class Engine:
         """k * P on the twist; subgroup=True: P is known to be in the r-torsion (4-way endomorphism split, ~1.8x faster)."""
         return self._scalar_mul("sylow_hip_g2_scalar_mul_subgroup_batch" if subgroup else "sylow_hip_g2_scalar_mul_batch", 16, p_xy, p_inf, k)
 
+    def g2_generator_mul(self, k):
+        """G2gen * k_i (the keygen shape) through the device's fixed-base table."""
+        k = _aos(k, 4)
+        n = k.shape[0]
+        dk = self.to_device_soa(k, 4)
+        do, doi = self.empty((16, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_g2_generator_mul_batch", dk.ptr, do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
     def g1_add(self, a_xy, b_xy, a_inf=None, b_inf=None):
         a_xy, b_xy = _aos(a_xy, 8), _aos(b_xy, 8)
         n = a_xy.shape[0]

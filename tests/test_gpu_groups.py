@@ -242,3 +242,23 @@ def test_g2_scalar_mul_subgroup_split_vs_generic_and_oracle(engine, coracle):
     psi_xy, _, _ = engine.g2_psi(base[:8])
     lam_q, _ = engine.g2_scalar_mul(base[:8], limbs([lam] * 8), subgroup=True)
     assert np.array_equal(lam_q, psi_xy)
+
+
+def test_g2_generator_mul_fixed_base_table(engine, coracle):
+    """sylow_hip_g2_generator_mul_batch (32 signed 8-bit digits against the device's table j 256^w G) == the window product of the
+    generator == the oracle, for scalars that hit digit 0, +-128, carries through every window, k >= r, and random ones."""
+    r = R.R_ORDER
+    rng = Xoshiro(SEED + 28)
+    edge = [0, 1, 2, 127, 128, 129, 255, 256, 257, (1 << 8) - 1, (1 << 248), (1 << 253) + 128, r - 1, r, r + 1, P - 1,
+            int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), int("0180" * 15, 16), R.BLS_X]
+    ks = [k % P for k in edge] + [rng.fp() for _ in range(100 - len(edge))]
+    n = len(ks)
+    got, got_inf = engine.g2_generator_mul(limbs(ks))
+    ref, ref_inf = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs(ks))
+    assert np.array_equal(got, ref) and np.array_equal(got_inf, ref_inf)
+    assert got_inf.tolist() == [1 if k % r == 0 else 0 for k in ks]
+    exp, exp_inf = coracle.g2_to_affine(coracle.g2_scalar_mul(g2_proj(np.repeat(pack(G2, 16), 24, 0)), limbs(ks[:24])))
+    assert np.array_equal(got[:24], exp) and np.array_equal(got_inf[:24], exp_inf)
+    # a second call reuses the table
+    again, _ = engine.g2_generator_mul(limbs(ks))
+    assert np.array_equal(again, got)

@@ -21,3 +21,4 @@ for rep in range(2):
     print("miller       %.2f ms" % timed(lambda: eng._call("sylow_hip_miller_loop_batch", p.ptr, q.ptr, gt.ptr, n)))
     print("subgroup     %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_subgroup_check_batch", q.ptr, None, ok.ptr, n)))
     print("g2_mul_subgr %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", q.ptr, None, kb.ptr, o2.ptr, o2i.ptr, n)))
+    print("g2_generator %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_generator_mul_batch", kb.ptr, o2.ptr, o2i.ptr, n)))
