@@ -78,14 +78,12 @@ def limbs_row(vals):
 
 def make_points(eng, n, seed):
     """P_i = a_i*G1gen, Q_i = b_i*G2gen generated on the device from the xoshiro stream; returns SoA device arrays."""
-    g1 = eng.empty((8, n)).upload(np.repeat(limbs_row(G1).T, n, axis=1))
-    g2 = eng.empty((16, n)).upload(np.repeat(limbs_row(G2).T, n, axis=1))
     ka = eng.empty((4, n)).upload(eng.xoshiro_fp_soa(seed, n))
     kb = eng.empty((4, n)).upload(eng.xoshiro_fp_soa(seed + (1 << 32), n))
     p, pi = eng.empty((8, n)), eng.empty((n,), np.uint8)
     q, qi = eng.empty((16, n)), eng.empty((n,), np.uint8)
-    eng._call("sylow_hip_g1_scalar_mul_batch", g1.ptr, None, ka.ptr, p.ptr, pi.ptr, n)
-    eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2.ptr, None, kb.ptr, q.ptr, qi.ptr, n)
+    eng._call("sylow_hip_g1_generator_mul_batch", ka.ptr, p.ptr, pi.ptr, n)          # fixed-base tables of the generators
+    eng._call("sylow_hip_g2_generator_mul_batch", kb.ptr, q.ptr, qi.ptr, n)
     eng.sync()
     return p, q, ka, kb
 

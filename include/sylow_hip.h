@@ -154,6 +154,8 @@ int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8
  * table of the generator (built once per device, 590 KB) turns the product into 32 additions, no doublings; same affine result
  * as sylow_hip_g2_scalar_mul_batch on the generator. */
 int32_t sylow_hip_g2_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* The same for G1Projective::generator() * k_i (GroupTrait::rand, test data): 295 KB table, 32 additions. */
+int32_t sylow_hip_g1_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 /* Add for &G1Projective (group.rs:528-599) on affine inputs, affine output */
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sylow_hip_g1_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_generator_mul_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_generator_mul_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_scalar_mul_subgroup_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g1_add_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g1_normalize_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],

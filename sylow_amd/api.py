@@ -130,7 +130,8 @@ class G1Affine(_Points):
 
     @classmethod
     def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g1.rs:293-305): generator * random scalar (seeded, reproducible)
-        return cls.generator(n) * engine().xoshiro_fp_soa(seed, n).T.copy()
+        xy, inf = engine().g1_generator_mul(engine().xoshiro_fp_soa(seed, n).T.copy())
+        return cls(xy, inf)
 
     def to_be_bytes(self):                         # g1.rs:151-180
         return engine().g1_to_be_bytes(self.xy, self.infinity)
@@ -199,7 +200,8 @@ class G2Affine(_Points):
 
     @classmethod
     def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g2.rs:204-240): a random r-torsion point (generator * random scalar)
-        return cls.generator(n) * engine().xoshiro_fp_soa(seed, n).T.copy()
+        xy, inf = engine().g2_generator_mul(engine().xoshiro_fp_soa(seed, n).T.copy())
+        return cls(xy, inf)._checked()
 
     def to_be_bytes(self):                         # g2.rs:319-359
         return engine().g2_to_be_bytes(self.xy, self.infinity)

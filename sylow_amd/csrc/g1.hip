@@ -64,6 +64,63 @@ __global__ void __launch_bounds__(BLOCK) k_g1_normalize(const u64* pxyz, u64* ox
   oinf[i] = rinf ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ k * G1gen with a fixed-base table ----------
+// G1Projective::generator() * k for a batch of scalars (test data, GroupTrait::rand): k mod r as 32 signed 8-bit digits against a
+// per-device table T[w][j] = j 256^w G (j = 1..128, affine, reduced carry-free digits, 32 x 128 x 18 words = 295 KB): 32 complete
+// additions, no doublings.  The twin of plk_group.hip's G2 table.
+constexpr int COMB_WIN = 32, COMB_ENT = 128;
+constexpr size_t COMB1_WORDS = (size_t)COMB_WIN * COMB_ENT * 18;
+__global__ void HEAVY_BOUNDS k_g1_comb_table(i32* table) {
+  const size_t e = TID;
+  if (e >= (size_t)COMB_WIN * COMB_ENT) return;
+  const int w = (int)(e / COMB_ENT), j = (int)(e % COMB_ENT) + 1;
+  if (w == COMB_WIN - 1 && j > 64) return;            // k mod r < 2^254: the top digit is at most 0x30 + 1, these entries are never read
+  u32 k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (q == (w >> 2)) k[q] = (u32)j << (8 * (w & 3));
+  const G1P g{fp_one(), fp_small(2), fp_one()};
+  const G1P r = g1_scalar_mul(g, k);                  // GLV window product (k < 2^256 is reduced mod r inside)
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, r);                         // never the identity: j 256^w < r
+  const F29 fx = f29_from_fp_reduced(x), fy = f29_from_fp_reduced(y);
+  i32* dst = table + e * 18;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { dst[q] = fx.v[q]; dst[9 + q] = fy.v[q]; }
+}
+__global__ void HEAVY_BOUNDS k_g1_generator_mul(const u64* ks, const i32* __restrict__ table, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t i = TID;
+  if (i >= n) return;
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);   // k mod r (k < p < 2r)
+  G1W res = proj_zero<OpsF29>();
+  int carry = 0;
+#pragma unroll 1
+  for (int w = 0; w < COMB_WIN; ++w) {
+    u32 byte = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q == (w >> 2)) byte = (k[q] >> (8 * (w & 3))) & 255u;
+    int d = (int)byte + carry;
+    carry = d >= 128;
+    d -= carry << 8;                                  // d in [-128, 127]; k < 2^254 leaves no carry out of the last window
+    const int mag = d < 0 ? -d : d;
+    const i32* src = table + ((size_t)w * COMB_ENT + (size_t)(mag ? mag - 1 : 0)) * 18;
+    F29 ex, ey;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { ex.v[q] = src[q]; ey.v[q] = src[9 + q]; }
+    const bool nz = mag != 0;
+    G1W q1;                                           // digit 0 adds the identity (0 : 1 : 0): the formulas are complete
+    q1.x = OpsF29::select(OpsF29::zero(), ex, nz);
+    q1.y = OpsF29::select(OpsF29::one(), OpsF29::select(ey, OpsF29::neg(ey), d < 0), nz);
+    q1.z = OpsF29::select(OpsF29::zero(), OpsF29::one(), nz);
+    res = proj_add<OpsF29>(res, q1);
+  }
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, G1P{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)});
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ sum of a batch of G1 points ----------
 // sum_i P_i as a log-depth tree of complete additions on a projective scratch array acc [12][n] (canonical words): the G1 side of
 // aggregate verification (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen)).  init: affine + flags -> projective; level: element t
@@ -235,6 +292,10 @@ __global__ void __launch_bounds__(BLOCK) k_g1_double(const u64* axy, const uint8
 
 // ================================================================== C ABI ======================
 namespace g1h {
+size_t g1_comb_bytes() { return COMB1_WORDS * sizeof(bn254::i32); }
+int32_t build_g1_comb(bn254::i32* table, void* stream) {
+  k_g1_comb_table<<<GRID((size_t)COMB_WIN * COMB_ENT)>>>(table); LAUNCHED();
+}
 int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate); LAUNCHED();
@@ -270,6 +331,13 @@ int32_t sylow_hip_g1_on_curve_batch(const uint64_t* p_xy, const uint8_t* p_inf, 
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   k_g1_normalize<<<GRID(n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  const bn254::i32* table = nullptr;
+  int32_t rc = host::g1_gen_comb(&table, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  k_g1_generator_mul<<<GRID(n)>>>(k, table, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
                                    uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {

@@ -31,6 +31,7 @@ struct Lease {
 // per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
 int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair line table (plk_common.hpp: LINE_TABLE_WORDS)
 int32_t gen_lines_sat(const u32** out, hipStream_t st);
+int32_t g1_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G1 generator (g1.hip), built on first use
 int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use         // single-lane Montgomery layout [87][48] uint32
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 }  // namespace host
@@ -64,6 +65,8 @@ int32_t build_gen_lines(u32* table, void* stream);              // k_g2_lines on
 int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);   // k_fp12_op selectors 0..11
 }  // namespace single
 namespace g1h {         // g1.hip
+size_t g1_comb_bytes();
+int32_t build_g1_comb(bn254::i32* table, void* stream);
 // H(m_i) (or -H(m_i)) affine with the library DST, SoA stride n
 int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream);
 // sum_i P_i (or its negative) -> column `col` of an affine SoA array of stride `stride`; acc: scratch of 12 n words

@@ -197,7 +197,7 @@ void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
 namespace {
 constexpr int MAX_DEV = 64;
 struct Block { void* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool recorded = false, leased = false; };
-struct DevState { std::vector<Block> blocks; bn254::i32* gen29 = nullptr; u32* gensat = nullptr; bn254::i32* g2comb = nullptr; };
+struct DevState { std::vector<Block> blocks; bn254::i32* gen29 = nullptr; u32* gensat = nullptr; bn254::i32* g2comb = nullptr; bn254::i32* g1comb = nullptr; };
 std::mutex g_mu;               // guards g_dev (bookkeeping + one-time table construction); never held across a user kernel
 DevState g_dev[MAX_DEV];
 int32_t current_device(int& d) {
@@ -303,6 +303,23 @@ int32_t gen_lines29(const bn254::i32** out, hipStream_t st) {
   *out = D.gen29;
   return SYLOW_HIP_OK;
 }
+int32_t g1_gen_comb(const bn254::i32** out, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  int d = 0;
+  int32_t rc = current_device(d);
+  if (rc != SYLOW_HIP_OK) return rc;
+  DevState& D = g_dev[d];
+  if (!D.g1comb) {
+    bn254::i32* t = nullptr;
+    HIPCHK(hipMalloc((void**)&t, g1h::g1_comb_bytes()));
+    rc = g1h::build_g1_comb(t, st);
+    hipError_t e = (rc == SYLOW_HIP_OK) ? hipStreamSynchronize(st) : hipSuccess;
+    if (rc != SYLOW_HIP_OK || e != hipSuccess) { (void)hipFree(t); return rc != SYLOW_HIP_OK ? rc : fail(e, "G1 generator comb table"); }
+    D.g1comb = t;
+  }
+  *out = D.g1comb;
+  return SYLOW_HIP_OK;
+}
 int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_mu);
   int d = 0;
@@ -387,7 +404,7 @@ int32_t sylow_hip_shutdown(void) {
   int32_t rc = SYLOW_HIP_OK;
   for (int d = 0; d < host::MAX_DEV; ++d) {
     host::DevState& D = host::g_dev[d];
-    if (D.blocks.empty() && !D.gen29 && !D.gensat && !D.g2comb) continue;
+    if (D.blocks.empty() && !D.gen29 && !D.gensat && !D.g2comb && !D.g1comb) continue;
     if (hipSetDevice(d) != hipSuccess) { rc = SYLOW_HIP_E_HIP; continue; }
     hipError_t e = hipDeviceSynchronize();          // nothing may still be reading a block or a table
     if (e != hipSuccess) rc = host::fail(e, "hipDeviceSynchronize(shutdown)");
@@ -399,6 +416,7 @@ int32_t sylow_hip_shutdown(void) {
     if (D.gen29) { (void)hipFree(D.gen29); D.gen29 = nullptr; }
     if (D.gensat) { (void)hipFree(D.gensat); D.gensat = nullptr; }
     if (D.g2comb) { (void)hipFree(D.g2comb); D.g2comb = nullptr; }
+    if (D.g1comb) { (void)hipFree(D.g1comb); D.g1comb = nullptr; }
   }
   if (have_prev) (void)hipSetDevice(prev);
   return rc;

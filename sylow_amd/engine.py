@@ -231,11 +231,18 @@ class Engine:
 
     def g2_generator_mul(self, k):
         """G2gen * k_i (the keygen shape) through the device's fixed-base table."""
+        return self._generator_mul("sylow_hip_g2_generator_mul_batch", 16, k)
+
+    def g1_generator_mul(self, k):
+        """G1gen * k_i through the device's fixed-base table."""
+        return self._generator_mul("sylow_hip_g1_generator_mul_batch", 8, k)
+
+    def _generator_mul(self, name, width, k):
         k = _aos(k, 4)
         n = k.shape[0]
         dk = self.to_device_soa(k, 4)
-        do, doi = self.empty((16, n)), self.empty((n,), np.uint8)
-        self._call("sylow_hip_g2_generator_mul_batch", dk.ptr, do.ptr, doi.ptr, n)
+        do, doi = self.empty((width, n)), self.empty((n,), np.uint8)
+        self._call(name, dk.ptr, do.ptr, doi.ptr, n)
         return self.from_device_soa(do), doi.download()
 
     def g1_add(self, a_xy, b_xy, a_inf=None, b_inf=None):

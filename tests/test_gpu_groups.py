@@ -262,3 +262,20 @@ def test_g2_generator_mul_fixed_base_table(engine, coracle):
     # a second call reuses the table
     again, _ = engine.g2_generator_mul(limbs(ks))
     assert np.array_equal(again, got)
+
+
+def test_g1_generator_mul_fixed_base_table(engine, coracle):
+    """sylow_hip_g1_generator_mul_batch == the GLV window product of the generator == the oracle (same scalar set as the G2 table)."""
+    r = R.R_ORDER
+    rng = Xoshiro(SEED + 29)
+    edge = [0, 1, 2, 127, 128, 129, 255, 256, 257, (1 << 248), (1 << 253) + 128, r - 1, r, r + 1, P - 1, P - 2,
+            int("80" * 31, 16), int("7f" * 31, 16), int("ff" * 31, 16), int("0180" * 15, 16), int("30" + "ff" * 31, 16)]
+    ks = [k % P for k in edge] + [rng.fp() for _ in range(130 - len(edge))]
+    n = len(ks)
+    got, got_inf = engine.g1_generator_mul(limbs(ks))
+    ref, ref_inf = engine.g1_scalar_mul(np.repeat(pack([1, 2], 8), n, 0), limbs(ks))
+    assert np.array_equal(got, ref) and np.array_equal(got_inf, ref_inf)
+    assert got_inf.tolist() == [1 if k % r == 0 else 0 for k in ks]
+    one = np.zeros((32, 4), dtype=np.uint64); one[:, 0] = 1
+    exp, _ = coracle.g1_to_affine(coracle.g1_scalar_mul(np.concatenate([np.repeat(pack([1, 2], 8), 32, 0), one], axis=1), limbs(ks[:32])))
+    assert np.array_equal(got[:32][~got_inf[:32].astype(bool)], exp[~got_inf[:32].astype(bool)])

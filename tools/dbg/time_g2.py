@@ -22,3 +22,4 @@ for rep in range(2):
     print("subgroup     %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_subgroup_check_batch", q.ptr, None, ok.ptr, n)))
     print("g2_mul_subgr %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", q.ptr, None, kb.ptr, o2.ptr, o2i.ptr, n)))
     print("g2_generator %.2f ms" % timed(lambda: eng._call("sylow_hip_g2_generator_mul_batch", kb.ptr, o2.ptr, o2i.ptr, n)))
+    print("g1_generator %.2f ms" % timed(lambda: eng._call("sylow_hip_g1_generator_mul_batch", ka.ptr, o1.ptr, o1i.ptr, n)))
