@@ -247,6 +247,12 @@ int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_o
  * pointer to the domain separation tag (NULL -> sylow's DST, lib.rs:90). */
 int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
                                    uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* SvdW::unchecked_map_to_point (svdw.rs:180-262, RFC 9380 6.6.1 straight line, Z = 1) by itself: u [4][n] -> (x, y) [8][n] on the
+ * curve; status (may be NULL) = CANNOT_HASH where the reference returns MapError. */
+int32_t sylow_hip_svdw_map_batch(const uint64_t* u, uint64_t* out_xy, uint8_t* status, size_t n, void* stream);
+/* Fp::compute_naf (fp.rs:653-662) on the raw 256-bit words k [4][n]: out_np / out_nm [4][n] = the masks of the +1 / -1 digits
+ * (digit_i = np_i - nm_i; x + (x >> 1) is taken modulo 2^256 exactly as the reference's 256-bit arithmetic does). */
+int32_t sylow_hip_fp_compute_naf_batch(const uint64_t* k, uint64_t* out_np, uint64_t* out_nm, size_t n, void* stream);
 /* sign(&Fp, &[u8]) (lib.rs:179-187): sig_i = sk_i * H(msg_i), affine out */
 int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                  uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream);

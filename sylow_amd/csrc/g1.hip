@@ -165,6 +165,40 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const
   oinf[i] = inf ? 1 : 0;
   if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
 }
+// SvdW::unchecked_map_to_point (svdw.rs:180-262) on its own: u -> (x, y) on the curve; status CANNOT_HASH where the reference
+// returns MapError (cannot happen on this curve)
+__global__ void __launch_bounds__(BLOCK) k_svdw_map(const u64* u, u64* oxy, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  Fp x, y;
+  const bool ok = svdw_map(x, y, load_fp(u, n, i, 0));
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
+}
+// Fp::compute_naf (fp.rs:653-662): the two 256-bit masks (np, nm) of the +1 / -1 digits of the RAW 256-bit value, digit_i = np_i - nm_i
+__global__ void __launch_bounds__(BLOCK) k_compute_naf(const u64* k, u64* onp, u64* onm, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  u64 x[4], xh[4], x3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = k[(size_t)j * n + i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xh[j] = (x[j] >> 1) | (j < 3 ? (x[j + 1] << 63) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                        // x + (x >> 1) modulo 2^256
+    const u64 s = x[j] + xh[j];
+    const u64 s2 = s + c;
+    c = (s < x[j] || s2 < s) ? 1 : 0;
+    x3[j] = s2;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u64 d = xh[j] ^ x3[j];
+    onp[(size_t)j * n + i] = x3[j] & d;
+    onm[(size_t)j * n + i] = xh[j] & d;
+  }
+}
 // Expander::hash_to_field(msg, 2, 48) (hasher.rs:84-128) over XMDExpander<Keccak256>::expand_message (hasher.rs:201-250)
 __global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, const u64* off, DstPrime dp, u64* out, size_t n) {
   size_t i = TID;
@@ -344,6 +378,14 @@ int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offs
   ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
   k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, 0); LAUNCHED();
+}
+int32_t sylow_hip_svdw_map_batch(const uint64_t* u, uint64_t* out_xy, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(u && out_xy); if (!n) return SYLOW_HIP_OK;
+  k_svdw_map<<<GRID(n)>>>(u, out_xy, status, n); LAUNCHED();
+}
+int32_t sylow_hip_fp_compute_naf_batch(const uint64_t* k, uint64_t* out_np, uint64_t* out_nm, size_t n, void* stream) {
+  ARGCHK(k && out_np && out_nm); if (!n) return SYLOW_HIP_OK;
+  k_compute_naf<<<GRID(n)>>>(k, out_np, out_nm, n); LAUNCHED();
 }
 int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* dst_host, size_t dst_len,
                                       uint64_t* out_u, size_t n, void* stream) {

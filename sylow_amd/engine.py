@@ -483,6 +483,24 @@ class Engine:
         blob = np.frombuffer(b"".join(msgs) or b"\x00", dtype=np.uint8)
         return self.to_device(blob), self.to_device(off)
 
+    def svdw_map(self, u):
+        """SvdW map of field elements u [n, 4] -> (xy [n, 8], status [n])."""
+        u = _aos(u, 4)
+        n = u.shape[0]
+        du = self.to_device_soa(u, 4)
+        do, ds = self.empty((8, n)), self.empty((n,), np.uint8)
+        self._call("sylow_hip_svdw_map_batch", du.ptr, do.ptr, ds.ptr, n)
+        return self.from_device_soa(do), ds.download()
+
+    def fp_compute_naf(self, k):
+        """Fp::compute_naf on raw 256-bit values k [n, 4] -> (np [n, 4], nm [n, 4])."""
+        k = _aos(k, 4)
+        n = k.shape[0]
+        dk = self.to_device_soa(k, 4)
+        dp, dm = self.empty((4, n)), self.empty((4, n))
+        self._call("sylow_hip_fp_compute_naf_batch", dk.ptr, dp.ptr, dm.ptr, n)
+        return self.from_device_soa(dp), self.from_device_soa(dm)
+
     def hash_to_field(self, msgs, dst: bytes | None = None):
         n = len(msgs)
         dm, doff = self._msgs(msgs)

@@ -167,3 +167,24 @@ def test_hash_to_field_vs_oracle(engine, coracle):
             want = [int.from_bytes(em[:48], "big") % R.P, int.from_bytes(em[48:], "big") % R.P]
             have = [sum(int(got[i, 4 * c + k]) << (64 * k) for k in range(4)) for c in range(2)]
             assert have == want, (i, dst)
+
+
+def test_svdw_map_and_compute_naf_entry_points(engine, coracle):
+    """a30 / a6 of the scope table as entry points of their own: SvdW::unchecked_map_to_point (svdw.rs:180-262) against both oracles
+    on edge and random field elements, and Fp::compute_naf (fp.rs:653-662) on raw 256-bit values incl. the wrap at 2^256."""
+    rng = Xoshiro(SEED + 33)
+    us = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 3, 4] + [rng.fp() for _ in range(120)]
+    xy, st = engine.svdw_map(limbs(us))
+    assert not st.any()
+    assert np.array_equal(xy, coracle.svdw_map(limbs(us)))
+    got = ints(xy)
+    for i in (0, 1, 3, 9, 50):
+        x, y = R.svdw_map_to_point(us[i])
+        assert got[2 * i: 2 * i + 2] == [x, y] and R.g1_is_on_curve_affine(x, y)
+    ks = [0, 1, 2, 3, 5, 7, (1 << 256) - 1, 1 << 255, (1 << 255) - 1, R.R_ORDER, P, int("a" * 64, 16), int("5" * 64, 16), int("6" * 64, 16)] + [rng.u256() for _ in range(86)]
+    kw = np.array([[(k >> (64 * j)) & ((1 << 64) - 1) for j in range(4)] for k in ks], dtype=np.uint64)
+    np_, nm_ = engine.fp_compute_naf(kw)
+    for i, k in enumerate(ks):
+        ep, em = R.compute_naf(k)
+        assert sum(int(np_[i, j]) << (64 * j) for j in range(4)) == ep and sum(int(nm_[i, j]) << (64 * j) for j in range(4)) == em, hex(k)
+        assert ep & em == 0 and (ep | em) & ((ep | em) << 1) & ((1 << 256) - 1) == 0 or k >= (1 << 255)      # non-adjacent form
