@@ -118,6 +118,13 @@ int32_t sylow_hip_fr_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void*
 
 /* ---- extension tower (test hooks): fields/fp2.rs:285-306,164-171,355-360; fp6.rs:283-367,
  * 415-423; fp12.rs:229-238,536-550,281-286,515-522,426-503 ------------------------------------ */
+/* FieldExtension<D, N, F> component-wise operators (fields/extensions.rs:67-238): Add / Sub / Neg and scale by a base-field
+ * element, for Fp2 / Fp6 / Fp12 batches: degree = 2, 6 or 12 Fp coefficients, arrays [4 * degree][n]; the scale factor k is one Fp
+ * per element, [4][n]. */
+int32_t sylow_hip_fext_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t degree, size_t n, void* stream);
+int32_t sylow_hip_fext_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t degree, size_t n, void* stream);
+int32_t sylow_hip_fext_neg_batch(const uint64_t* a, uint64_t* out, int32_t degree, size_t n, void* stream);
+int32_t sylow_hip_fext_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, int32_t degree, size_t n, void* stream);
 int32_t sylow_hip_fp2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp2_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp2_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);

@@ -64,6 +64,10 @@ SIGNATURES = {
     "sylow_hip_final_exp_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_pairing_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_vp],
     "sylow_hip_multi_pairing_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz, c_i32, c_u64p, c_u8p, c_vp],
+    "sylow_hip_fext_add_batch": [c_u64p, c_u64p, c_u64p, ctypes.c_int32, c_sz, c_vp],
+    "sylow_hip_fext_sub_batch": [c_u64p, c_u64p, c_u64p, ctypes.c_int32, c_sz, c_vp],
+    "sylow_hip_fext_neg_batch": [c_u64p, c_u64p, ctypes.c_int32, c_sz, c_vp],
+    "sylow_hip_fext_scale_batch": [c_u64p, c_u64p, c_u64p, ctypes.c_int32, c_sz, c_vp],
     "sylow_hip_svdw_map_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_fp_compute_naf_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_hash_to_field_batch": [c_u8p, c_u64p, ctypes.c_char_p, c_sz, c_u64p, c_sz, c_vp],

@@ -454,6 +454,31 @@ FP_BIN(fr, 1, add, OP_ADD) FP_BIN(fr, 1, sub, OP_SUB) FP_BIN(fr, 1, mul, OP_MUL)
 FP_UN(fp, 0, sqr, OP_SQR) FP_UN(fp, 0, neg, OP_NEG) FP_UN(fp, 0, inv, OP_INV)
 FP_UN(fr, 1, sqr, OP_SQR) FP_UN(fr, 1, neg, OP_NEG) FP_UN(fr, 1, inv, OP_INV)
 
+// FieldExtension<D, N, F> component-wise operators (extensions.rs:67-238: Add / Sub / Neg and scale by a base-field element) for
+// Fp2 / Fp6 / Fp12 batches: an extension value is `degree` Fp coefficients, a batch [4 * degree][n] is `degree` consecutive Fp
+// planes of [4][n], so each operator is the Fp kernel once per coefficient (HBM-bound like the Fp micro-batches).
+#define FEXT_CHECK() ARGCHK(a && out && (degree == 2 || degree == 6 || degree == 12)); if (!n) return SYLOW_HIP_OK
+int32_t sylow_hip_fext_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t degree, size_t n, void* stream) {
+  FEXT_CHECK(); ARGCHK(b);
+  for (int c = 0; c < degree; ++c) k_fp_binop<OP_ADD, 0><<<GRID((n + 1) / 2)>>>(a + 4 * n * c, b + 4 * n * c, out + 4 * n * c, n);
+  LAUNCHED();
+}
+int32_t sylow_hip_fext_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, int32_t degree, size_t n, void* stream) {
+  FEXT_CHECK(); ARGCHK(b);
+  for (int c = 0; c < degree; ++c) k_fp_binop<OP_SUB, 0><<<GRID((n + 1) / 2)>>>(a + 4 * n * c, b + 4 * n * c, out + 4 * n * c, n);
+  LAUNCHED();
+}
+int32_t sylow_hip_fext_neg_batch(const uint64_t* a, uint64_t* out, int32_t degree, size_t n, void* stream) {
+  FEXT_CHECK();
+  for (int c = 0; c < degree; ++c) k_fp_unop<OP_NEG, 0><<<GRID((n + 1) / 2)>>>(a + 4 * n * c, out + 4 * n * c, n);
+  LAUNCHED();
+}
+// scale(&self, factor: F) with a base-field factor k_i [4][n] per element (extensions.rs:121-139 applied down to Fp)
+int32_t sylow_hip_fext_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, int32_t degree, size_t n, void* stream) {
+  FEXT_CHECK(); ARGCHK(k);
+  for (int c = 0; c < degree; ++c) k_fp_binop<OP_MUL, 0><<<GRID((n + 1) / 2)>>>(a + 4 * n * c, k, out + 4 * n * c, n);
+  LAUNCHED();
+}
 int32_t sylow_hip_fp_pow_batch(const uint64_t* a, const uint64_t* e, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && e && out); if (!n) return SYLOW_HIP_OK; k_fp_pow<<<GRID(n)>>>(a, e, out, n); LAUNCHED();
 }

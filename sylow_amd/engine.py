@@ -483,6 +483,19 @@ class Engine:
         blob = np.frombuffer(b"".join(msgs) or b"\x00", dtype=np.uint8)
         return self.to_device(blob), self.to_device(off)
 
+    def fext_op(self, op, a, b=None):
+        """Component-wise FieldExtension operators on Fp2 / Fp6 / Fp12 batches: op in add / sub / neg / scale (b = one Fp per element)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        n, width = a.shape
+        degree = width // 4
+        da, do = self.to_device_soa(a, width), self.empty((width, n))
+        if op == "neg":
+            self._call("sylow_hip_fext_neg_batch", da.ptr, do.ptr, degree, n)
+        else:
+            db = self.to_device_soa(_aos(b, 4 if op == "scale" else width), 4 if op == "scale" else width)
+            self._call("sylow_hip_fext_%s_batch" % op, da.ptr, db.ptr, do.ptr, degree, n)
+        return self.from_device_soa(do)
+
     def svdw_map(self, u):
         """SvdW map of field elements u [n, 4] -> (xy [n, 8], status [n])."""
         u = _aos(u, 4)

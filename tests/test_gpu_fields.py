@@ -159,3 +159,25 @@ def test_fp_pow_sqrt_is_square_vs_oracle(engine, coracle):
     assert np.array_equal(r, er) and np.array_equal(ok, eok) and np.array_equal(ok, sq)
     e = limbs([0, 1, 2, P - 1, P - 2, (1 << 256) - 1] + [rng.u256() for _ in range(58)])
     assert np.array_equal(engine.fp_pow(a[:64], e), coracle.fp_pow(a[:64], e))
+
+
+def test_field_extension_componentwise_operators(engine, coracle):
+    """FieldExtension Add / Sub / Neg / scale (extensions.rs:67-238) for Fp2, Fp6, Fp12 batches (scope row a8) against the oracle's
+    Fp arithmetic coefficient by coefficient and pyref's tower operators, odd batch size included."""
+    from helpers import rand_fp_array
+    rng = Xoshiro(SEED + 40)
+    for deg, n in ((2, 33), (6, 17), (12, 64)):
+        a, b = rand_fp_array(rng, n, deg), rand_fp_array(rng, n, deg)
+        k = rand_fp_array(rng, n, 1)
+        a[0] = 0; b[1] = 0
+        flat = lambda x: x.reshape(n * deg, 4)
+        assert np.array_equal(engine.fext_op("add", a, b), coracle.fp_op("add", flat(a), flat(b)).reshape(n, 4 * deg))
+        assert np.array_equal(engine.fext_op("sub", a, b), coracle.fp_op("sub", flat(a), flat(b)).reshape(n, 4 * deg))
+        assert np.array_equal(engine.fext_op("neg", a), coracle.fp_op("sub", np.zeros_like(flat(a)), flat(a)).reshape(n, 4 * deg))
+        assert np.array_equal(engine.fext_op("scale", a, k), coracle.fp_op("mul", flat(a), np.repeat(k, deg, 0)).reshape(n, 4 * deg))
+    from oracle import pyref as R
+    x, y = rand_fp_array(rng, 3, 2), rand_fp_array(rng, 3, 2)
+    got = ints(engine.fext_op("add", x, y))
+    xs, ys = ints(x), ints(y)
+    for i in range(3):
+        assert tuple(got[2 * i: 2 * i + 2]) == R.fp2_add((xs[2 * i], xs[2 * i + 1]), (ys[2 * i], ys[2 * i + 1]))
