@@ -256,10 +256,10 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 // values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KPROD pairs per lane pair (k_multi_pairing with
 // raw_miller = 1), the chunk values are multiplied together by a log-depth tree of Fp12 products, and one lane pair runs the
 // final exponentiation.
-__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs) {
+__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs, size_t chunk) {
   const size_t j = TID;
   if (j > n_jobs) return;
-  const size_t v = j * (size_t)KPROD;
+  const size_t v = j * chunk;
   off[j] = v < n_pairs ? v : n_pairs;
 }
 // out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out
@@ -435,14 +435,20 @@ int32_t sylow_hip_glued_miller_loop_precomputed_batch(const uint64_t* coeffs, si
 static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, size_t n_pairs,
                                    int32_t skip_infinity, host::Lease& ws, u64** result, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const size_t n_jobs = (n_pairs + plk::KPROD - 1) / plk::KPROD;
+  // pairs per lane pair: as few as keep the whole product inside ONE round of the GPU (2^16 lane pairs resident), at most KPROD --
+  // a small product is latency-bound (one pair per lane pair on the single-pair loop: one Miller loop deep), a large one
+  // throughput-bound (shared squarings)
+  size_t chunk = (n_pairs + 65535) / 65536;
+  if (chunk > (size_t)plk::KPROD) chunk = plk::KPROD;
+  const size_t n_jobs = (n_pairs + chunk - 1) / chunk;
   // workspace: chunk offsets + two ping-pong buffers of Fp12 values
   const size_t n_off = (n_jobs + 2) & ~(size_t)1, n_a = 48 * n_jobs, n_b = 48 * ((n_jobs + 1) / 2);
   int32_t rc = ws.acquire((n_off + n_a + n_b) * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
-  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs);
-  plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk);
+  if (chunk <= 2) plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  else plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   u64 *cur = bufa, *nxt = bufb;
   size_t m = n_jobs;
   while (m > 1) {
