@@ -130,6 +130,20 @@ def cpu_baseline(check=None, target_seconds=10.0):
     t0 = time.perf_counter()
     C.sign(sk, msgs)
     sign_single = ns / (time.perf_counter() - t0)
+    # verify shape (lib.rs:223-236: hash + two full pairings + compare) and BASELINE.json configs[0] as written, "single BLS
+    # sign+verify": keygen outside the clock (benches/sig.rs generates the key pair in its setup), n = 32, one thread
+    nv = 32
+    g2_proj = np.concatenate([limbs_row(G2), np.array([[1, 0, 0, 0, 0, 0, 0, 0]], dtype=np.uint64)], axis=1)
+    pk = C.g2_scalar_mul(np.repeat(g2_proj, nv, 0), sk[:nv])
+    sig = C.sign(sk[:nv], msgs[:nv])
+    C.verify(pk[:1], msgs[:1], sig[:1])
+    t0 = time.perf_counter()
+    ok = C.verify(pk, msgs[:nv], sig)
+    verify_single = nv / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for i in range(8):
+        C.verify(pk[i:i + 1], msgs[i:i + 1], C.sign(sk[i:i + 1], msgs[i:i + 1]))
+    sign_verify_ms = (time.perf_counter() - t0) / 8 * 1e3
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -156,6 +170,10 @@ def cpu_baseline(check=None, target_seconds=10.0):
                      f"C restatement of the reference's formulas and loop structure (oracle/sylow_oracle.c), not sylow itself",
            "single_thread_pairings_per_s": single, "single_thread_signs_per_s": sign_single,
            "sign_sample": f"{ns} x sign(sk, 20_i32.to_be_bytes()) (benches/sig.rs:10-21 shape), one thread",
+           "single_thread_verifies_per_s": verify_single, "verify_all_true": int(bool(np.all(ok))),
+           "verify_sample": f"{nv} x verify(pk, 20_i32.to_be_bytes(), sig) (lib.rs:223-236: hash + two pairings), one thread",
+           "C1_single_sign_plus_verify_ms": sign_verify_ms,
+           "C1_sample": "BASELINE.json configs[0]: 8 x (sign then verify) of the bench message, one element at a time, one thread (CPU plumbing only)",
            "reference_published": {"pairing_ms": 8.183, "sign_us": 954, "source": "sylow_devguide.pdf p.62, hardware unstated"},
            "rust_toolchain": cargo_probe()}
     if check is not None:

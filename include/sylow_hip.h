@@ -65,7 +65,8 @@ int32_t sylow_hip_init_devices(const int32_t* device_ids, int32_t n_dev);
  * does) call this before a batch of entry points; pointers passed to a call must belong to that device. */
 int32_t sylow_hip_set_device(int32_t device);
 /* Frees every scratch block, completion event and generator table on every device (after a device synchronise).  The library
- * stays usable: state is rebuilt on demand. */
+ * stays usable: state is rebuilt on demand.  EXCLUSIVE: while another host thread is inside an entry point that holds a scratch
+ * block the call frees nothing and returns SYLOW_HIP_E_ARG. */
 int32_t sylow_hip_shutdown(void);
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
@@ -130,6 +131,14 @@ int32_t sylow_hip_fp2_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void
 int32_t sylow_hip_fp2_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp6_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp6_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+/* The small tower items the pairing composes, as entry points of their own: Fp2::residue_mul (x (9 + u), fp2.rs:99-107),
+ * Fp2::frobenius(exponent) (fp2.rs:119-133: conjugation for odd exponents), Fp6::square (fp6.rs:213-236), Fp6::residue_mul
+ * (x v, fp6.rs:189-192), Fp6::frobenius(exponent) (fp6.rs:205-211: any exponent, tables indexed mod 6) */
+int32_t sylow_hip_fp2_residue_mul_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp2_frobenius_batch(const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp6_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp6_residue_mul_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
+int32_t sylow_hip_fp6_frobenius_batch(const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp12_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp12_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
@@ -169,6 +178,20 @@ int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const
 /* Add for &G2Projective, GroupProjective::double for G1 / G2 (group.rs:528-599, 339-386), affine in / out */
 int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
                                uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* Sub for &G1Projective / &G2Projective (group.rs:614-624: self + (-other)), affine in / out */
+int32_t sylow_hip_g1_sub_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
+                               uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t sylow_hip_g2_sub_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf,
+                               uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* G1Projective::new([x, y, z]) (g1.rs:383-402) and G2Projective::new([x, y, z]) (g2.rs:460-525) on projective SoA input
+ * ([12][n] / [24][n]): status OK / NOT_ON_CURVE / NOT_IN_SUBGROUP (G2 only); Z = 0 is accepted as the reference does.  Where the
+ * reference panics (an off-curve G2 input reaches endomorphism(), g2.rs:151) the status is NOT_ON_CURVE. */
+int32_t sylow_hip_g1_projective_new_batch(const uint64_t* p_xyz, uint8_t* status, size_t n, void* stream);
+int32_t sylow_hip_g2_projective_new_batch(const uint64_t* p_xyz, uint8_t* status, size_t n, void* stream);
+/* ConstantTimeEq / PartialEq for projective points (group.rs:426-447): eq[i] = 1 iff both are the identity, or neither is and
+ * the cross-multiplied coordinates agree.  a, b projective SoA [12][n] / [24][n]. */
+int32_t sylow_hip_g1_ct_eq_batch(const uint64_t* a_xyz, const uint64_t* b_xyz, uint8_t* eq, size_t n, void* stream);
+int32_t sylow_hip_g2_ct_eq_batch(const uint64_t* a_xyz, const uint64_t* b_xyz, uint8_t* eq, size_t n, void* stream);
 int32_t sylow_hip_g1_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 /* Weighted aggregation sum_i k_{j,i} * P_{j,i} (examples/threshold_signing.rs:124-143: partial signatures times
@@ -228,7 +251,8 @@ int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_i
 /* The same loops against line tables a host CACHED from sylow_hip_g2_precompute_batch (`G2PreComputed`, pairing.rs:556):
  * G2PreComputed::miller_loop(&G1Affine) (pairing.rs:590-619) and glued_miller_loop(&[G2PreComputed], &[G1Affine])
  * (pairing.rs:970-1022).  coeffs is the canonical SoA array [87*24][n_tables] exactly as g2_precompute_batch wrote it; pair i
- * uses table table_idx[i] (uint64 device array), or table i when table_idx is NULL (then n_tables must equal the number of
+ * uses table table_idx[i] (uint64 device array, every entry < n_tables -- NOT checked on the device: an out-of-range index
+ * reads outside coeffs), or table i when table_idx is NULL (then n_tables must equal the number of
  * pairs) -- so one cached key serves any number of G1 points.  Raw MillerLoopResult out, no identity handling (as the
  * reference).  The glued form takes the job layout of multi_pairing_batch; an empty job yields 1. */
 int32_t sylow_hip_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,

@@ -126,6 +126,7 @@ inline Gt glued_pairing(const std::vector<G1Affine>& g1s, const std::vector<G2Af
   std::vector<G1Affine> a(g1s.begin(), g1s.begin() + k);
   std::vector<G2Affine> b(g2s.begin(), g2s.begin() + k);
   std::vector<uint8_t> ai, bi;
+  if ((g1_inf && g1_inf->size() < k) || (g2_inf && g2_inf->size() < k)) throw Error("glued_pairing: identity flags shorter than the point list");
   if (g1_inf) ai.assign(g1_inf->begin(), g1_inf->begin() + k);
   if (g2_inf) bi.assign(g2_inf->begin(), g2_inf->begin() + k);
   auto dp = to_device_soa(a); auto dq = to_device_soa(b);

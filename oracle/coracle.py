@@ -217,6 +217,56 @@ def g2_projective_new(a):
     return st
 
 
+def g1_projective_new(a):
+    a = _u64(a, 12)
+    st = np.empty(a.shape[0], dtype=np.uint8)
+    lib().oracle_g1_projective_new(_p(a), _p(st), ctypes.c_size_t(a.shape[0]))
+    return st
+
+
+def _group_binop(name, width, a, b):
+    a, b = _u64(a, width), _u64(b, width)
+    out = np.empty_like(a)
+    getattr(lib(), name)(_p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def g1_sub(a, b): return _group_binop("oracle_g1_sub", 12, a, b)
+def g2_sub(a, b): return _group_binop("oracle_g2_sub", 24, a, b)
+
+
+def _group_eq(name, width, a, b):
+    a, b = _u64(a, width), _u64(b, width)
+    eq = np.empty(a.shape[0], dtype=np.uint8)
+    getattr(lib(), name)(_p(a), _p(b), _p(eq), ctypes.c_size_t(a.shape[0]))
+    return eq
+
+
+def g1_ct_eq(a, b): return _group_eq("oracle_g1_ct_eq", 12, a, b)
+def g2_ct_eq(a, b): return _group_eq("oracle_g2_ct_eq", 24, a, b)
+
+
+def fp2_frobenius(a, e):
+    a = _u64(a, 8)
+    out = np.empty_like(a)
+    lib().oracle_fp2_frobenius(ctypes.c_int(e), _p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fp6_frobenius(a, e):
+    a = _u64(a, 24)
+    out = np.empty_like(a)
+    lib().oracle_fp6_frobenius(ctypes.c_int(e), _p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fp6_residue_mul(a):
+    a = _u64(a, 24)
+    out = np.empty_like(a)
+    lib().oracle_fp6_residue_mul(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
 def g2_psi(xy):
     xy = _u64(xy, 16)
     out = np.empty_like(xy)

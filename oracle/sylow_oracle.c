@@ -872,6 +872,56 @@ API void oracle_g2_projective_new(const u64 *a, uint8_t *status, size_t n) {
   oracle_init();
   for (size_t i = 0; i < n; ++i) status[i] = (uint8_t)g2_projective_new(ldg2(a + 24 * i));
 }
+/* G1Projective::new (g1.rs:383-402): Y^2 Z == X^3 + 3 Z^3, or Z == 0.  0 ok, 1 NotOnCurve */
+API void oracle_g1_projective_new(const u64 *a, uint8_t *status, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g1p v = ldg1(a + 12 * i);
+    fp lhs = fp_mul(fp_sqr(v.y), v.z);
+    fp rhs = fp_add(fp_mul(fp_sqr(v.x), v.x), fp_mul(fp_mul(fp_sqr(v.z), v.z), THREE_C));
+    status[i] = (uint8_t)((fp_eq(lhs, rhs) || fp_is_zero(v.z)) ? 0 : 1);
+  }
+}
+/* Sub for projective points (group.rs:614-624): self + (-other) */
+API void oracle_g1_sub(const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg1(out + 12 * i, g1_add(ldg1(a + 12 * i), g1_neg(ldg1(b + 12 * i))));
+}
+API void oracle_g2_sub(const u64 *a, const u64 *b, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) stg2(out + 24 * i, g2_add(ldg2(a + 24 * i), g2_neg(ldg2(b + 24 * i))));
+}
+/* ConstantTimeEq for projective points (group.rs:426-447): cross-multiplied coordinates, both-identity, never identity vs finite */
+API void oracle_g1_ct_eq(const u64 *a, const u64 *b, uint8_t *eq, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g1p x = ldg1(a + 12 * i), y = ldg1(b + 12 * i);
+    int iz = fp_is_zero(x.z), yz = fp_is_zero(y.z);
+    eq[i] = (uint8_t)((iz && yz) || (!iz && !yz && fp_eq(fp_mul(x.x, y.z), fp_mul(y.x, x.z)) && fp_eq(fp_mul(x.y, y.z), fp_mul(y.y, x.z))));
+  }
+}
+API void oracle_g2_ct_eq(const u64 *a, const u64 *b, uint8_t *eq, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) {
+    g2p x = ldg2(a + 24 * i), y = ldg2(b + 24 * i);
+    int iz = fp2_is_zero(x.z), yz = fp2_is_zero(y.z);
+    eq[i] = (uint8_t)((iz && yz) || (!iz && !yz && fp2_eq(fp2_mul(x.x, y.z), fp2_mul(y.x, x.z)) && fp2_eq(fp2_mul(x.y, y.z), fp2_mul(y.y, x.z))));
+  }
+}
+/* Fp2::frobenius (fp2.rs:119-133), Fp2::residue_mul (fp2.rs:99-107: op 7 of oracle_fp2_op), Fp6::frobenius (fp6.rs:205-211: any
+ * exponent, tables indexed mod 6), Fp6::residue_mul (fp6.rs:189-192) */
+API void oracle_fp2_frobenius(int e, const u64 *a, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st2(out + 8 * i, fp2_frob(ld2(a + 8 * i), e));
+}
+API void oracle_fp6_frobenius(int e, const u64 *a, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st6(out + 24 * i, fp6_frob(ld6(a + 24 * i), e));
+}
+API void oracle_fp6_residue_mul(const u64 *a, u64 *out, size_t n) {
+  oracle_init();
+  for (size_t i = 0; i < n; ++i) st6(out + 24 * i, fp6_mul_v(ld6(a + 24 * i)));
+}
 API void oracle_g2_psi(const u64 *xy, u64 *out, size_t n) {
   oracle_init();
   for (size_t i = 0; i < n; ++i) { int ok = 1; g2a q = {ld2(xy + 16 * i), ld2(xy + 16 * i + 8), 0}; g2a r = g2_psi_affine(q, &ok); st2(out + 16 * i, r.x); st2(out + 16 * i + 8, r.y); }

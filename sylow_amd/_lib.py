@@ -50,6 +50,11 @@ SIGNATURES = {
     "sylow_hip_fp12_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_inv_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_frobenius_batch": [c_u64p, c_i32, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp2_residue_mul_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp2_frobenius_batch": [c_u64p, ctypes.c_uint64, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp6_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp6_residue_mul_batch": [c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_fp6_frobenius_batch": [c_u64p, ctypes.c_uint64, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_sparse_mul_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_g1_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_scalar_mul_batch": [c_u64p, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp],
@@ -104,6 +109,12 @@ SIGNATURES = {
     "sylow_hip_g2_psi_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_gt_pow_batch": [c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_g2_add_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_sub_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_sub_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_projective_new_batch": [c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_projective_new_batch": [c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g1_ct_eq_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
+    "sylow_hip_g2_ct_eq_batch": [c_u64p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g1_double_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_double_batch": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_vp],
     "sylow_hip_flags_all": [c_u8p, c_sz, c_vp, c_vp],

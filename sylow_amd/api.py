@@ -95,6 +95,15 @@ class _Points:
         return self.infinity.astype(bool)
 
 
+
+def _random_scalars(n, seed):
+    """n scalars in [0, r) as [n, 4] limbs.  seed None: the operating system's generator (what the reference's `rand(&mut OsRng)` call
+    sites use); an int: the reproducible xoshiro test stream -- NOT for secrets or nonces."""
+    if seed is None:
+        import secrets
+        return fp([secrets.randbelow(R_ORDER) for _ in range(n)])
+    return engine().fr_add(engine().xoshiro_fp_soa(seed, n).T.copy(), np.zeros((n, 4), dtype=np.uint64))
+
 class G1Affine(_Points):
     """Batch of G1 points in affine form (g1.rs:30); identity = (0, 1, infinity)."""
     WIDTH = 8
@@ -129,8 +138,8 @@ class G1Affine(_Points):
         return G1Affine(xy, inf)
 
     @classmethod
-    def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g1.rs:293-305): generator * random scalar (seeded, reproducible)
-        xy, inf = engine().g1_generator_mul(engine().xoshiro_fp_soa(seed, n).T.copy())
+    def rand(cls, n=1, seed=None):                 # GroupTrait::rand (g1.rs:293-305): generator * random scalar; an int seed is test-only
+        xy, inf = engine().g1_generator_mul(_random_scalars(n, seed))
         return cls(xy, inf)
 
     def to_be_bytes(self):                         # g1.rs:151-180
@@ -199,8 +208,8 @@ class G2Affine(_Points):
         return G2Affine(xy, inf)._checked(self.in_subgroup)
 
     @classmethod
-    def rand(cls, n=1, seed=0):                    # GroupTrait::rand (g2.rs:204-240): a random r-torsion point (generator * random scalar)
-        xy, inf = engine().g2_generator_mul(engine().xoshiro_fp_soa(seed, n).T.copy())
+    def rand(cls, n=1, seed=None):                 # GroupTrait::rand (g2.rs:204-240): a random r-torsion point; an int seed is test-only
+        xy, inf = engine().g2_generator_mul(_random_scalars(n, seed))
         return cls(xy, inf)._checked()
 
     def to_be_bytes(self):                         # g2.rs:319-359
@@ -291,8 +300,8 @@ class Fr:
         return engine().fr_to_be_bytes(self.v)
 
     @classmethod
-    def rand(cls, n=1, seed=0):                    # FieldExtensionTrait::rand, seeded: a uniform Fp draw reduced mod r
-        return cls(engine().fr_add(engine().xoshiro_fp_soa(seed, n).T.copy(), np.zeros((n, 4), dtype=np.uint64)))
+    def rand(cls, n=1, seed=None):                 # FieldExtensionTrait::rand; seed None = OS generator, an int = reproducible test stream
+        return cls(_random_scalars(n, seed))
 
 
 def aggregate(points: "G1Affine", weights: "Fr", n_jobs: int, n_terms: int) -> "G1Affine":
@@ -312,6 +321,8 @@ class G2PreComputed:
     def miller_loop(self, g1: G1Affine, table_idx=None) -> MillerLoopResult:     # pairing.rs:590-619
         """Consumes the cached tables (no G2 arithmetic): element i pairs g1[i] with table table_idx[i] (default: table i), so
         ONE precomputed key serves any number of G1 points."""
+        if table_idx is None and len(g1) != len(self.q):
+            raise ValueError(f"{len(g1)} G1 points against {len(self.q)} precomputed tables: pass table_idx (one table index per point)")
         return MillerLoopResult(engine().miller_loop_precomputed(self.coeffs, g1.xy, table_idx))
 
 
@@ -378,11 +389,7 @@ class KeyPair:
     @classmethod
     def generate(cls, n=1, seed=None):
         """`seed` None: the operating system's generator like the reference's OsRng; an int: reproducible (tests)."""
-        if seed is None:
-            import secrets
-            sk = fp([secrets.randbelow(R_ORDER) for _ in range(n)])
-        else:
-            sk = Fr.rand(n, seed).v
+        sk = _random_scalars(n, seed)
         xy, inf = engine().g2_generator_mul(sk)          # fixed-base table of the generator
         return cls(sk, G2Affine(xy, inf)._checked())
 

@@ -26,6 +26,37 @@ __global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t*
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
   oinf[i] = rinf ? 1 : 0;
 }
+// Sub for projective points (group.rs:614-624): self + (-other), affine SoA in / out like k_g1_add
+__global__ void __launch_bounds__(BLOCK) k_g1_sub(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P b{load_fp(bxy, n, i, 0), fp_neg(load_fp(bxy, n, i, 4)), (binf && binf[i]) ? fp_zero() : fp_one()};
+  G1P r = g1_add(a, b);
+  Fp x, y; bool rinf;
+  g1_to_affine(x, y, rinf, r);
+  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+  oinf[i] = rinf ? 1 : 0;
+}
+// G1Projective::new([x, y, z]) (g1.rs:383-402): Y^2 Z == X^3 + 3 Z^3, or Z == 0
+__global__ void __launch_bounds__(BLOCK) k_g1_projective_new(const u64* pxyz, uint8_t* status, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const Fp x = load_fp(pxyz, n, i, 0), y = load_fp(pxyz, n, i, 4), z = load_fp(pxyz, n, i, 8);
+  const Fp lhs = fp_mul(fp_sqr(y), z);
+  const Fp rhs = fp_add(fp_mul(fp_sqr(x), x), fp_mul(fp_mul(fp_sqr(z), z), fp_small(3)));
+  status[i] = (fp_eq(lhs, rhs) || fp_is_zero(z)) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
+// ConstantTimeEq for projective points (group.rs:426-447)
+__global__ void __launch_bounds__(BLOCK) k_g1_ct_eq(const u64* a, const u64* b, uint8_t* eq, size_t n) {
+  size_t i = TID;
+  if (i >= n) return;
+  const Fp ax = load_fp(a, n, i, 0), ay = load_fp(a, n, i, 4), az = load_fp(a, n, i, 8);
+  const Fp bx = load_fp(b, n, i, 0), by = load_fp(b, n, i, 4), bz = load_fp(b, n, i, 8);
+  const bool iz = fp_is_zero(az), yz = fp_is_zero(bz);
+  const bool same = fp_eq(fp_mul(ax, bz), fp_mul(bx, az)) && fp_eq(fp_mul(ay, bz), fp_mul(by, az));
+  eq[i] = ((iz && yz) || (!iz && !yz && same)) ? 1 : 0;
+}
 // out_j = sum_i k_{j,i} * P_{j,i}: the aggregation loop of examples/threshold_signing.rs:124-143 (Lagrange-weighted partial
 // signatures), one job per lane, terms walked in order with the reference's own scalar multiplication and complete addition.
 // Term-major layout: element (job j, term i) lives at index i * n_jobs + j, so a wave reads consecutive addresses.
@@ -354,6 +385,16 @@ int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   k_g1_add<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_sub_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  k_g1_sub<<<GRID(n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_projective_new_batch(const uint64_t* p_xyz, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(p_xyz && status); if (!n) return SYLOW_HIP_OK; k_g1_projective_new<<<GRID(n)>>>(p_xyz, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g1_ct_eq_batch(const uint64_t* a_xyz, const uint64_t* b_xyz, uint8_t* eq, size_t n, void* stream) {
+  ARGCHK(a_xyz && b_xyz && eq); if (!n) return SYLOW_HIP_OK; k_g1_ct_eq<<<GRID(n)>>>(a_xyz, b_xyz, eq, n); LAUNCHED();
 }
 int32_t sylow_hip_g1_lincomb_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n_jobs, size_t n_terms, void* stream) {
   ARGCHK(out_xy && out_inf && (n_terms == 0 || (p_xy && k))); if (!n_jobs) return SYLOW_HIP_OK;

@@ -110,8 +110,7 @@ BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-29
   return s2_eq(s2_sub(s2_sqr(y), s2_mul(s2_sqr(x), x)), s2_const(C_TWIST_B));
 }
 // g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
-BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
-  const G2Q q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()};
+BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q) {
   const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
   G2Q a;
   g2q_scalar_mul(a, q, bx, 17);                   // x < 2^63: 16 digits + the recoding carry
@@ -134,6 +133,7 @@ BN_NOINLINE bool g2q_in_subgroup(const S2& x, const S2& y) {
   g2q_add(r, r, nl);
   return OpsW2::is_zero(r.z);
 }
+BN_DEV bool g2q_in_subgroup(const S2& x, const S2& y) { return g2q_in_subgroup_proj(G2Q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()}); }
 BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
   return G2Q{w2_from_s2(load_s2(xy, n, i, 0, odd)), w2_from_s2(load_s2(xy, n, i, 8, odd)), (inf && inf[i]) ? OpsW2::zero() : OpsW2::one()};
 }
@@ -228,6 +228,44 @@ __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const
   G2Q r;
   g2q_add(r, load_g2q(axy, ainf, n, i, odd), load_g2q(bxy, binf, n, i, odd));
   store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+// Sub for projective points (group.rs:614-624): self + (-other)
+__global__ void HEAVY_BOUNDS k_g2_sub(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  G2Q r;
+  g2q_add(r, load_g2q(axy, ainf, n, i, odd), proj_neg<OpsW2>(load_g2q(bxy, binf, n, i, odd)));
+  store_g2q_affine(oxy, oinf, n, i, odd, r);
+}
+BN_DEV G2Q load_g2q_proj(const u64* pxyz, size_t n, size_t i, int odd) {
+  return G2Q{w2_from_s2(load_s2(pxyz, n, i, 0, odd)), w2_from_s2(load_s2(pxyz, n, i, 8, odd)), w2_from_s2(load_s2(pxyz, n, i, 16, odd))};
+}
+// G2Projective::new([x, y, z]) (g2.rs:460-525): Y^2 Z == X^3 + b' Z^3 or Z == 0, then the subgroup relation on the projective
+// point itself.  Off the curve the reference's endomorphism() panics inside the subgroup test (g2.rs:151): NOT_ON_CURVE here.
+__global__ void HEAVY_BOUNDS k_g2_projective_new(const u64* pxyz, uint8_t* status, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const S2 x = load_s2(pxyz, n, i, 0, odd), y = load_s2(pxyz, n, i, 8, odd), z = load_s2(pxyz, n, i, 16, odd);
+  const S2 lhs = s2_mul(s2_sqr(y), z);
+  const S2 rhs = s2_add(s2_mul(s2_sqr(x), x), s2_mul(s2_mul(s2_sqr(z), z), s2_const(C_TWIST_B)));
+  const bool zz = s2_is_zero(z);
+  uint8_t st = SYLOW_HIP_ST_OK;
+  if (!(s2_eq(lhs, rhs) || zz)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
+  else if (!zz && !g2q_in_subgroup_proj(load_g2q_proj(pxyz, n, i, odd))) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;   // Z == 0 passes both tests
+  if (!odd) status[i] = st;
+}
+// ConstantTimeEq for projective points (group.rs:426-447)
+__global__ void HEAVY_BOUNDS k_g2_ct_eq(const u64* a, const u64* b, uint8_t* eq, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const S2 ax = load_s2(a, n, i, 0, odd), ay = load_s2(a, n, i, 8, odd), az = load_s2(a, n, i, 16, odd);
+  const S2 bx = load_s2(b, n, i, 0, odd), by = load_s2(b, n, i, 8, odd), bz = load_s2(b, n, i, 16, odd);
+  const bool iz = s2_is_zero(az), yz = s2_is_zero(bz);
+  const bool same = s2_eq(s2_mul(ax, bz), s2_mul(bx, az)) && s2_eq(s2_mul(ay, bz), s2_mul(by, az));
+  if (!odd) eq[i] = ((iz && yz) || (!iz && !yz && same)) ? 1 : 0;
 }
 __global__ void HEAVY_BOUNDS k_g2_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
   const size_t t = TID, i = t >> 1;
@@ -520,6 +558,16 @@ int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::g2_add(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n, stream);
   plk::k_g2_add<<<GRID(2 * n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_sub_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  plk::k_g2_sub<<<GRID(2 * n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_projective_new_batch(const uint64_t* p_xyz, uint8_t* status, size_t n, void* stream) {
+  ARGCHK(p_xyz && status); if (!n) return SYLOW_HIP_OK; plk::k_g2_projective_new<<<GRID(2 * n)>>>(p_xyz, status, n); LAUNCHED();
+}
+int32_t sylow_hip_g2_ct_eq_batch(const uint64_t* a_xyz, const uint64_t* b_xyz, uint8_t* eq, size_t n, void* stream) {
+  ARGCHK(a_xyz && b_xyz && eq); if (!n) return SYLOW_HIP_OK; plk::k_g2_ct_eq<<<GRID(2 * n)>>>(a_xyz, b_xyz, eq, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;

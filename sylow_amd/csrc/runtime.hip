@@ -270,6 +270,7 @@ int32_t Lease::release() {
     return SYLOW_HIP_OK;
   }
   std::lock_guard<std::mutex> lock(g_mu);
+  if ((size_t)slot >= g_dev[dev].blocks.size()) { slot = -1; return SYLOW_HIP_OK; }    // defensive: shutdown refuses while a block is leased
   Block& b = g_dev[dev].blocks[slot];
   slot = -1;
   b.leased = false;
@@ -399,6 +400,11 @@ int32_t sylow_hip_set_device(int32_t device) {
 }
 int32_t sylow_hip_shutdown(void) {
   std::lock_guard<std::mutex> lock(host::g_mu);
+  // another host thread inside an entry point holds a Lease: freeing its block under it would leave its queued kernels on freed
+  // memory -- shutdown is refused (nothing is freed) until every entry point has returned
+  for (int d = 0; d < host::MAX_DEV; ++d)
+    for (const host::Block& b : host::g_dev[d].blocks)
+      if (b.leased) { snprintf(sylow_g_err, sizeof(sylow_g_err), "shutdown while an entry point is still running on device %d", d); return SYLOW_HIP_E_ARG; }
   int prev = 0;
   const bool have_prev = hipGetDevice(&prev) == hipSuccess;
   int32_t rc = SYLOW_HIP_OK;

@@ -3,12 +3,16 @@
 #include "host.hpp"
 
 // ------------------------------------------------------------------ tower test hooks ----------
+enum { OPX_RESIDUE_MUL = 16, OPX_FROB_ODD = 17, OPX_COPY = 18, OPX_FROB6 = 32 };
 __global__ void __launch_bounds__(BLOCK) k_fp2_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
   size_t i = TID;
   if (i >= n) return;
   Fp2 x = load_fp2(a, n, i, 0), r;
   if (op == OP_MUL) r = fp2_mul(x, load_fp2(b, n, i, 0));
   else if (op == OP_SQR) r = fp2_sqr(x);
+  else if (op == OPX_RESIDUE_MUL) r = fp2_mul_xi(x);                 // Fp2::residue_mul (fp2.rs:99-107)
+  else if (op == OPX_FROB_ODD) r = fp2_conj(x);                      // Fp2::frobenius(odd) (fp2.rs:119-133); even exponents are the identity
+  else if (op == OPX_COPY) r = x;
   else r = fp2_inv(x);
   store_fp2(out, n, i, 0, r);
 }
@@ -18,6 +22,16 @@ __global__ void HEAVY_BOUNDS k_fp6_op(int op, const u64* a, const u64* b, u64* o
   Fp6 x, y, r;
   load_fp6(x, a, n, i, 0);
   if (op == OP_MUL) { load_fp6(y, b, n, i, 0); fp6_mul(r, x, y); }
+  else if (op == OP_SQR) fp6_sqr(r, x);                              // Fp6::square (fp6.rs:213-236)
+  else if (op == OPX_RESIDUE_MUL) r = fp6_mul_v(x);                  // Fp6::residue_mul (fp6.rs:189-192)
+  else if (op == OPX_COPY) r = x;
+  else if (op >= OPX_FROB6 && op <= OPX_FROB6 + 5) {                 // Fp6::frobenius(e), e mod 6 (fp6.rs:205-211): the tables of
+    const int e = op - OPX_FROB6;                                    // exponents 4 and 5 are those of 1 and 2 composed with 3
+    r = x;
+    if (e >= 3) { fp6_frobenius<3>(y, r); r = y; }
+    if (e % 3 == 1) { fp6_frobenius<1>(y, r); r = y; }
+    if (e % 3 == 2) { fp6_frobenius<2>(y, r); r = y; }
+  }
   else fp6_inv(r, x);
   store_fp6(out, n, i, 0, r);
 }
@@ -570,6 +584,21 @@ int32_t sylow_hip_fp6_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* 
 }
 int32_t sylow_hip_fp6_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OP_INV, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp2_residue_mul_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>(OPX_RESIDUE_MUL, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp2_frobenius_batch(const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp2_op<<<GRID(n)>>>((exponent & 1) ? OPX_FROB_ODD : OPX_COPY, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp6_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OP_SQR, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp6_residue_mul_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OPX_RESIDUE_MUL, a, nullptr, out, n); LAUNCHED();
+}
+int32_t sylow_hip_fp6_frobenius_batch(const uint64_t* a, uint64_t exponent, uint64_t* out, size_t n, void* stream) {
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OPX_FROB6 + (int)(exponent % 6), a, nullptr, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_MUL, a, b, out, n); LAUNCHED();

@@ -160,6 +160,19 @@ class Engine:
     def fp2_inv(self, a): return self._unop("sylow_hip_fp2_inv_batch", 8, a)
     def fp6_mul(self, a, b): return self._binop("sylow_hip_fp6_mul_batch", 24, a, b)
     def fp6_inv(self, a): return self._unop("sylow_hip_fp6_inv_batch", 24, a)
+    def fp2_residue_mul(self, a): return self._unop("sylow_hip_fp2_residue_mul_batch", 8, a)
+    def fp6_sqr(self, a): return self._unop("sylow_hip_fp6_sqr_batch", 24, a)
+    def fp6_residue_mul(self, a): return self._unop("sylow_hip_fp6_residue_mul_batch", 24, a)
+
+    def _frobenius(self, name, width, a, e):
+        a = _aos(a, width)
+        n = a.shape[0]
+        da, do = self.to_device_soa(a, width), self.empty((width, n))
+        self._call(name, da.ptr, int(e), do.ptr, n)
+        return self.from_device_soa(do)
+
+    def fp2_frobenius(self, a, e): return self._frobenius("sylow_hip_fp2_frobenius_batch", 8, a, e)
+    def fp6_frobenius(self, a, e): return self._frobenius("sylow_hip_fp6_frobenius_batch", 24, a, e)
     def fp12_mul(self, a, b): return self._binop("sylow_hip_fp12_mul_batch", 48, a, b)
     def fp12_sqr(self, a): return self._unop("sylow_hip_fp12_sqr_batch", 48, a)
     def fp12_inv(self, a): return self._unop("sylow_hip_fp12_inv_batch", 48, a)
@@ -274,6 +287,38 @@ class Engine:
         do, doi = self.empty((16, n)), self.empty((n,), np.uint8)
         self._call("sylow_hip_g2_add_batch", da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
         return self.from_device_soa(do), doi.download()
+
+    def _group_binop(self, name, width, a_xy, b_xy, a_inf, b_inf):
+        a_xy, b_xy = _aos(a_xy, width), _aos(b_xy, width)
+        n = a_xy.shape[0]
+        da, db = self.to_device_soa(a_xy, width), self.to_device_soa(b_xy, width)
+        dai, dbi = self._flags(a_inf, n), self._flags(b_inf, n)
+        do, doi = self.empty((width, n)), self.empty((n,), np.uint8)
+        self._call(name, da.ptr, self._ptr(dai), db.ptr, self._ptr(dbi), do.ptr, doi.ptr, n)
+        return self.from_device_soa(do), doi.download()
+
+    def g1_sub(self, a_xy, b_xy, a_inf=None, b_inf=None): return self._group_binop("sylow_hip_g1_sub_batch", 8, a_xy, b_xy, a_inf, b_inf)
+    def g2_sub(self, a_xy, b_xy, a_inf=None, b_inf=None): return self._group_binop("sylow_hip_g2_sub_batch", 16, a_xy, b_xy, a_inf, b_inf)
+
+    def _projective_new(self, name, width, p_xyz):
+        p_xyz = _aos(p_xyz, width)
+        n = p_xyz.shape[0]
+        dp, dst = self.to_device_soa(p_xyz, width), self.empty((n,), np.uint8)
+        self._call(name, dp.ptr, dst.ptr, n)
+        return dst.download()
+
+    def g1_projective_new(self, p_xyz): return self._projective_new("sylow_hip_g1_projective_new_batch", 12, p_xyz)
+    def g2_projective_new(self, p_xyz): return self._projective_new("sylow_hip_g2_projective_new_batch", 24, p_xyz)
+
+    def _ct_eq(self, name, width, a_xyz, b_xyz):
+        a_xyz, b_xyz = _aos(a_xyz, width), _aos(b_xyz, width)
+        n = a_xyz.shape[0]
+        da, db, deq = self.to_device_soa(a_xyz, width), self.to_device_soa(b_xyz, width), self.empty((n,), np.uint8)
+        self._call(name, da.ptr, db.ptr, deq.ptr, n)
+        return deq.download()
+
+    def g1_ct_eq(self, a_xyz, b_xyz): return self._ct_eq("sylow_hip_g1_ct_eq_batch", 12, a_xyz, b_xyz)
+    def g2_ct_eq(self, a_xyz, b_xyz): return self._ct_eq("sylow_hip_g2_ct_eq_batch", 24, a_xyz, b_xyz)
 
     def _double(self, name, width, a_xy, a_inf):
         a_xy = _aos(a_xy, width)
@@ -431,9 +476,24 @@ class Engine:
         return int(out.download()[0])
 
     # G2PreComputed consumers (pairing.rs:590-619, 970-1022): coeffs [m, 87*24] as g2_precompute returns them
+    @staticmethod
+    def _check_table_idx(table_idx, n, m):
+        """table_idx is consumed unchecked on the device (coeffs[table_idx[i]]): validate it while it is still a host array."""
+        if table_idx is None:
+            if n != m:
+                raise ValueError(f"without table_idx, pair i reads table i: {n} G1 points need {n} tables, got {m}")
+            return None
+        ti = np.ascontiguousarray(table_idx, dtype=np.uint64).reshape(-1)
+        if ti.shape[0] != n:
+            raise ValueError(f"table_idx has {ti.shape[0]} entries for {n} G1 points")
+        if n and (m == 0 or int(ti.max()) >= m):
+            raise ValueError(f"table_idx refers to table {int(ti.max()) if n else 0}, only {m} tables were given")
+        return ti
+
     def miller_loop_precomputed(self, coeffs, p_xy, table_idx=None):
         coeffs, p_xy = _aos(coeffs, 87 * 24), _aos(p_xy, 8)
         n, m = p_xy.shape[0], coeffs.shape[0]
+        table_idx = self._check_table_idx(table_idx, n, m)
         dc, dp = self.to_device_soa(coeffs, 87 * 24), self.to_device_soa(p_xy, 8)
         dti = self.to_device(np.ascontiguousarray(table_idx, dtype=np.uint64)) if table_idx is not None else None
         do = self.empty((48, n))
@@ -443,8 +503,11 @@ class Engine:
     def glued_miller_loop_precomputed(self, coeffs, p_xy, offsets, table_idx=None):
         coeffs, p_xy = _aos(coeffs, 87 * 24), _aos(p_xy, 8)
         n, m = p_xy.shape[0], coeffs.shape[0]
+        table_idx = self._check_table_idx(table_idx, n, m)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         nj = off.shape[0] - 1
+        if nj < 0 or (nj >= 0 and (np.any(off[1:] < off[:-1]) or int(off[-1]) > n)):
+            raise ValueError("offsets must be non-decreasing and end at most at the number of pairs")
         dc = self.to_device_soa(coeffs, 87 * 24) if m else None
         dp = self.to_device_soa(p_xy, 8) if n else None
         dti = self.to_device(np.ascontiguousarray(table_idx, dtype=np.uint64)) if table_idx is not None else None

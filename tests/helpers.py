@@ -68,3 +68,30 @@ def fast_rand_fp_array(seed, n, width_fp):
     a = g.integers(0, 1 << 63, size=(n, width_fp, 4), dtype=np.uint64) * np.uint64(2) + g.integers(0, 2, size=(n, width_fp, 4), dtype=np.uint64)
     a[:, :, 3] &= np.uint64((1 << 61) - 1)
     return a.reshape(n, 4 * width_fp)
+
+
+def _R():
+    from oracle import pyref
+    return pyref
+
+
+def fp2_sqrt(a):
+    """sqrt in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4 (complex method); None if a is not a square"""
+    a0, a1 = a
+    if a1 == 0:
+        s = _R().fp_sqrt(a0)
+        if s is not None:
+            return (s, 0)
+        s = _R().fp_sqrt((-a0) % P)
+        return (0, s)
+    n = _R().fp_sqrt((a0 * a0 + a1 * a1) % P)
+    if n is None:
+        return None
+    for nn in (n, (-n) % P):
+        h = (a0 + nn) * _R().fp_inv(2) % P
+        x0 = _R().fp_sqrt(h)
+        if x0 is not None and x0 != 0:
+            x1 = a1 * _R().fp_inv(2 * x0 % P) % P
+            if _R().fp2_square((x0, x1)) == (a0 % P, a1 % P):
+                return (x0, x1)
+    return None

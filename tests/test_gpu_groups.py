@@ -3,7 +3,7 @@ Points are compared after affine normalisation, as the reference'
 import numpy as np
 import pytest
 
-from helpers import P, SEED, Xoshiro, fast_rand_fp_array, ints, limbs, pack
+from helpers import P, SEED, Xoshiro, fast_rand_fp_array, fp2_sqrt, ints, limbs, pack
 from oracle import pyref as R
 
 pytestmark = pytest.mark.gpu
@@ -116,28 +116,6 @@ def test_g1_add_and_normalize(engine, coracle):
     assert np.array_equal(nq, q) and not nqinf.any()
     eq, einf = coracle.g2_to_affine(projq)
     assert np.array_equal(nq, eq)
-
-
-def fp2_sqrt(a):
-    """sqrt in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4 (complex method); None if a is not a square"""
-    a0, a1 = a
-    if a1 == 0:
-        s = R.fp_sqrt(a0)
-        if s is not None:
-            return (s, 0)
-        s = R.fp_sqrt((-a0) % P)
-        return (0, s)
-    n = R.fp_sqrt((a0 * a0 + a1 * a1) % P)
-    if n is None:
-        return None
-    for nn in (n, (-n) % P):
-        h = (a0 + nn) * R.fp_inv(2) % P
-        x0 = R.fp_sqrt(h)
-        if x0 is not None and x0 != 0:
-            x1 = a1 * R.fp_inv(2 * x0 % P) % P
-            if R.fp2_square((x0, x1)) == (a0 % P, a1 % P):
-                return (x0, x1)
-    return None
 
 
 def test_g2_subgroup_check(engine, coracle):
