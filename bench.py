@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--no-aux", action="store_true", help="skip the untimed BLS-verify / other-config aux leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and the oracle spot check)")
     ap.add_argument("--plant-bad", type=int, default=-1, metavar="RANK", help="corrupt one signature on that rank (aux leg): the global AND must read 0")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and the native ncclComm_t) even for one rank")
     args = ap.parse_args()
 
     import torch
@@ -303,9 +304,11 @@ def main():
     if os.environ.get("SYLOW_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -348,6 +351,28 @@ def main():
         idx = np.sort(np.random.default_rng(SEED).choice(n, size=min(16, n), replace=False))
         check = tuple(np.ascontiguousarray(d.download()[:, idx].T) for d in (p, q, gt))
 
+    # ---- native RCCL communicator for the C ABI's aggregate entry points (one per rank; backend nccl only) -------------
+    comm, comm_err = None, None
+    if dist is not None and backend == "nccl":
+        from sylow_amd.rccl import NativeComm
+        comm, comm_err = NativeComm.from_process_group(dist)
+    rccl_ranks = comm.ranks if comm is not None else None
+    comm_ptr = comm.value if comm is not None else None
+
+    def timed_ranks(fn, reps=3):
+        """(seconds per call with the slowest rank's clock -- barrier + synchronize on both sides --, this rank's HIP-event ms per call)"""
+        fn()
+        fence()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record(stream)
+        for _ in range(reps):
+            fn()
+        b.record(stream)
+        fence()
+        dt = (time.perf_counter() - t0) / reps
+        return sharding.max_over_ranks(dt, dist), a.elapsed_time(b) / reps
+
     # ---- untimed aux leg: batched BLS verify + aggregate AND over ranks (RCCL MIN) ----------------
     aux = {}
     if not args.no_aux:
@@ -362,57 +387,80 @@ def main():
         sig, sigi = eng.empty((8, nv)), eng.empty((nv,), np.uint8)
         ok = eng.empty((nv,), np.uint8)
         eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr, nv)
-        eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv)
-        fence()
-        tsg = time.perf_counter()
-        eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv)
-        fence()
-        dtsg = time.perf_counter() - tsg
+        dtsg, sign_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv))
         if args.plant_bad == rank:                # sig_j <- sig_{j+1}: a valid point, the wrong signature
             s_h = sig.download()
             j = nv // 3
             s_h[:, j] = s_h[:, (j + 1) % nv]
             sig.upload(s_h)
-        eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)  # warm
         # torch's first device allocation initialises its allocator (seconds on a cold box): keep it outside the clocks
         flag = torch.ones(1, dtype=torch.int32, device="cuda")
         flag2 = torch.ones(1, dtype=torch.int32, device="cuda")
-        fence()
-        tv = time.perf_counter()
-        eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-        eng._call("sylow_hip_flags_all", ok.ptr, nv, flag.data_ptr())
-        flag = sharding.and_reduce_(flag, dist)          # AND over ranks: 4 bytes over xGMI (RCCL MIN)
-        fence()
-        dtv = time.perf_counter() - tv
-        eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)  # warm
-        fence()
-        tf = time.perf_counter()
-        eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-        eng._call("sylow_hip_flags_all", ok.ptr, nv, flag2.data_ptr())
-        flag2 = sharding.and_reduce_(flag2, dist)
-        fence()
-        dtf = time.perf_counter() - tf
+
+        def and_over_ranks(okbuf, m, out):
+            """AND of this rank's flags AND-ed over all ranks: the native entry point (device-side AND + 4-byte ncclAllReduce(min) on the
+            rank's own ncclComm_t) when a communicator exists, else the device-side AND + the process group's MIN."""
+            if comm is not None:
+                eng._call("sylow_hip_all_valid", okbuf.ptr, m, comm_ptr, out.data_ptr())
+                return out
+            eng._call("sylow_hip_flags_all", okbuf.ptr, m, out.data_ptr())
+            return sharding.and_reduce_(out, dist)
+
+        def verify_weak():
+            nonlocal flag
+            eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
+            flag = and_over_ranks(ok, nv, flag)          # AND over ranks: 4 bytes over xGMI (RCCL MIN)
+
+        dtv, verify_ms = timed_ranks(verify_weak)
+
+        def verify_two():
+            nonlocal flag2
+            eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
+            flag2 = and_over_ranks(ok, nv, flag2)
+
+        dtf, verify2_ms = timed_ranks(verify_two, 1)
         n_bad = int(nv - int(ok.download().sum()))
-        eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)   # warm
-        fence()
-        ts = time.perf_counter()
-        eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-        fence()
-        dts = time.perf_counter() - ts
+        dts, same_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), 2)
+
+        # ---- STRONG scaling, BASELINE.json configs[3] as written: ONE batch of 2^20 verifies (and of 2^20 pairings) sharded over the
+        # ranks as contiguous blocks (sharding.shard_bounds); every element is independent and synthetic, so rank r's block is the first
+        # hi - lo elements of its own arrays, re-packed to the block's SoA stride outside the clock
+        n_total = nv
+        lo, hi = sharding.shard_bounds(n_total, rank, world)
+        ms = hi - lo
+
+        def block(d, rows, dtype=np.uint64):
+            return d if ms == nv else eng.empty((rows, ms) if rows else (ms,), dtype).upload(np.ascontiguousarray(d.download()[..., :ms]))
+
+        pk_s, sig_s, p_s, q_s = block(pk, 16), block(sig, 8), block(p, 8), block(q, 16)
+        dm_s = dm if ms == nv else eng.to_device(msgs_np[:ms].reshape(-1))
+        doff_s = doff if ms == nv else eng.to_device(off[:ms + 1])
+        ok_s, gt_s = eng.empty((max(ms, 1),), np.uint8), eng.empty((48, max(ms, 1)))
+        flag3 = torch.ones(1, dtype=torch.int32, device="cuda")
+
+        def verify_strong():
+            nonlocal flag3
+            if ms:
+                eng._call("sylow_hip_bls_verify_batch", pk_s.ptr, None, dm_s.ptr, doff_s.ptr, sig_s.ptr, None, ok_s.ptr, ms)
+            flag3 = and_over_ranks(ok_s, ms, flag3)
+
+        dtvs, _ = timed_ranks(verify_strong)
+        dtps, _ = timed_ranks(lambda: ms and eng._call("sylow_hip_pairing_batch", p_s.ptr, None, q_s.ptr, None, gt_s.ptr, ms))
+        strong = {"scaling": "strong", "batch_total": n_total, "shard_this_rank": ms, "bls_verifies_per_s": n_total / dtvs, "pairings_per_s": n_total / dtps,
+                  "bls_all_valid": int(flag3.item()),
+                  "note": "ONE batch of %d sharded over %d rank(s) as contiguous blocks; time = slowest rank between barriers; verify includes the AND over ranks" % (n_total, world)}
+        del pk_s, sig_s, p_s, q_s, ok_s, gt_s
+
         # aggregate verification (examples/verify_multiple_messages_same_signer.rs:41-60 / threshold_signing.rs:92-121 shape): the product
-        # of the 2 nv pairs (sig_i, G2gen), (-H(m_i), pk_i) == identity as ONE boolean per rank, signatures summed in G1 first
-        # (sylow_hip_bls_aggregate_verify_batch); hashing is inside the clock.  The planted bad signature (--plant-bad) must flip it.
+        # of the 2 nv pairs (sig_i, G2gen), (-H(m_i), pk_i) of EVERY rank == identity as ONE boolean: each rank reduces its shard to a raw
+        # Miller product (signatures summed in G1 first), the 384-byte partials are all-gathered over the rank's ncclComm_t and every rank
+        # finishes product + final exponentiation (sylow_hip_bls_aggregate_verify_batch(comm)); hashing is inside the clock.
+        # Without a communicator (one rank, or the gloo debugging backend): per-rank booleans AND-ed through the process group.
         na = nv
         gt1, is1 = eng.empty((48, 1)), eng.empty((1,), np.uint8)
-        agg = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, None, gt1.ptr, is1.ptr)
-        agg()                                                                         # warm
-        fence()
-        ta = time.perf_counter()
-        agg()
-        fence()
-        dta = time.perf_counter() - ta
-        # AND over ranks of the per-rank aggregate booleans (a planted bad signature on any rank must reach rank 0)
-        agg_ok = sharding.all_valid(int(is1.download()[0]), dist)
+        agg = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, comm_ptr, gt1.ptr, is1.ptr)
+        dta, agg_ms = timed_ranks(agg, 2)
+        agg_ok = int(is1.download()[0]) if comm is not None else sharding.all_valid(int(is1.download()[0]), dist)
         # the same with ONE signer for the whole batch: both halves collapse (n hashes, two G1 sums, a two-pair product)
         k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
         sk1, sk1one = eng.empty((4, nv)).upload(np.repeat(k1, nv, axis=1)), eng.empty((4, 1)).upload(k1)
@@ -421,26 +469,29 @@ def main():
         g2one = eng.empty((16, 1)).upload(limbs_row(G2).T.copy())
         eng._call("sylow_hip_bls_sign_batch", sk1.ptr, dm.ptr, doff.ptr, sig1.ptr, sig1i.ptr, nv)
         eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2one.ptr, None, sk1one.ptr, pk1.ptr, pk1i.ptr, 1)
-        agg1 = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk1.ptr, None, 1, dm.ptr, doff.ptr, sig1.ptr, None, nv, None, gt1.ptr, is1.ptr)
-        agg1()
-        fence()
-        ta1 = time.perf_counter()
-        agg1()
-        fence()
-        dta1 = time.perf_counter() - ta1
+        agg1 = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk1.ptr, None, 1, dm.ptr, doff.ptr, sig1.ptr, None, nv, comm_ptr, gt1.ptr, is1.ptr)
+        dta1, agg1_ms = timed_ranks(agg1, 2)
         agg1_ok = int(is1.download()[0])
         del sk1, sig1, sig1i
         aux = {"aggregate_verify_sigs_per_s": world * na / dta, "aggregate_all_valid": agg_ok, "aggregate_batch_per_gpu": na,
                "aggregate_same_signer_sigs_per_s": world * nv / dta1, "aggregate_same_signer_all_valid": agg1_ok,
+               "aggregate_path": ("native: sylow_hip_bls_aggregate_verify_batch over this rank's ncclComm_t (all-gather of %d partial products)" % rccl_ranks) if comm is not None
+                                 else "per-rank product, booleans AND-ed through the process group",
                "bls_signs_per_s": world * nv / dtsg, "bls_verifies_per_s": world * nv / dtv, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
                "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
                "bls_verify_frac_of_hbm": world * nv * VERIFY_BYTES / dtv / 1e9 / (HBM_PEAK_GBS * world),
                "bls_verifies_per_s_two_pairings": world * nv / dtf, "bls_all_valid_two_pairings": int(flag2.item()), "bad_flags_this_rank": n_bad,
+               "kernel_ms_rank0": {"bls_sign": sign_ms, "bls_verify": verify_ms, "bls_verify_two_pairings": verify2_ms, "same_signer": same_ms,
+                                   "aggregate": agg_ms, "aggregate_same_signer": agg1_ms},
+               "and_path": "native: sylow_hip_all_valid (device AND + ncclAllReduce(min) on this rank's ncclComm_t)" if comm is not None
+                           else "sylow_hip_flags_all + torch.distributed MIN" if dist is not None else "sylow_hip_flags_all (one rank)",
+               "strong": strong,
+               "timing": "every figure: mean of 2-3 calls after a warm call, slowest rank's wall clock between barrier + synchronize; kernel_ms_rank0 = HIP events on the launch stream",
                "note": "verify = sylow_hip_bls_verify_batch: the boolean of lib.rs:223-236 as e(sig,G2gen)*e(-H,pk)==1 (hash + shared-squaring 2-pair Miller loop + ONE final exponentiation); "
                        "two_pairings = the same boolean evaluated literally (hash + two full pairings + compare); "
                        "aggregate = prod_i e(sig_i,G2gen) e(-H(m_i),pk_i) == identity as one boolean: hash + G1 sum of the signatures + product tree over the n key pairs + one final exponentiation; "
                        "aggregate_same_signer = one key: hash + two G1 sums + a two-pair product"}
-        if world == 1:
+        if world == 1 and not args.force_dist:
             del dm, doff, sk, g2, pk, pki, sig, sigi, ok, pk1, pk1i, g2one, sk1one
             aux["configs"] = single_gpu_configs(eng, torch, stream, p, q, ka, n)
 
@@ -452,7 +503,7 @@ def main():
         live = pmc is not None and not stale
         out = {
             "metric": "BN254 optimal-ate pairings/s", "value": value, "unit": "pairings/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32/u32 limbs (9x29-bit carry-free core + 8x32-bit Montgomery, exact integer)", "data": "synthetic",
             "config": {"workload": f"pairing_batch: 2^{args.log2n} independent e(a_i*G1, b_i*G2) per GPU per step "
@@ -481,7 +532,14 @@ def main():
             out["aux"] = aux
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(check)
+        if dist is not None:
+            out["collective_backend"] = backend
+            if comm_err:
+                out["rccl_native_error"] = comm_err
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -253,7 +253,14 @@ __global__ void HEAVY_BOUNDS k_g2_projective_new(const u64* pxyz, uint8_t* statu
   const bool zz = s2_is_zero(z);
   uint8_t st = SYLOW_HIP_ST_OK;
   if (!(s2_eq(lhs, rhs) || zz)) st = SYLOW_HIP_ST_NOT_ON_CURVE;
-  else if (!zz && !g2q_in_subgroup_proj(load_g2q_proj(pxyz, n, i, odd))) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;   // Z == 0 passes both tests
+  else if (zz) {
+    // Z == 0 is waved through the curve test whatever X and Y are (g2.rs:469), and the torsion test then runs the complete formulas on
+    // (X, Y, 0).  With X == 0 or Y == 0 every intermediate keeps Z == 0 and the verdict is Ok; otherwise x Q comes out as (XY, Y^2, 0)
+    // (the last digit of the NAF of x is +1), (x + 1) Q = (XY, Y^2, 0) + (X, Y, 0) has Z = 3 XY X (2 X Y^2) != 0 and the relation
+    // fails: NotInSubgroup -- the outcome of the reference's arithmetic, stated directly (the oracle replays it step by step)
+    if (!s2_is_zero(x) && !s2_is_zero(y)) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
+  }
+  else if (!g2q_in_subgroup_proj(load_g2q_proj(pxyz, n, i, odd))) st = SYLOW_HIP_ST_NOT_IN_SUBGROUP;
   if (!odd) status[i] = st;
 }
 // ConstantTimeEq for projective points (group.rs:426-447)

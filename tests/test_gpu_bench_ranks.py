@@ -33,6 +33,10 @@ def test_two_rank_bench_all_valid():
     aux = out["aux"]
     assert aux["bls_all_valid"] == 1 and aux["bls_all_valid_two_pairings"] == 1 and aux["aggregate_all_valid"] == 1
     assert aux["bls_verify_batch_per_gpu"] == 4096 and aux["bad_flags_this_rank"] == 0
+    # strong scaling: ONE batch of 4096 cut into two contiguous blocks (BASELINE.json configs[3] as written)
+    st = aux["strong"]
+    assert st["batch_total"] == 4096 and st["shard_this_rank"] == 2048 and st["bls_all_valid"] == 1 and st["bls_verifies_per_s"] > 0 and st["pairings_per_s"] > 0
+    assert out["rccl_ranks"] is None and out["collective_backend"] == "gloo"        # two ranks on one GPU: RCCL cannot run here
 
 
 def test_two_rank_bench_planted_bad_signature_on_rank_1():
@@ -41,6 +45,28 @@ def test_two_rank_bench_planted_bad_signature_on_rank_1():
     assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_two_pairings"] == 0      # rank 0 sees rank 1's failure through the reduce
     assert aux["aggregate_all_valid"] == 0 and aux["aggregate_same_signer_all_valid"] == 1   # the aggregate check sees it too
     assert aux["bad_flags_this_rank"] == 0                                       # ... although all of rank 0's own flags are set
+
+
+def run_bench_nccl_one_rank(extra):
+    """backend nccl with ONE rank (plain child process, --force-dist): the process group is RCCL, the rank builds its own native
+    ncclComm_t from the broadcast unique id, and the C ABI's aggregate entry points run on it -- the path the driver's N > 1 runs take."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("SYLOW_BENCH_BACKEND", None); env.pop("SYLOW_BENCH_SINGLE_DEVICE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--log2n", "12", "--steps", "1", "--warmup", "1", "--no-cpu"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+
+
+def test_one_rank_nccl_native_communicator():
+    out = run_bench_nccl_one_rank([])
+    assert out["rccl_ranks"] == 1 and out["collective_backend"] == "nccl" and "rccl_native_error" not in out
+    aux = out["aux"]
+    assert aux["and_path"].startswith("native") and aux["aggregate_path"].startswith("native")
+    assert aux["bls_all_valid"] == 1 and aux["aggregate_all_valid"] == 1 and aux["aggregate_same_signer_all_valid"] == 1 and aux["strong"]["bls_all_valid"] == 1
+    bad = run_bench_nccl_one_rank(["--plant-bad", "0"])["aux"]
+    assert bad["bls_all_valid"] == 0 and bad["aggregate_all_valid"] == 0 and bad["strong"]["bls_all_valid"] == 0 and bad["aggregate_same_signer_all_valid"] == 1
 
 
 def test_single_rank_bench_self_check():

@@ -81,7 +81,9 @@ def test_group_sub_vs_oracle(engine, coracle):
     a1, b1, a2, b2 = p_xy[:n].copy(), p_xy[n:].copy(), q_xy[:n].copy(), q_xy[n:].copy()
     b1[0], b2[0] = a1[0], a2[0]                                  # P - P = identity
     ainf = np.zeros(n, dtype=np.uint8); binf = np.zeros(n, dtype=np.uint8)
-    ainf[1] = 1; binf[2] = 1; ainf[3] = binf[3] = 1              # identity on either / both sides
+    ainf[1] = 1; binf[2] = 1; ainf[3] = binf[3] = 1              # identity on either / both sides, spelled (0, 1, inf) as the
+    for arr, flags, ident in ((a1, ainf, [0, 1]), (b1, binf, [0, 1]), (a2, ainf, [0, 0, 1, 0]), (b2, binf, [0, 0, 1, 0])):   # reference's affine form does
+        arr[flags == 1] = limbs(ident).reshape(-1)
     z4 = np.zeros((n, 4), dtype=np.uint64)
     one1 = np.repeat(ONE4, n, 0)
     pa = np.concatenate([a1, one1 * (1 - ainf.astype(np.uint64))[:, None]], axis=1)
@@ -119,11 +121,14 @@ def test_projective_new_vs_oracle(engine, coracle):
         y = fp2_sqrt(R.fp2_add(R.fp2_mul(R.fp2_square(x), x), R.TWIST_B))
     b[8] = _g2_proj(coracle, pack(list(x) + list(y), 16), [0], [(rng.fp() or 1, rng.fp())])[0]
     b[9] = limbs([1, 2, 3, 4, 1, 0]).reshape(-1)                 # off the curve
-    b[10] = limbs([1, 2, 3, 4, 0, 0]).reshape(-1)                # Z = 0 passes
+    b[10] = limbs([1, 2, 3, 4, 0, 0]).reshape(-1)                # Z = 0 with X, Y != 0: passes the curve test, fails the torsion test
+    b[11] = limbs([0, 0, 5, 6, 0, 0]).reshape(-1)                # Z = 0, X = 0: every intermediate keeps Z = 0 -> Ok
+    b[12] = limbs([1, 2, 0, 0, 0, 0]).reshape(-1)                # Z = 0, Y = 0 -> Ok
+    b[13] = limbs([0, 0, 0, 0, 0, 0]).reshape(-1)
     got, exp = engine.g2_projective_new(b), coracle.g2_projective_new(b)
     exp = np.where(exp == 3, 1, exp).astype(np.uint8)            # the reference panics there: NOT_ON_CURVE here (documented)
     assert np.array_equal(got, exp)
-    assert got[9] == 1 and got[10] == 0 and not got[:8].any()
+    assert got[9] == 1 and got[10] == 2 and not got[:8].any() and not got[11:14].any()
     assert got[8] == 2                                           # on the twist, outside the r-torsion
 
 
