@@ -394,8 +394,8 @@ def main():
             s_h[:, j] = s_h[:, (j + 1) % nv]
             sig.upload(s_h)
         # torch's first device allocation initialises its allocator (seconds on a cold box): keep it outside the clocks
-        flag = torch.ones(1, dtype=torch.int32, device="cuda")
-        flag2 = torch.ones(1, dtype=torch.int32, device="cuda")
+        flag_dev = torch.ones(1, dtype=torch.int32, device="cuda")          # the device word the native calls write; results are kept apart
+        flag = flag2 = flag3 = flag_dev                                      # (a host-side backend returns a host copy)
 
         def and_over_ranks(okbuf, m, out):
             """AND of this rank's flags AND-ed over all ranks: the native entry point (device-side AND + 4-byte ncclAllReduce(min) on the
@@ -409,16 +409,18 @@ def main():
         def verify_weak():
             nonlocal flag
             eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-            flag = and_over_ranks(ok, nv, flag)          # AND over ranks: 4 bytes over xGMI (RCCL MIN)
+            flag = and_over_ranks(ok, nv, flag_dev)      # AND over ranks: 4 bytes over xGMI (RCCL MIN)
 
         dtv, verify_ms = timed_ranks(verify_weak)
+        all_valid_weak = int(flag.item())
 
         def verify_two():
             nonlocal flag2
             eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-            flag2 = and_over_ranks(ok, nv, flag2)
+            flag2 = and_over_ranks(ok, nv, flag_dev)
 
         dtf, verify2_ms = timed_ranks(verify_two, 1)
+        all_valid_two = int(flag2.item())
         n_bad = int(nv - int(ok.download().sum()))
         dts, same_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), 2)
 
@@ -436,18 +438,18 @@ def main():
         dm_s = dm if ms == nv else eng.to_device(msgs_np[:ms].reshape(-1))
         doff_s = doff if ms == nv else eng.to_device(off[:ms + 1])
         ok_s, gt_s = eng.empty((max(ms, 1),), np.uint8), eng.empty((48, max(ms, 1)))
-        flag3 = torch.ones(1, dtype=torch.int32, device="cuda")
 
         def verify_strong():
             nonlocal flag3
             if ms:
                 eng._call("sylow_hip_bls_verify_batch", pk_s.ptr, None, dm_s.ptr, doff_s.ptr, sig_s.ptr, None, ok_s.ptr, ms)
-            flag3 = and_over_ranks(ok_s, ms, flag3)
+            flag3 = and_over_ranks(ok_s, ms, flag_dev)
 
         dtvs, _ = timed_ranks(verify_strong)
+        all_valid_strong = int(flag3.item())
         dtps, _ = timed_ranks(lambda: ms and eng._call("sylow_hip_pairing_batch", p_s.ptr, None, q_s.ptr, None, gt_s.ptr, ms))
         strong = {"scaling": "strong", "batch_total": n_total, "shard_this_rank": ms, "bls_verifies_per_s": n_total / dtvs, "pairings_per_s": n_total / dtps,
-                  "bls_all_valid": int(flag3.item()),
+                  "bls_all_valid": all_valid_strong,
                   "note": "ONE batch of %d sharded over %d rank(s) as contiguous blocks; time = slowest rank between barriers; verify includes the AND over ranks" % (n_total, world)}
         del pk_s, sig_s, p_s, q_s, ok_s, gt_s
 
@@ -478,9 +480,9 @@ def main():
                "aggregate_path": ("native: sylow_hip_bls_aggregate_verify_batch over this rank's ncclComm_t (all-gather of %d partial products)" % rccl_ranks) if comm is not None
                                  else "per-rank product, booleans AND-ed through the process group",
                "bls_signs_per_s": world * nv / dtsg, "bls_verifies_per_s": world * nv / dtv, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
-               "bls_all_valid": int(flag.item()), "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
+               "bls_all_valid": all_valid_weak, "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
                "bls_verify_frac_of_hbm": world * nv * VERIFY_BYTES / dtv / 1e9 / (HBM_PEAK_GBS * world),
-               "bls_verifies_per_s_two_pairings": world * nv / dtf, "bls_all_valid_two_pairings": int(flag2.item()), "bad_flags_this_rank": n_bad,
+               "bls_verifies_per_s_two_pairings": world * nv / dtf, "bls_all_valid_two_pairings": all_valid_two, "bad_flags_this_rank": n_bad,
                "kernel_ms_rank0": {"bls_sign": sign_ms, "bls_verify": verify_ms, "bls_verify_two_pairings": verify2_ms, "same_signer": same_ms,
                                    "aggregate": agg_ms, "aggregate_same_signer": agg1_ms},
                "and_path": "native: sylow_hip_all_valid (device AND + ncclAllReduce(min) on this rank's ncclComm_t)" if comm is not None

@@ -250,6 +250,150 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
   }
 }
 
+// ------------------------------------------------------------------ glued pairings through line tables in HBM ---------------
+// Jobs of three or more pairs.  Sharing the squarings of one accumulator among k pairs needs k working G2 points next to the
+// accumulator, which 256 registers do not hold (the in-register schedule above parks them in the stack frame and runs no faster than
+// k separate loops).  So the work is cut where the data is smallest: PHASE A gives every (job, slot) its own lane pair, walks that
+// pair's G2 point through the 87 steps with NO accumulator alive, and streams the lines -- already scaled by P: (l0, l1 P.y, l2 P.x),
+// the operands of sparse_mul (pairing.rs:598) -- to HBM; PHASE B gives every job one lane pair that holds the accumulator and one line,
+// and per step squares once and multiplies by the k lines it reads back.  Same field elements as the shared-squaring loop of
+// glued_miller_loop (pairing.rs:970-1022): products commute and every value is an exact residue, so raw Miller values still match
+// bit for bit.  A line is 27 R/N-class int32 digits per lane (three Fp2 coefficients x 9 limbs), stored as 7 x 16 bytes per lane,
+// [line][slot][chunk][thread]: a wavefront writes / reads 1 KB contiguous per instruction.  19.5 KB per pair, written once and read
+// once: 0.5 - 1 TB/s while these issue-bound kernels run, HBM the path otherwise leaves idle.
+constexpr int LT_CHUNKS = 7;
+constexpr int LT_LINES = 87;
+struct LineW { W2 l0, l4, l2; };
+BN_DEV void line_put(uint4* at, size_t stride, const LineW& L) {
+  const i32 w[28] = {L.l0.c.v[0], L.l0.c.v[1], L.l0.c.v[2], L.l0.c.v[3], L.l0.c.v[4], L.l0.c.v[5], L.l0.c.v[6], L.l0.c.v[7], L.l0.c.v[8],
+                     L.l4.c.v[0], L.l4.c.v[1], L.l4.c.v[2], L.l4.c.v[3], L.l4.c.v[4], L.l4.c.v[5], L.l4.c.v[6], L.l4.c.v[7], L.l4.c.v[8],
+                     L.l2.c.v[0], L.l2.c.v[1], L.l2.c.v[2], L.l2.c.v[3], L.l2.c.v[4], L.l2.c.v[5], L.l2.c.v[6], L.l2.c.v[7], L.l2.c.v[8], 0};
+#pragma unroll
+  for (int c = 0; c < LT_CHUNKS; ++c) at[(size_t)c * stride] = make_uint4((u32)w[4 * c], (u32)w[4 * c + 1], (u32)w[4 * c + 2], (u32)w[4 * c + 3]);
+}
+BN_DEV LineW line_get(const uint4* at, size_t stride) {
+  u32 w[28];
+#pragma unroll
+  for (int c = 0; c < LT_CHUNKS; ++c) {
+    const uint4 q = at[(size_t)c * stride];
+    w[4 * c] = q.x; w[4 * c + 1] = q.y; w[4 * c + 2] = q.z; w[4 * c + 3] = q.w;
+  }
+  LineW L;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { L.l0.c.v[i] = (i32)w[i]; L.l4.c.v[i] = (i32)w[9 + i]; L.l2.c.v[i] = (i32)w[18 + i]; }
+  return L;
+}
+// PHASE A: lane pair u = slot * jb + (job - job0) owns pair offsets[job] + slot.  A slot without a pair -- the job is shorter, or
+// skip_infinity drops the pair (EIP-197: an identity on either side contributes 1) -- writes 87 unit lines.  In replay mode a G2
+// identity walks through the formulas with Z = 0 exactly as in glued_miller_chunks.
+__global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, const u64* offsets,
+                                          size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity, uint4* table) {
+  const size_t t = TID, u = t >> 1;
+  const int odd = (int)(t & 1);
+  if (u >= (size_t)kt * jb) return;
+  const size_t slot = u / jb, jl = u - slot * jb, job = job0 + jl;
+  const size_t lo = offsets[job], hi = offsets[job + 1], idx = lo + slot;
+  const bool exists = idx < hi;
+  const bool pi = exists && pinf && pinf[idx], qi = exists && qinf && qinf[idx];
+  const bool live = exists && !(skip_infinity && (pi || qi));
+  const size_t stride = 2 * jb, line_step = (size_t)kt * LT_CHUNKS * stride;
+  uint4* at = table + slot * LT_CHUNKS * stride + 2 * jl + (size_t)odd;
+  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  if (!live) {
+    const LineW unit{w_one, w_zero, w_zero};
+#pragma unroll 1
+    for (int l = 0; l < LT_LINES; ++l) line_put(at + (size_t)l * line_step, stride, unit);
+    return;
+  }
+  const F29 px = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 0))), py = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 4)));
+  const S2 qxs = load_s2(qxy, n_pairs, idx, 0, odd), qys = load_s2(qxy, n_pairs, idx, 8, odd);
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+  // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the glued loop never looks at the flag again
+  G2W r{qx, qy, qi ? w_zero : w_one};
+  W2 l0, l1, l2;
+  int line = 0;
+  auto emit = [&]() {
+    line_put(at + (size_t)line * line_step, stride, LineW{l0, w2_scale(l1, py), w2_scale(l2, px)});
+    ++line;
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    g2_doubling_step29(r, l0, l1, l2);
+    emit();
+    if ((nz >> (63 - i)) & 1) {
+      g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
+      emit();
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;                              // endomorphism() returns self for the identity (g2.rs:141-143)
+  g2_psi_affine(q1x, q1y, qxs, qys);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  q1x = s2_select(q1x, qxs, qi); q1y = s2_select(q1y, qys, qi);
+  q2x = s2_select(q2x, qxs, qi); q2y = s2_select(q2y, qys, qi);
+  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  emit();
+  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+  emit();
+}
+// PHASE B, the Miller part: out of line for the same stack-frame reason as glued_miller_chunks.  kw = the wavefront's largest slot
+// count; a lane pair with fewer pairs reads the unit lines phase A wrote for its empty slots.
+BN_NOINLINE void glued_miller_tables(W12& f, const uint4* at, size_t stride, size_t line_step, int kw) {
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  const u64 nz = BN_ATE_NAF_NZ;
+  int line = 0;
+  auto lines = [&]() {
+    const uint4* row = at + (size_t)line * line_step;
+#pragma unroll 1
+    for (int sl = 0; sl < kw; ++sl) {
+      const LineW L = line_get(row + (size_t)sl * LT_CHUNKS * stride, stride);
+      f = w12_sparse_mul(f, L.l0, L.l4, L.l2);
+    }
+    ++line;
+  };
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    f = w12_sqr(f);
+    lines();
+    if ((nz >> (63 - it)) & 1) lines();
+  }
+  lines();
+  lines();
+}
+__global__ void HEAVY_BOUNDS k_glued_from_tables(const uint4* table, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                                 const u64* offsets, size_t job0, size_t jb, size_t n_jobs, size_t n_pairs, int kt, int skip_infinity,
+                                                 u64* gout, uint8_t* is_one, int raw_miller) {
+  const size_t t = TID, jl = t >> 1;
+  const int odd = (int)(t & 1);
+  const bool active = jl < jb;                 // no early return: every lane takes part in the wave reductions
+  const size_t job = job0 + (active ? jl : 0);
+  const size_t lo = offsets[job], hi = offsets[job + 1];
+  const size_t k = active ? hi - lo : 0;
+  const int kw = wave_max((int)(k < (size_t)kt ? k : (size_t)kt));
+  const size_t stride = 2 * jb;
+  W12 acc;
+  glued_miller_tables(acc, table + 2 * (active ? jl : 0) + (size_t)odd, stride, (size_t)kt * LT_CHUNKS * stride, kw);
+  // pairs beyond the table's slots (a job much longer than the batch average): the in-register schedule, one more product
+  if (wave_max(k > (size_t)kt ? 1 : 0)) {
+    W12 rest;
+    const size_t from = k > (size_t)kt ? lo + (size_t)kt : hi;
+    glued_miller_chunks<KMAXW>(rest, pxy, pinf, qxy, qinf, from, active ? hi : from, n_pairs, skip_infinity, odd);
+    w12_mul_nl(acc, acc, rest);
+  }
+  S12 fin, g;
+  w12_to_s12(fin, acc);
+  if (raw_miller) g = fin;
+  else final_exponentiation29(g, fin);
+  if (active) {
+    if (gout) store_s12(gout, n_jobs, job, odd, g);
+    const bool one = s12_is_one(g);
+    if (is_one && !odd) is_one[job] = one ? 1 : 0;
+  }
+}
+
 // ------------------------------------------------------------------ one product over a whole batch ---------------------------
 // glued_pairing over n pairs as ONE Gt (examples/verify_multiple_messages_same_signer.rs:41-60: 2n pairs, one final
 // exponentiation, == identity).  The shared-squaring Miller value of a set of pairs is exactly the product of the per-pair Miller
@@ -402,12 +546,51 @@ __global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst,
   result[j] = st ? 0 : is_one[j];
 }
 
+// jobs of three or more pairs on average: lines to HBM, then the table-driven loop (see k_pair_lines).  Job batches of TBL_JOBS share
+// one leased table (19.5 KB per slot and job: 5 GB at four slots), reused in stream order.  SYLOW_HIP_MULTI_TABLES=0 / 1 forces the
+// in-register / the table route for every job size (A/B measurements); SYLOW_HIP_MULTI_JOBS sets the batch size.
+static int multi_tables_mode() {
+  static const int v = [] { const char* e = getenv("SYLOW_HIP_MULTI_TABLES"); return e ? atoi(e) : -1; }();
+  return v;
+}
+static size_t multi_tables_jobs() {
+  static const size_t v = [] { const char* e = getenv("SYLOW_HIP_MULTI_JOBS"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)65536; }();
+  return v;
+}
+static bool use_tables(size_t n_jobs, size_t n_pairs) {
+  const int m = multi_tables_mode();
+  if (m == 0) return false;
+  if (m == 1) return n_pairs != 0;
+  return n_pairs > 2 * n_jobs;
+}
+static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
+                                    size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  size_t kt = (n_pairs + n_jobs - 1) / n_jobs;                 // slots per job: the batch average, rounded up; longer jobs take the in-register tail
+  if (kt < 1) kt = 1;
+  if (kt > 8) kt = 8;
+  const size_t jb_max = n_jobs < multi_tables_jobs() ? n_jobs : multi_tables_jobs();
+  host::Lease ws;
+  int32_t rc = ws.acquire((size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * jb_max * sizeof(uint4), st);
+  if (rc != SYLOW_HIP_OK) return rc;
+  uint4* table = (uint4*)ws.p;
+  for (size_t job0 = 0; job0 < n_jobs; job0 += jb_max) {
+    const size_t jb = n_jobs - job0 < jb_max ? n_jobs - job0 : jb_max;
+    plk::k_pair_lines<<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
+    plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_jobs, n_pairs, (int)kt, skip_infinity, gt_out, is_one, raw_miller);
+  }
+  const hipError_t e = hipGetLastError();
+  rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
+}
+
 extern "C" {
 int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
+  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, stream);
   // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
   // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
   if (n_pairs <= 2 * n_jobs) { plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED(); }
@@ -416,6 +599,7 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
 int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
                                            uint64_t* f_out, void* stream) {
   ARGCHK(pair_offsets && f_out && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
+  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1, stream);
   plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1); LAUNCHED();
 }
 
@@ -579,6 +763,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
     if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
+    else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, stream);
     else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
   }
