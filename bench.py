@@ -254,7 +254,7 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n):
     g1b, g1nb, g2b = (x.download().reshape(n3, -1)[:npts] for x in (b1, b1n, b2))
     pos, neg = np.concatenate([g1b, g2b], axis=1), np.concatenate([g1nb, g2b], axis=1)        # [npts][192] each
     for k in (2, 4):
-        njk = nj if k == 2 else nj // 2
+        njk = nj                               # 2^16 jobs for both shapes (BASELINE.json configs[4]); a k = 4 job uses two base points
         if k == 2:
             jobs = np.concatenate([pos[:njk], neg[:njk]], axis=1)
         else:
@@ -271,7 +271,7 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n):
         res[f"C5_ecpairing_bytes_2^{int(np.log2(njk))}_k{k}"] = {
             "units_per_s": njk / t, "pairs_per_s": k * njk / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS,
             "pattern_ok": int(np.array_equal(r, (~spoil).astype(np.uint8)) and not d_st.download().any()),
-            "kernel": "k_evm_decode_pairs + plk::k_multi_pairing<%d>" % (2 if k == 2 else 4)}
+            "kernel": "k_evm_decode_pairs + plk::k_pair_lines + plk::k_glued_from_tables + plk::k_final_exp_jobs"}
     return res
 
 

@@ -13,6 +13,7 @@
 mod device;
 #[allow(dead_code)]
 mod ffi;
+pub mod surface;
 
 pub use device::{Device, DeviceBuf, Error};
 
@@ -55,14 +56,14 @@ fn group_error(status: u8) -> GroupError {
     }
 }
 
-fn first_failure(status: &[u8]) -> Result<(), HipError> {
+pub(crate) fn first_failure(status: &[u8]) -> Result<(), HipError> {
     match status.iter().position(|&s| s != ST_OK) {
         None => Ok(()),
         Some(index) => Err(HipError::Group { index, error: group_error(status[index]) }),
     }
 }
 
-fn fp_from_words(w: &[u64]) -> Fp {
+pub(crate) fn fp_from_words(w: &[u64]) -> Fp {
     Fp::new(U256::from_words([w[0], w[1], w[2], w[3]]))
 }
 fn fp2_from_words(w: &[u64]) -> Fp2 {
@@ -72,7 +73,7 @@ fn fp6_from_words(w: &[u64]) -> Fp6 {
     Fp6::new(&[fp2_from_words(&w[0..8]), fp2_from_words(&w[8..16]), fp2_from_words(&w[16..24])])
 }
 /// 48 canonical words in the reference's nesting order (c0 then c1, each an Fp6) -> Fp12 / Gt
-fn gt_from_words(w: &[u64; 48]) -> GtOut {
+pub(crate) fn gt_from_words(w: &[u64; 48]) -> GtOut {
     let f = Fp12::new(&[fp6_from_words(&w[0..24]), fp6_from_words(&w[24..48])]);
     #[cfg(feature = "gt-from-fp12")]
     {
@@ -200,7 +201,7 @@ pub fn public_keys(dev: &Device, sk: &[Fp]) -> Result<Vec<G2Projective>, HipErro
     download_g2(dev, &out)
 }
 
-fn messages(dev: &Device, msgs: &[&[u8]]) -> Result<(DeviceBuf<u8>, DeviceBuf<u64>), Error> {
+pub(crate) fn messages(dev: &Device, msgs: &[&[u8]]) -> Result<(DeviceBuf<u8>, DeviceBuf<u64>), Error> {
     let mut offsets = Vec::with_capacity(msgs.len() + 1);
     let mut blob = Vec::new();
     offsets.push(0u64);
@@ -294,6 +295,7 @@ pub fn verify_batch(dev: &Device, pk: &[G2Affine], msgs: &[&[u8]], sig: &[G1Affi
 /// CACHED across calls: build it once with `KeyTable::new`, then verify any number of batches against it.
 pub struct KeyTable {
     table: DeviceBuf<i32>,
+    inf: DeviceBuf<u8>,      // the key's identity flag (1 byte): pairing(_, identity) = 1 upstream, so pair B must be dead for such a key
 }
 impl KeyTable {
     pub fn new(dev: &Device, pk: &G2Affine) -> Result<Self, HipError> {
@@ -304,7 +306,7 @@ impl KeyTable {
         // SAFETY: dpk is a 1-element SoA array; table holds `words` int32.
         device::check(unsafe { ffi::sylow_hip_g2_line_table(dpk.xy.as_ptr(), 1, 0, table.as_mut_ptr(), dev.stream) })?;
         dev.sync()?;
-        Ok(KeyTable { table })
+        Ok(KeyTable { table, inf: dpk.inf })
     }
 
     pub fn verify_batch(&self, dev: &Device, msgs: &[&[u8]], sig: &[G1Affine]) -> Result<Vec<bool>, HipError> {
@@ -313,9 +315,9 @@ impl KeyTable {
         let dsig = upload_g1(dev, sig)?;
         let (d_msgs, d_off) = messages(dev, msgs)?;
         let ok = dev.alloc::<u8>(n)?;
-        // SAFETY: table built by KeyTable::new on this device; n signatures, n + 1 offsets, n flags; pk_inf = NULL (not the identity).
+        // SAFETY: table built by KeyTable::new on this device; n signatures, n + 1 offsets, n flags; pk_inf = the key's 1-byte flag.
         device::check(unsafe {
-            ffi::sylow_hip_bls_verify_line_table_batch(self.table.as_ptr(), ptr::null(), d_msgs.as_ptr(), d_off.as_ptr(), dsig.xy.as_ptr(),
+            ffi::sylow_hip_bls_verify_line_table_batch(self.table.as_ptr(), self.inf.as_ptr(), d_msgs.as_ptr(), d_off.as_ptr(), dsig.xy.as_ptr(),
                                                        dsig.inf.as_ptr(), ok.as_mut_ptr(), n, dev.stream)
         })?;
         Ok(dev.download(&ok)?.iter().map(|&f| f != 0).collect())

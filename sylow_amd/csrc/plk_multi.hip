@@ -261,21 +261,23 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 // bit for bit.  A line is 27 R/N-class int32 digits per lane (three Fp2 coefficients x 9 limbs), stored as 7 x 16 bytes per lane,
 // [line][slot][chunk][thread]: a wavefront writes / reads 1 KB contiguous per instruction.  19.5 KB per pair, written once and read
 // once: 0.5 - 1 TB/s while these issue-bound kernels run, HBM the path otherwise leaves idle.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // a native vector: loads keep their address space
 constexpr int LT_CHUNKS = 7;
 constexpr int LT_LINES = 87;
 struct LineW { W2 l0, l4, l2; };
-BN_DEV void line_put(uint4* at, size_t stride, const LineW& L) {
+BN_DEV void line_put(u32x4* at, size_t stride, const LineW& L) {
   const i32 w[28] = {L.l0.c.v[0], L.l0.c.v[1], L.l0.c.v[2], L.l0.c.v[3], L.l0.c.v[4], L.l0.c.v[5], L.l0.c.v[6], L.l0.c.v[7], L.l0.c.v[8],
                      L.l4.c.v[0], L.l4.c.v[1], L.l4.c.v[2], L.l4.c.v[3], L.l4.c.v[4], L.l4.c.v[5], L.l4.c.v[6], L.l4.c.v[7], L.l4.c.v[8],
                      L.l2.c.v[0], L.l2.c.v[1], L.l2.c.v[2], L.l2.c.v[3], L.l2.c.v[4], L.l2.c.v[5], L.l2.c.v[6], L.l2.c.v[7], L.l2.c.v[8], 0};
 #pragma unroll
-  for (int c = 0; c < LT_CHUNKS; ++c) at[(size_t)c * stride] = make_uint4((u32)w[4 * c], (u32)w[4 * c + 1], (u32)w[4 * c + 2], (u32)w[4 * c + 3]);
+  for (int c = 0; c < LT_CHUNKS; ++c) at[(size_t)c * stride] = u32x4{(u32)w[4 * c], (u32)w[4 * c + 1], (u32)w[4 * c + 2], (u32)w[4 * c + 3]};
 }
-BN_DEV LineW line_get(const uint4* at, size_t stride) {
+template <class PTR>
+BN_DEV LineW line_get(PTR at, size_t stride) {
   u32 w[28];
 #pragma unroll
   for (int c = 0; c < LT_CHUNKS; ++c) {
-    const uint4 q = at[(size_t)c * stride];
+    const u32x4 q = at[(size_t)c * stride];
     w[4 * c] = q.x; w[4 * c + 1] = q.y; w[4 * c + 2] = q.z; w[4 * c + 3] = q.w;
   }
   LineW L;
@@ -287,7 +289,7 @@ BN_DEV LineW line_get(const uint4* at, size_t stride) {
 // skip_infinity drops the pair (EIP-197: an identity on either side contributes 1) -- writes 87 unit lines.  In replay mode a G2
 // identity walks through the formulas with Z = 0 exactly as in glued_miller_chunks.
 __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, const u64* offsets,
-                                          size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity, uint4* table) {
+                                          size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity, u32x4* table) {
   const size_t t = TID, u = t >> 1;
   const int odd = (int)(t & 1);
   if (u >= (size_t)kt * jb) return;
@@ -297,7 +299,7 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
   const bool pi = exists && pinf && pinf[idx], qi = exists && qinf && qinf[idx];
   const bool live = exists && !(skip_infinity && (pi || qi));
   const size_t stride = 2 * jb, line_step = (size_t)kt * LT_CHUNKS * stride;
-  uint4* at = table + slot * LT_CHUNKS * stride + 2 * jl + (size_t)odd;
+  u32x4* at = table + slot * LT_CHUNKS * stride + 2 * jl + (size_t)odd;
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   if (!live) {
     const LineW unit{w_one, w_zero, w_zero};
@@ -336,9 +338,15 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
   g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
   emit();
 }
-// PHASE B, the Miller part: out of line for the same stack-frame reason as glued_miller_chunks.  kw = the wavefront's largest slot
-// count; a lane pair with fewer pairs reads the unit lines phase A wrote for its empty slots.
-BN_NOINLINE void glued_miller_tables(W12& f, const uint4* at, size_t stride, size_t line_step, int kw) {
+// PHASE B: the raw glued Miller value of every job of the batch.  kw = the wavefront's largest slot count; a lane pair with fewer
+// pairs reads the unit lines phase A wrote for its empty slots.  The accumulator is a LOCAL value (as a reference parameter it would
+// live in the caller's frame and every leaf call would force it back to memory), the table pointer is re-qualified as global memory
+// (through a call boundary it is a generic pointer: flat loads), and a line is loaded where it is used -- requesting it one
+// operation ahead (27 more live registers across a line product) measured 1 % slower.
+BN_NOINLINE void glued_miller_tables(W12& fout, const u32x4* at_generic, size_t stride, size_t line_step, int kw) {
+  typedef const __attribute__((address_space(1))) u32x4* gptr;
+  const gptr at = (gptr)at_generic;
+  W12 f;
   {
     S12 one = s12_one();
     w12_from_s12(f, one);
@@ -346,7 +354,7 @@ BN_NOINLINE void glued_miller_tables(W12& f, const uint4* at, size_t stride, siz
   const u64 nz = BN_ATE_NAF_NZ;
   int line = 0;
   auto lines = [&]() {
-    const uint4* row = at + (size_t)line * line_step;
+    const gptr row = at + (size_t)line * line_step;
 #pragma unroll 1
     for (int sl = 0; sl < kw; ++sl) {
       const LineW L = line_get(row + (size_t)sl * LT_CHUNKS * stride, stride);
@@ -362,10 +370,12 @@ BN_NOINLINE void glued_miller_tables(W12& f, const uint4* at, size_t stride, siz
   }
   lines();
   lines();
+  fout = f;
 }
-__global__ void HEAVY_BOUNDS k_glued_from_tables(const uint4* table, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
-                                                 const u64* offsets, size_t job0, size_t jb, size_t n_jobs, size_t n_pairs, int kt, int skip_infinity,
-                                                 u64* gout, uint8_t* is_one, int raw_miller) {
+// fout: SoA stride n_out, job j of the batch at column out0 + j
+__global__ void HEAVY_BOUNDS k_glued_from_tables(const u32x4* table, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+                                                 const u64* offsets, size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity,
+                                                 u64* fout, size_t n_out, size_t out0) {
   const size_t t = TID, jl = t >> 1;
   const int odd = (int)(t & 1);
   const bool active = jl < jb;                 // no early return: every lane takes part in the wave reductions
@@ -383,15 +393,22 @@ __global__ void HEAVY_BOUNDS k_glued_from_tables(const uint4* table, const u64* 
     glued_miller_chunks<KMAXW>(rest, pxy, pinf, qxy, qinf, from, active ? hi : from, n_pairs, skip_infinity, odd);
     w12_mul_nl(acc, acc, rest);
   }
-  S12 fin, g;
+  S12 fin;
   w12_to_s12(fin, acc);
-  if (raw_miller) g = fin;
-  else final_exponentiation29(g, fin);
-  if (active) {
-    if (gout) store_s12(gout, n_jobs, job, odd, g);
-    const bool one = s12_is_one(g);
-    if (is_one && !odd) is_one[job] = one ? 1 : 0;
-  }
+  if (active) store_s12(fout, n_out, out0 + jl, odd, fin);
+}
+// PHASE C: final exponentiation of the batch's raw values (a kernel of its own: fused behind phase B it ran a third slower -- every
+// wavefront of the one-round launch reaches the exponentiation, and its stack frame traffic, at the same moment)
+__global__ void HEAVY_BOUNDS k_final_exp_jobs(const u64* fin, size_t n_in, size_t job0, size_t jb, size_t n_jobs, u64* gout, uint8_t* is_one) {
+  const size_t t = TID, jl = t >> 1;
+  const int odd = (int)(t & 1);
+  if (jl >= jb) return;
+  S12 f, g;
+  load_s12(f, fin, n_in, jl, odd);
+  final_exponentiation29(g, f);
+  if (gout) store_s12(gout, n_jobs, job0 + jl, odd, g);
+  const bool one = s12_is_one(g);
+  if (is_one && !odd) is_one[job0 + jl] = one ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ one product over a whole batch ---------------------------
@@ -546,22 +563,18 @@ __global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst,
   result[j] = st ? 0 : is_one[j];
 }
 
-// jobs of three or more pairs on average: lines to HBM, then the table-driven loop (see k_pair_lines).  Job batches of TBL_JOBS share
-// one leased table (19.5 KB per slot and job: 5 GB at four slots), reused in stream order.  SYLOW_HIP_MULTI_TABLES=0 / 1 forces the
-// in-register / the table route for every job size (A/B measurements); SYLOW_HIP_MULTI_JOBS sets the batch size.
+// Jobs of two or more pairs on average: lines to HBM, then the table-driven loop, then the final exponentiations (see k_pair_lines).
+// Job batches share one leased workspace, reused in stream order: 19.5 KB per slot and job, batches of whole GPU rounds (2^16 lane
+// pairs) up to TBL_BYTES.  SYLOW_HIP_MULTI_TABLES=0 / 1 forces the in-register / the table route for every job size (A/B runs).
 static int multi_tables_mode() {
   static const int v = [] { const char* e = getenv("SYLOW_HIP_MULTI_TABLES"); return e ? atoi(e) : -1; }();
-  return v;
-}
-static size_t multi_tables_jobs() {
-  static const size_t v = [] { const char* e = getenv("SYLOW_HIP_MULTI_JOBS"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)65536; }();
   return v;
 }
 static bool use_tables(size_t n_jobs, size_t n_pairs) {
   const int m = multi_tables_mode();
   if (m == 0) return false;
   if (m == 1) return n_pairs != 0;
-  return n_pairs > 2 * n_jobs;
+  return n_pairs >= 2 * n_jobs;
 }
 static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                     size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
@@ -569,15 +582,26 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   size_t kt = (n_pairs + n_jobs - 1) / n_jobs;                 // slots per job: the batch average, rounded up; longer jobs take the in-register tail
   if (kt < 1) kt = 1;
   if (kt > 8) kt = 8;
-  const size_t jb_max = n_jobs < multi_tables_jobs() ? n_jobs : multi_tables_jobs();
+  constexpr size_t ROUND = 65536, TBL_BYTES = (size_t)12 << 30;
+  const size_t per_job = (size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);
+  size_t rounds = TBL_BYTES / (per_job * ROUND);
+  if (rounds < 1) rounds = 1;
+  const size_t jb_max = n_jobs < rounds * ROUND ? n_jobs : rounds * ROUND;
+  const size_t w_raw = raw_miller ? 0 : 48 * jb_max * sizeof(u64);
   host::Lease ws;
-  int32_t rc = ws.acquire((size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * jb_max * sizeof(uint4), st);
+  int32_t rc = ws.acquire(per_job * jb_max + w_raw, st);
   if (rc != SYLOW_HIP_OK) return rc;
-  uint4* table = (uint4*)ws.p;
+  plk::u32x4* table = (plk::u32x4*)ws.p;
+  u64* raw = (u64*)((uint8_t*)ws.p + per_job * jb_max);
   for (size_t job0 = 0; job0 < n_jobs; job0 += jb_max) {
     const size_t jb = n_jobs - job0 < jb_max ? n_jobs - job0 : jb_max;
     plk::k_pair_lines<<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
-    plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_jobs, n_pairs, (int)kt, skip_infinity, gt_out, is_one, raw_miller);
+    if (raw_miller) {
+      plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, gt_out, n_jobs, job0);
+    } else {
+      plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, raw, jb, 0);
+      plk::k_final_exp_jobs<<<GRID(2 * jb)>>>(raw, jb, job0, jb, n_jobs, gt_out, is_one);
+    }
   }
   const hipError_t e = hipGetLastError();
   rc = ws.release();

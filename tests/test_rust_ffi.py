@@ -69,7 +69,7 @@ def test_wrappers_call_only_declared_entry_points():
     """Every ffi::sylow_hip_* the safe layer calls exists in ffi.rs, with the argument count the declaration has."""
     r = parse_ffi()
     used = 0
-    for fn in ("lib.rs", "device.rs"):
+    for fn in ("lib.rs", "device.rs", "surface.rs"):
         text = open(os.path.join(ROOT, "rust", "sylow-hip", "src", fn)).read()
         for m in re.finditer(r"ffi::(sylow_hip_\w+)\s*\(", text):
             name = m.group(1)
@@ -86,4 +86,15 @@ def test_wrappers_call_only_declared_entry_points():
             argc = (commas + 1) if any_arg else 0
             assert argc == len(r[name][1]), (fn, name, argc, len(r[name][1]))
             used += 1
-    assert used >= 25
+    assert used >= 85
+
+
+def test_every_entry_point_is_reached_by_a_wrapper():
+    """north_star: the host side stays Rust.  Every entry point of include/sylow_hip.h must be called (or passed as a function item) by
+    the safe layer -- lib.rs, device.rs or surface.rs -- so that a new C entry point cannot ship without its typed Rust form."""
+    h = parse_header()
+    text = "".join(open(os.path.join(ROOT, "rust", "sylow-hip", "src", fn)).read() for fn in ("lib.rs", "device.rs", "surface.rs"))
+    reached = set(re.findall(r"ffi::(sylow_hip_\w+)", text))
+    missing = sorted(set(h) - reached)
+    assert not missing, missing
+    assert reached <= set(h), sorted(reached - set(h))
