@@ -655,7 +655,12 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk);
-  if (chunk <= 2) plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
+  if (chunk >= 2 && multi_tables_mode() != 0) {
+    rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+  }
+  else if (chunk <= 2) plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   else plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   u64 *cur = bufa, *nxt = bufb;
   size_t m = n_jobs;

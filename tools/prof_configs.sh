@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: prof_configs.sh <tag> [--only name,name]
+# rocprofv3 evidence for EVERY configuration bench.py prints: one --kernel-trace run for durations, then one --pmc
+# run per counter group (a trace domain is never combined with --pmc; FETCH_SIZE and WRITE_SIZE in passes of their own, as
+# MI355X_MICROARCH.md prescribes), all over the same workload driver (tools/prof_configs.py, which brackets every configuration
+# with marker launches).  tools/prof_summarize.py cuts each pass into per-configuration windows and writes
+#   gpurun_out/prof_<tag>/{summary.json, pmc_current.json, kernel_stats.csv}   -> copy to profiles/<tag>/ and profiles/pmc_current.json
+TAG=${1:-r03_configs}; shift
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o p -- python3 tools/prof_configs.py --manifest $OUT/manifest.json "$@" > $OUT/trace.log 2>&1
+cp $OUT/trace/p_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 tools/prof_configs.py $EXTRA > $OUT/$name.log 2>&1; }
+EXTRA="$@"
+run mix SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+run stall SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+python3 tools/prof_summarize.py $OUT "profiles/$TAG"
