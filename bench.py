@@ -48,28 +48,38 @@ G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
       0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA,
       0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B]
 M64 = (1 << 64) - 1
-# sources the dominant kernel is compiled from: the committed PMC summary is only valid for the build it was measured on
-PAIRING_KERNEL_SOURCES = ["plk_pairing.hip", "plk_common.hpp", "host.hpp", "common.hpp", "bn254_pair29.hpp", "bn254_pair.hpp", "bn254_f29.hpp",
-                          "bn254_tower.hpp", "bn254_fp.hpp", "bn254_constants.hpp", "bn254_pairing.hpp", "bn254_hash.hpp", "bn254_fr.hpp"]
-
-
-def kernel_source_hash():
+def csrc_hash():
+    """Hash of every kernel source: the committed PMC summary (profiles/pmc_current.json) is only valid for the build it was measured on."""
     h = hashlib.sha256()
-    for name in PAIRING_KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "sylow_amd", "csrc", name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read())
+    d = os.path.join(ROOT, "sylow_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
 def load_pmc():
-    """rocprofv3 PMC facts about plk::k_pairing (bench.py cannot collect PMC counters itself): per-pairing constants measured by
-    tools/prof_pairing.sh (separate --pmc passes, n = 2^20) in profiles/pmc_current.json.  Returns (pmc or None, stale?)."""
+    """rocprofv3 PMC facts per configuration (bench.py cannot collect PMC counters itself): per-unit constants measured by
+    tools/prof_configs.sh (separate --pmc passes, bench.py's sizes) in profiles/pmc_current.json.  Returns (pmc or None, stale?)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             pmc = json.load(f)
     except OSError:
         return None, False
-    return pmc, pmc.get("kernel_source_hash") != kernel_source_hash()
+    return pmc, pmc.get("csrc_hash") != csrc_hash()
+
+
+def issue_fields(pmc_cfg):
+    """The issue-roof entry of one configuration: cycle-weighted VALU issue cycles (quarter-rate 64-bit class x 4 + other VALU x 2) over
+    the SIMD cycles the GPU spent on the configuration's kernels -- numerator and denominator from the SAME rocprofv3 pass, so no clock
+    enters and the fraction is a property of the build, not of the box."""
+    if not pmc_cfg or pmc_cfg.get("issue_frac") is None:
+        return {}
+    return {"issue_frac": pmc_cfg["issue_frac"], "issue_frac_vs_measured_issue_rates": pmc_cfg.get("issue_frac_vs_measured_issue_rates"),
+            "valu_instr_per_unit": pmc_cfg.get("valu_instr_per_unit"), "int64_class_frac": pmc_cfg.get("int64_class_frac"),
+            "issue_cycles_ideal_per_unit": pmc_cfg.get("issue_cycles_ideal_per_unit"), "simd_cycles_per_unit": pmc_cfg.get("simd_cycles_per_unit"),
+            "hbm_bytes_per_unit_measured": pmc_cfg.get("hbm_bytes_per_unit"), "profile_ms_per_launch": pmc_cfg.get("ms_per_launch_kernel_sum")}
 
 
 def limbs_row(vals):
@@ -201,7 +211,7 @@ def hip_timed(torch, stream, fn, reps):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-def single_gpu_configs(eng, torch, stream, p, q, ka, n):
+def single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs=None):
     """BASELINE.json configs[1], [2], [4] on one GPU, device-resident, HIP-event timed (units/s, algorithmic GB/s, fraction of
     the 8 TB/s HBM roof).  Fp mul / add are the HBM-bound kernels of the path (96 algorithmic bytes per element)."""
     res = {}
@@ -272,6 +282,8 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n):
             "units_per_s": njk / t, "pairs_per_s": k * njk / t, "algorithmic_GBps": gbs, "frac_of_hbm": gbs / HBM_PEAK_GBS,
             "pattern_ok": int(np.array_equal(r, (~spoil).astype(np.uint8)) and not d_st.download().any()),
             "kernel": "k_evm_decode_pairs + plk::k_pair_lines + plk::k_glued_from_tables + plk::k_final_exp_jobs"}
+    for name, e in res.items():                      # both roofs for every configuration
+        e.update(issue_fields((pmc_cfgs or {}).get(name)))
     return res
 
 
@@ -350,6 +362,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         idx = np.sort(np.random.default_rng(SEED).choice(n, size=min(16, n), replace=False))
         check = tuple(np.ascontiguousarray(d.download()[:, idx].T) for d in (p, q, gt))
+
+    pmc, pmc_stale = load_pmc()
+    pmc_cfgs = pmc.get("configs", {}) if (pmc is not None and not pmc_stale) else {}
 
     # ---- native RCCL communicator for the C ABI's aggregate entry points (one per rank; backend nccl only) -------------
     comm, comm_err = None, None
@@ -488,6 +503,11 @@ def main():
                "and_path": "native: sylow_hip_all_valid (device AND + ncclAllReduce(min) on this rank's ncclComm_t)" if comm is not None
                            else "sylow_hip_flags_all + torch.distributed MIN" if dist is not None else "sylow_hip_flags_all (one rank)",
                "strong": strong,
+               "issue_roof": {k: issue_fields(pmc_cfgs.get(v)) for k, v in (("bls_sign", "bls_sign_2^20"), ("bls_verify", "bls_verify_2^20"),
+                                                                               ("bls_verify_two_pairings", "bls_verify_two_pairings_2^20"),
+                                                                               ("same_signer_shape", "bls_verify_same_signer_shape_2^20"),
+                                                                               ("aggregate", "aggregate_verify_2^20"), ("aggregate_same_signer", "aggregate_same_signer_2^20"))
+                              if nv == 1 << 20 and pmc_cfgs.get(v)},
                "timing": "every figure: mean of 2-3 calls after a warm call, slowest rank's wall clock between barrier + synchronize; kernel_ms_rank0 = HIP events on the launch stream",
                "note": "verify = sylow_hip_bls_verify_batch: the boolean of lib.rs:223-236 as e(sig,G2gen)*e(-H,pk)==1 (hash + shared-squaring 2-pair Miller loop + ONE final exponentiation); "
                        "two_pairings = the same boolean evaluated literally (hash + two full pairings + compare); "
@@ -495,14 +515,13 @@ def main():
                        "aggregate_same_signer = one key: hash + two G1 sums + a two-pair product"}
         if world == 1 and not args.force_dist:
             del dm, doff, sk, g2, pk, pki, sig, sigi, ok, pk1, pk1i, g2one, sk1one
-            aux["configs"] = single_gpu_configs(eng, torch, stream, p, q, ka, n)
+            aux["configs"] = single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs)
 
     if rank == 0:
         total = world * n * args.steps
         value = total / elapsed
         achieved = PAIRING_BYTES * n / (kern_ms * 1e-3) / 1e9
-        pmc, stale = load_pmc()
-        live = pmc is not None and not stale
+        main_cfg = pmc_cfgs.get("pairing_2^%d" % args.log2n)
         out = {
             "metric": "BN254 optimal-ate pairings/s", "value": value, "unit": "pairings/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
@@ -514,22 +533,23 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "achieved_note": "ALGORITHMIC bytes (576 per pairing) / kernel time; the HBM-bound kernels of the path are aux.configs C2a",
-                         "traffic": (pmc["hbm_bytes_per_pairing"] * n) if live else None,
-                         "traffic_note": (("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + pmc["source"] + ")") if live else
-                                          ("profiles/pmc_current.json was measured on another build of the kernel (source hash differs): re-run tools/prof_pairing.sh"
+                         "traffic": (main_cfg["hbm_bytes_per_unit"] * n) if main_cfg and main_cfg.get("hbm_bytes_per_unit") else None,
+                         "traffic_note": (("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + pmc["source"] + ")") if main_cfg else
+                                          ("profiles/pmc_current.json was measured on another build of the kernels (source hash differs): re-run tools/prof_configs.sh"
                                            if pmc is not None else None)),
                          "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
         }
-        if live and "valu_cycles_ideal_per_pairing" in pmc:
-            # cycle-weighted issue roofline: sum over instruction classes of (measured wave-instructions x issue cycles of the class) /
-            # SIMD-cycles available in the launch (clock from GRBM_GUI_ACTIVE of the same PMC run)
-            simd_cycles = kern_ms * 1e-3 * pmc["clock_ghz"] * 1e9 * N_SIMD
+        if main_cfg and main_cfg.get("issue_frac") is not None:
+            # cycle-weighted issue roofline: sum over instruction classes of (wave-instructions x issue cycles of the class) over the SIMD
+            # cycles of the launch, both from the same rocprofv3 pass (clock-free); the live kernel time is shown beside the profiled one
             out["issue_roofline"] = {"bound": "valu-issue", "unit": "SIMD issue cycles per launch",
-                                     "achieved": pmc["valu_cycles_ideal_per_pairing"] * n, "peak": simd_cycles,
-                                     "frac": pmc["valu_cycles_ideal_per_pairing"] * n / simd_cycles,
-                                     "frac_vs_measured_issue_rates": pmc["valu_cycles_ubench_per_pairing"] * n / simd_cycles,
-                                     "valu_instr_per_pairing": pmc["valu_instr_per_pairing"], "mix": pmc.get("mix"),
-                                     "note": pmc.get("issue_note")}
+                                     "achieved": main_cfg["issue_cycles_ideal_per_unit"] * n, "peak": main_cfg["simd_cycles_per_unit"] * n,
+                                     "frac": main_cfg["issue_frac"], "frac_vs_measured_issue_rates": main_cfg.get("issue_frac_vs_measured_issue_rates"),
+                                     "valu_instr_per_pairing": main_cfg["valu_instr_per_unit"], "int64_class_frac": main_cfg.get("int64_class_frac"),
+                                     "kernel_ms_live": kern_ms, "kernel_ms_profiled": main_cfg.get("ms_per_launch_kernel_sum"),
+                                     "note": "frac = (SQ_INSTS_VALU_INT64 x 4 + other VALU x 2 issue cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the profiled "
+                                             "launch (" + pmc["source"] + "): a property of the build, no clock enters; v_mul_lo_u32 (4 cycles, ~2 % of the stream) "
+                                             "is counted in the 2-cycle class, so the fraction is a slight under-estimate"}
         if aux:
             out["aux"] = aux
         if not args.no_cpu and world == 1:
