@@ -378,6 +378,18 @@ int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8
                                               const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, uint64_t* f_out, void* stream);
 int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                              const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream);
+/* The SOUND one-boolean form ("random-linear-combination multi-pairing"): the small-exponent batch test
+ *   prod_i [ e(sig_i, G2gen) e(-H(msg_i), pk_i) ]^(w_i) == identity,   evaluated as e(sum_i w_i sig_i, G2gen) prod_i e(-w_i H(msg_i), pk_i).
+ * weights [4][n]: w_i as Fp values (the caller draws them AFTER the signatures are fixed, e.g. 64 or 128 random bits each; 0 removes an
+ * element from the test).  If every signature is valid the result is the identity; if any is not, the test passes with probability at most
+ * 2^-(bits of the weights) over the caller's randomness (keys in G2 proper, as G2Projective::new guarantees).  No counterpart exists upstream --
+ * the reference's examples multiply unweighted (the two entry points above); the Gt value equals the reference's glued_pairing over the 2n
+ * pairs (w_i sig_i, G2gen), (-w_i H(msg_i), pk_i), which is how it is tested.  Shapes, n_pk, comm and the _partial_ form as above. */
+int32_t sylow_hip_bls_weighted_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                             const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, uint64_t* f_out, void* stream);
+int32_t sylow_hip_bls_batch_verify_weighted(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                            const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, void* comm,
+                                            uint64_t* gt_out, uint8_t* is_one, void* stream);
 
 /* ---- test hooks (stable enough for the repo's own tests; not part of the drop-in surface) ------------------------------------
  * Granger-Scott cyclotomic square (pairing.rs:309-350) and the raw Fp12 selector: 0..7 single-lane tower ops, 8 / 9 product /

@@ -580,6 +580,35 @@ pub fn aggregate_partial(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &Devi
     })?;
     Ok(f)
 }
+/// The SOUND one-boolean batch verification (small-exponent test): prod_i [e(sig_i, G2gen) e(-H(msg_i), pk_i)]^(w_i) == identity, with
+/// `weights` drawn by the caller AFTER the signatures are fixed (e.g. 128 random bits each).  True when every signature is valid; a batch
+/// with an invalid one passes with probability at most 2^-(bits of the weights).  `pk` one key per message or ONE key; `comm` as `all_valid`.
+pub fn batch_verify_weighted(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &DeviceG1, weights: &[Fp], comm: *mut c_void) -> Result<(GtOut, bool), HipError> {
+    assert!(sig.n == msgs.len() && weights.len() == msgs.len() && (pk.n == msgs.len() || pk.n == 1));
+    let (d_msgs, d_off) = messages(dev, msgs)?;
+    let dw = dev.upload_soa::<4>(&fp_words(weights))?;
+    let (gt, one) = (dev.alloc::<u64>(48)?, dev.alloc::<u8>(1)?);
+    // SAFETY: pk.n keys, n signatures, n + 1 offsets, 4 * n weight words; gt 48 words; one 1 byte; comm null or a live communicator.
+    device::check(unsafe {
+        ffi::sylow_hip_bls_batch_verify_weighted(pk.xy.as_ptr(), pk.inf.as_ptr(), pk.n, d_msgs.as_ptr(), d_off.as_ptr(), sig.xy.as_ptr(), sig.inf.as_ptr(),
+                                                 dw.as_ptr(), sig.n, comm, gt.as_mut_ptr(), one.as_mut_ptr(), dev.stream)
+    })?;
+    let words = dev.download_aos::<48>(&gt, 1)?;
+    Ok((gt_from_words(&words[0]), dev.download(&one)?[0] != 0))
+}
+/// This shard's raw Miller product of the weighted test, for a host-side gather (`fp12_product_final_exp` finishes it).
+pub fn weighted_partial(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &DeviceG1, weights: &[Fp]) -> Result<DeviceBuf<u64>, HipError> {
+    assert!(sig.n == msgs.len() && weights.len() == msgs.len() && (pk.n == msgs.len() || pk.n == 1));
+    let (d_msgs, d_off) = messages(dev, msgs)?;
+    let dw = dev.upload_soa::<4>(&fp_words(weights))?;
+    let f = dev.alloc::<u64>(48)?;
+    // SAFETY: as batch_verify_weighted; 48 words out.
+    device::check(unsafe {
+        ffi::sylow_hip_bls_weighted_partial_batch(pk.xy.as_ptr(), pk.inf.as_ptr(), pk.n, d_msgs.as_ptr(), d_off.as_ptr(), sig.xy.as_ptr(), sig.inf.as_ptr(),
+                                                  dw.as_ptr(), sig.n, f.as_mut_ptr(), dev.stream)
+    })?;
+    Ok(f)
+}
 /// AND of a device-resident flag vector (one rank; `all_valid` in lib.rs adds the reduce over ranks).
 pub fn flags_all(dev: &Device, flags: &DeviceBuf<u8>) -> Result<bool, HipError> {
     let out = dev.alloc::<i32>(1)?;

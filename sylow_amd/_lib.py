@@ -90,6 +90,8 @@ SIGNATURES = {
     "sylow_hip_g2_from_be_bytes_batch": [c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_bls_aggregate_partial_batch": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_u64p, c_vp],
     "sylow_hip_bls_aggregate_verify_batch": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_sz, c_vp, c_u64p, c_u8p, c_vp],
+    "sylow_hip_bls_weighted_partial_batch": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_sz, c_u64p, c_vp],
+    "sylow_hip_bls_batch_verify_weighted": [c_u64p, c_u8p, c_sz, c_u8p, c_u64p, c_u64p, c_u8p, c_u64p, c_sz, c_vp, c_u64p, c_u8p, c_vp],
     "sylow_hip_bls_verify_same_signer_batch": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_vp],
     "sylow_hip_g2_precompute_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_f29_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],

@@ -43,6 +43,11 @@ class GroupError(Exception):
     NOT_ON_CURVE, NOT_IN_SUBGROUP, CANNOT_HASH_TO_GROUP, DECODE_ERROR = "NotOnCurve", "NotInSubgroup", "CannotHashToGroup", "DecodeError"
 
 
+def _ints(arr) -> list:
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 4)
+    return [sum(int(arr[i, k]) << (64 * k) for k in range(4)) for i in range(arr.shape[0])]
+
+
 def fp(values) -> np.ndarray:
     """Fp::new on a list of Python ints (any 256-bit value; reduced on the device like the reference)."""
     vals = [int(v) for v in np.atleast_1d(np.asarray(values, dtype=object))]
@@ -377,6 +382,20 @@ class KeyTable:
 
     def verify(self, msgs, sig: G1Affine) -> np.ndarray:
         return engine().bls_verify_line_table(self.table, list(msgs), sig.xy, self.infinity, sig.infinity).astype(bool)
+
+
+def batch_verify(pubkey: G2Affine, msgs, sig: G1Affine, weight_bits: int = 128, seed=None) -> bool:
+    """Sound one-boolean batch verification (the small-exponent test): prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) == identity
+    with fresh `weight_bits`-bit weights from the operating system's generator (an int `seed` draws reproducible weights: tests
+    only).  True when every signature is valid; a batch with an invalid one passes with probability <= 2^-weight_bits."""
+    n = len(sig)
+    if seed is None:
+        import secrets
+        w = fp([secrets.randbits(weight_bits) | 1 for _ in range(n)])
+    else:
+        w = fp([((int(v) & ((1 << weight_bits) - 1)) | 1) for v in _ints(engine().xoshiro_fp_soa(seed, n).T)])
+    _, ok = engine().bls_batch_verify_weighted(pubkey.xy, list(msgs), sig.xy, w, pubkey.infinity, sig.infinity)
+    return ok
 
 
 class KeyPair:

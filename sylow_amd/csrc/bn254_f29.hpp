@@ -339,6 +339,10 @@ BN_DEV F29 f29_sqr(const F29& a) {
   r.v[8] = (i32)acc;
   return r;
 }
+// out-of-line squaring leaf (45 + 81 multiply-adds against the 81 + 81 of f29_mul_leaf(a, a)): the group law's squarings
+BN_NOINLINE F29 f29_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8) {
+  return f29_sqr(F29{{a0, a1, a2, a3, a4, a5, a6, a7, a8}});
+}
 // a^e for a 256-bit exponent given as 8 wave-uniform words: 4-bit fixed windows over the carry-free core (254 squarings of
 // 126 multiply-adds + at most 64 products + 14 for the table, against 381 saturated Montgomery products of 256 multiply-add
 // / add-carry pairs each).  0^e = 0, so inv(0) = 0 as in the reference (fp.rs:418-433, test fp.rs:1126-1132).

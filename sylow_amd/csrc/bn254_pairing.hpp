@@ -178,7 +178,7 @@ struct OpsF29 {
   static BN_DEV F sub(const F& a, const F& b) { return f29_norm(f29_sub(a, b)); }
   static BN_DEV F neg(const F& a) { return f29_norm(f29_neg(a)); }
   static BN_DEV F mul(const F& a, const F& b) { return f29_mul_leaf(W_ARGS(a), W_ARGS(b)); }
-  static BN_DEV F sqr(const F& a) { return f29_mul_leaf(W_ARGS(a), W_ARGS(a)); }
+  static BN_DEV F sqr(const F& a) { return f29_sqr_leaf(W_ARGS(a)); }                 // coordinates are N-class (|limbs| < 2^29): inside f29_sqr's column bound
   static BN_DEV F zero() { return F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
   // 2^261 mod p, the Montgomery one of the core
   static BN_DEV F one() { return F29{{0x157ccc21, 0x141c2758, 0x185230d3, 0x014c0419, 0x0aa36fb9, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836}}; }

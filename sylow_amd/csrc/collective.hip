@@ -84,8 +84,8 @@ int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf
 // Aggregate verification over a batch sharded across the ranks of `comm` (NULL = this process alone): every rank reduces its shard to
 // one raw Miller product (sylow_hip_bls_aggregate_partial_batch), the 384-byte partials are all-gathered, and each rank finishes
 // product + final exponentiation: one boolean on every rank.
-int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                             const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+static int32_t aggregate_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(gt_out || is_one);
   hipStream_t st = (hipStream_t)stream;
   int world = 1;
@@ -100,7 +100,8 @@ int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_
   int32_t rc = ws.acquire((size_t)(48 + 96 * (size_t)world) * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *mine = (u64*)ws.p, *all = mine + 48, *soa = all + 48 * (size_t)world;
-  rc = sylow_hip_bls_aggregate_partial_batch(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, n, mine, stream);
+  rc = weights ? sylow_hip_bls_weighted_partial_batch(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, weights, n, mine, stream)
+               : sylow_hip_bls_aggregate_partial_batch(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, n, mine, stream);
   if (rc == SYLOW_HIP_OK && comm) {
     ncclResult_t e = r->all_gather(mine, all, 48, ncclUint64, (ncclComm_t)comm, st);                 // 384 bytes per rank
     if (e != ncclSuccess) rc = nccl_fail(r, e, "ncclAllGather");
@@ -112,5 +113,15 @@ int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_
   const int32_t rc2 = ws.release();
   return rc != SYLOW_HIP_OK ? rc : rc2;
 }
-
+int32_t sylow_hip_bls_aggregate_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                             const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  return aggregate_verify(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, nullptr, n, comm, gt_out, is_one, stream);
+}
+// The small-exponent batch test: prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) == identity with caller-supplied weights
+// (sylow_hip_bls_weighted_partial_batch); same sharding as the unweighted aggregate.
+int32_t sylow_hip_bls_batch_verify_weighted(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                            const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, void* comm, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  ARGCHK(weights || !n);
+  return aggregate_verify(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, weights, n, comm, gt_out, is_one, stream);
+}
 }  // extern "C"

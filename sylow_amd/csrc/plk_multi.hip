@@ -708,22 +708,30 @@ int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint
 // G2gen half: prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen) -- n additions in G1 instead of n Miller loops -- and, for ONE key, the
 // other half too: prod_i e(-H(m_i), pk) = e(-sum_i H(m_i), pk).  The Gt value is the same group element either way, so gt_out and
 // the boolean are the reference's.  This entry leaves the shard's raw Miller product (for the cross-GPU aggregate, collective.hip).
-int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                              const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, uint64_t* f_out, void* stream) {
+// `weights` (NULL = none): w_i as Fp values [4][n]; the product becomes prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) = e(sum w_i sig_i, G2gen)
+// prod_i e(-w_i H(m_i), pk_i) -- the small-exponent batch test (SURVEY.md e1 "alternative aggregate check"): with weights drawn after
+// the signatures are fixed, a batch that contains an invalid signature passes with probability at most 2^-(bits of the weights).
+static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                 const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, uint64_t* f_out, void* stream) {
   ARGCHK(f_out && (n == 0 || (pk_xy && msgs && msg_offsets && sig_xy && (n_pk == 1 || n_pk == n))));
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) { plk::k_fp12_set_one<<<1, 64, 0, st>>>(f_out); LAUNCHED(); }
   // scratch (u64 words): H or -H [8][n], the summation tree [12][n], the two collapsed pairs G1 [8][2] / G2 [16][2], one product, flags
-  const size_t w_h = 8 * n, w_acc = 12 * n, w_flags = (n + 4 + 7) / 8;
+  const size_t w_h = 8 * n, w_acc = 12 * n, w_flags = (2 * n + 4 + 7) / 8, w_sw = weights ? 8 * n : 0;
   host::Lease ws;
-  int32_t rc = ws.acquire((w_h + w_acc + 16 + 32 + 48 + w_flags) * sizeof(u64), st);
+  int32_t rc = ws.acquire((w_h + w_acc + w_sw + 16 + 32 + 48 + w_flags) * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
-  u64 *hxy = (u64*)ws.p, *acc = hxy + w_h, *p2 = acc + w_acc, *q2 = p2 + 16, *prod_b = q2 + 32;
-  uint8_t *hinf = (uint8_t*)(prod_b + 48), *p2inf = hinf + n, *q2inf = p2inf + 2;
+  u64 *hxy = (u64*)ws.p, *acc = hxy + w_h, *sw = acc + w_acc, *p2 = sw + w_sw, *q2 = p2 + 16, *prod_b = q2 + 32;
+  uint8_t *hinf = (uint8_t*)(prod_b + 48), *p2inf = hinf + n, *q2inf = p2inf + 2, *swinf = q2inf + 2;
   const bool one_key = n_pk == 1 && n != 1;
   host::Lease wa, wb;
   u64 *pa = nullptr, *pb = nullptr;
   rc = g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
+  if (rc == SYLOW_HIP_OK && weights) {                      // H_i <- w_i H_i (in place), sig_i -> w_i sig_i (scratch)
+    rc = sylow_hip_g1_scalar_mul_batch(hxy, hinf, weights, hxy, hinf, n, stream);
+    if (rc == SYLOW_HIP_OK) rc = sylow_hip_g1_scalar_mul_batch(sig_xy, sig_inf, weights, sw, swinf, n, stream);
+    sig_xy = sw; sig_inf = swinf;
+  }
   if (rc == SYLOW_HIP_OK && !one_key) {
     // e(sum sig, G2gen) as a one-pair product (stride 1 arrays = column 0 of stride-1 views), prod_i e(-H_i, pk_i) over the batch
     rc = g1h::sum(sig_xy, sig_inf, n, acc, p2, p2inf, 1, 0, 0, stream);
@@ -750,6 +758,15 @@ int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8
   if (rc != SYLOW_HIP_OK) return rc;
   if (e != hipSuccess) return host::fail(e, "kernel launch");
   return r1 != SYLOW_HIP_OK ? r1 : r2 != SYLOW_HIP_OK ? r2 : r3;
+}
+int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                              const uint64_t* sig_xy, const uint8_t* sig_inf, size_t n, uint64_t* f_out, void* stream) {
+  return aggregate_partial(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, nullptr, n, f_out, stream);
+}
+int32_t sylow_hip_bls_weighted_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                             const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, uint64_t* f_out, void* stream) {
+  ARGCHK(weights || !n);
+  return aggregate_partial(pk_xy, pk_inf, n_pk, msgs, msg_offsets, sig_xy, sig_inf, weights, n, f_out, stream);
 }
 int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK((gt_out || is_one) && (parts || !k));

@@ -626,6 +626,19 @@ class Engine:
         self._call("sylow_hip_bls_aggregate_verify_batch", self._ptr(dpk), self._ptr(dpi), n_pk, dm.ptr, doff.ptr, self._ptr(dsig), self._ptr(dsi), n, comm, dgt.ptr, done.ptr)
         return self.from_device_soa(dgt)[0], int(done.download()[0])
 
+    def bls_batch_verify_weighted(self, pk_xy, msgs, sig_xy, weights, pk_inf=None, sig_inf=None, comm=None):
+        """The small-exponent batch test prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) == identity (sound one-boolean batch
+        verification); weights [n, 4] Fp values drawn by the caller after the signatures are fixed.  Returns (Gt words, bool)."""
+        pk_xy, sig_xy, weights = _aos(pk_xy, 16), _aos(sig_xy, 8), _aos(weights, 4)
+        n, n_pk = sig_xy.shape[0], pk_xy.shape[0]
+        assert len(msgs) == n and weights.shape[0] == n and n_pk in (1, n)
+        dpk, dsig, dw = self.to_device_soa(pk_xy, 16), self.to_device_soa(sig_xy, 8), self.to_device_soa(weights, 4)
+        dm, doff = self._msgs(msgs)
+        dpi, dsi = self._flags(pk_inf, n_pk), self._flags(sig_inf, n)
+        dgt, dis = self.empty((48, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_bls_batch_verify_weighted", dpk.ptr, self._ptr(dpi), n_pk, dm.ptr, doff.ptr, dsig.ptr, self._ptr(dsi), dw.ptr, n, comm, dgt.ptr, dis.ptr)
+        return self.from_device_soa(dgt), bool(dis.download()[0])
+
     def bls_verify_same_signer(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None):
         pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
         assert pk_xy.shape[0] == 1

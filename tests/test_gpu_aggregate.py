@@ -178,3 +178,42 @@ def test_aggregate_verify_equals_the_glued_product_of_the_reference_shape(engine
     assert engine.bls_aggregate_verify(pk[:1], msgs[:1], sig[1:2])[1] == 0
     gt0, ok0 = engine.bls_aggregate_verify(pk[:1] if same_signer else pk[:0], [], sig[:0])
     assert ok0 == 1 and np.array_equal(gt0, one)
+
+
+def test_weighted_batch_verification_vs_oracle(engine, coracle):
+    """sylow_hip_bls_batch_verify_weighted == the reference's glued_pairing over the 2n pairs (w_i sig_i, G2gen), (-w_i H(m_i), pk_i)
+    (oracle scalar multiplications + glued_pairing), for distinct keys and for one key; a valid batch gives the identity for any
+    weights; one wrong signature is caught; a zero weight removes that element from the test."""
+    n = 9
+    for same_signer in (False, True):
+        pk, msgs, sig = signed_batch(engine, n, same_signer=same_signer, seed=SEED + 95)
+        rng = Xoshiro(SEED + 96)
+        w = limbs([rng.next() | (rng.next() << 64) | 1 for _ in range(n)])
+        gt, ok = engine.bls_batch_verify_weighted(pk[:1] if same_signer else pk, msgs, sig, w)
+        assert ok
+        # the oracle's value of the same product
+        one4 = np.zeros((n, 4), dtype=np.uint64); one4[:, 0] = 1
+        z4 = np.zeros((n, 4), dtype=np.uint64)
+        h_xy, _ = coracle.g1_to_affine(coracle.hash_to_curve(msgs))
+        nh = h_xy.copy(); nh[:, 4:] = coracle.fp_op("neg", h_xy[:, 4:])
+        wsig, _ = coracle.g1_to_affine(coracle.g1_scalar_mul(np.concatenate([sig, one4], axis=1), w))
+        wnh, _ = coracle.g1_to_affine(coracle.g1_scalar_mul(np.concatenate([nh, one4], axis=1), w))
+        g2 = np.repeat(pack(G2, 16), n, 0)
+        p_all = np.concatenate([np.concatenate([wsig, one4], axis=1), np.concatenate([wnh, one4], axis=1)], axis=0)
+        pkn = np.repeat(pk, n, 0) if pk.shape[0] == 1 else pk
+        q_all = np.concatenate([np.concatenate([g2, one4, z4], axis=1), np.concatenate([pkn, one4, z4], axis=1)], axis=0)
+        exp = coracle.glued_pairing(p_all, q_all, [0, 2 * n])
+        assert np.array_equal(gt, exp)
+        # one signature replaced by another valid point: the weighted test fails, and passes again once that element's weight is zero
+        bad = sig.copy(); bad[4] = sig[5]
+        _, ok_bad = engine.bls_batch_verify_weighted(pk[:1] if same_signer else pk, msgs, bad, w)
+        assert not ok_bad
+        w0 = w.copy(); w0[4] = 0
+        _, ok_masked = engine.bls_batch_verify_weighted(pk[:1] if same_signer else pk, msgs, bad, w0)
+        assert ok_masked
+    # signatures permuted among the messages pass the UNWEIGHTED product (its documented blind spot) and fail the weighted one
+    pk, msgs, sig = signed_batch(engine, n, same_signer=True, seed=SEED + 97)
+    perm = sig[[1, 0] + list(range(2, n))]
+    _, ok_plain = engine.bls_aggregate_verify(pk[:1], msgs, perm)
+    _, ok_w = engine.bls_batch_verify_weighted(pk[:1], msgs, perm, limbs([3 + 2 * i for i in range(n)]))
+    assert ok_plain and not ok_w
