@@ -129,8 +129,10 @@ BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp
 // 1P..8P in the lane's scratch frame.  k*P as a group element is the same; only affine-normalised
 // results cross the boundary.  k is the Fp VALUE (< p, not reduced mod r: N4).  `nwin` < 64 walks only the low
 // 4 nwin bits (callers with a short fixed scalar, e.g. the 63-bit BN parameter of the subgroup check: 17 windows incl. the carry).
-template <class O, class DBL, class ADD>
-BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin = 64) {
+// `dbl` / `add` build the table (out-of-line group operations keep that straight-line part small); `dbl_loop` / `add_loop` run in
+// the window loop (inlined there, no point travels through the stack frame: measured -16 % on the lane-pair G2 product).
+template <class O, class DBL, class ADD, class DBLL, class ADDL>
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin, DBLL dbl_loop, ADDL add_loop) {
   typedef Proj<typename O::F> Pt;
   // signed recoding: k = sum d_i 16^i, d_i in [-8, 7]; k < 2^254 so the top digit cannot overflow
   signed char dig[64];
@@ -156,15 +158,19 @@ BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const
   for (int i = nwin - 1; i >= 0; --i) {
     if (i != nwin - 1) {
 #pragma unroll 1
-      for (int j = 0; j < 4; ++j) res = dbl(res);
+      for (int j = 0; j < 4; ++j) res = dbl_loop(res);
     }
     int d = dig[i];
     int m = d < 0 ? -d : d;
     Pt q = T[m];
     q.y = O::select(q.y, O::neg(q.y), d < 0);
-    res = add(res, q);
+    res = add_loop(res, q);
   }
   return res;
+}
+template <class O, class DBL, class ADD>
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin = 64) {
+  return scalar_mul_window<O>(p, k, dbl, add, nwin, dbl, add);
 }
 // G1 group law on the carry-free core (bn254_f29.hpp): the same complete formulas over F29 coordinates.  Class invariant:
 // every coordinate is N-class (limbs in [0, 2^29), top limb signed) -- additions are carry-normalised (34 instructions

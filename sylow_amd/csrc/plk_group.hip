@@ -31,7 +31,8 @@ BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
 BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
 BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64) {
   out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
-                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin);
+                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin,
+                                 [](const G2Q& a) { return proj_double<OpsW2>(a); }, [](const G2Q& a, const G2Q& b) { return proj_add<OpsW2>(a, b); });
 }
 // k * Q for Q in the r-torsion (G2 proper): the 4-dimensional GLS split of bn254_pairing.hpp (gls4_decompose) -- four 64-bit
 // sub-scalars against Q, psi Q, psi^2 Q, psi^3 Q on one shared window schedule: 17 windows of 4 doublings and 4 complete additions
@@ -77,7 +78,7 @@ BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
   for (int w = 16; w >= 0; --w) {
     if (w != 16) {
 #pragma unroll 1
-      for (int j = 0; j < 4; ++j) g2q_double(res, res);
+      for (int j = 0; j < 4; ++j) res = proj_double<OpsW2>(res);      // inlined in the loop: no point travels through the stack frame
     }
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
@@ -94,7 +95,7 @@ BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
         if (i == 3) flip = !flip;
       }
       q.y = OpsW2::select(q.y, OpsW2::neg(q.y), flip);
-      g2q_add(res, res, q);
+      res = proj_add<OpsW2>(res, q);
     }
   }
   out = res;
@@ -195,7 +196,7 @@ __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __rest
     q2.x = OpsW2::select(OpsW2::zero(), ex, nz);
     q2.y = OpsW2::select(OpsW2::one(), OpsW2::select(ey, OpsW2::neg(ey), d < 0), nz);
     q2.z = OpsW2::select(OpsW2::zero(), OpsW2::one(), nz);
-    g2q_add(res, res, q2);
+    res = proj_add<OpsW2>(res, q2);          // inlined in the loop: no point travels through the stack frame
   }
   store_g2q_affine(oxy, oinf, n, i, odd, res);
 }
