@@ -586,11 +586,20 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   const size_t per_job = (size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);
   size_t rounds = TBL_BYTES / (per_job * ROUND);
   if (rounds < 1) rounds = 1;
-  const size_t jb_max = n_jobs < rounds * ROUND ? n_jobs : rounds * ROUND;
-  const size_t w_raw = raw_miller ? 0 : 48 * jb_max * sizeof(u64);
+  size_t jb_max = n_jobs < rounds * ROUND ? n_jobs : rounds * ROUND;
+  size_t w_raw = raw_miller ? 0 : 48 * jb_max * sizeof(u64);
   host::Lease ws;
   int32_t rc = ws.acquire(per_job * jb_max + w_raw, st);
-  if (rc != SYLOW_HIP_OK) return rc;
+  if (rc != SYLOW_HIP_OK && jb_max > ROUND) {                  // a device short of memory: one round per batch
+    (void)hipGetLastError();
+    jb_max = ROUND;
+    w_raw = raw_miller ? 0 : 48 * jb_max * sizeof(u64);
+    rc = ws.acquire(per_job * jb_max + w_raw, st);
+  }
+  if (rc != SYLOW_HIP_OK) {                                    // no room for a table at all: the in-register schedule needs no workspace
+    (void)hipGetLastError();
+    plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, raw_miller); LAUNCHED();
+  }
   plk::u32x4* table = (plk::u32x4*)ws.p;
   u64* raw = (u64*)((uint8_t*)ws.p + per_job * jb_max);
   for (size_t job0 = 0; job0 < n_jobs; job0 += jb_max) {
