@@ -31,7 +31,8 @@ def _load_rccl():
     for name in names:
         try:
             lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
-        except OSError as e:
+            lib.ncclCommInitRank, lib.ncclGetUniqueId, lib.ncclCommCount, lib.ncclCommDestroy, lib.ncclGetErrorString   # AttributeError if absent
+        except (OSError, AttributeError) as e:
             last = e
             continue
         lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
@@ -98,8 +99,8 @@ class NativeComm:
         lib, err = None, None
         try:
             lib = _load_rccl()
-        except OSError as e:
-            err = str(e)
+        except Exception as e:  # noqa: BLE001 -- whatever went wrong here must not leave the other ranks waiting
+            err = f"{type(e).__name__}: {e}"
         if not all_fine(lib is not None):
             return None, err or "another rank could not load RCCL"
         # rank 0's unique id (+ a status byte) to everybody
@@ -119,8 +120,8 @@ class NativeComm:
         comm, err = None, None
         try:
             comm = cls._init(lib, uid, world, rank)
-        except RuntimeError as e:
-            err = str(e)
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
         if not all_fine(comm is not None and comm.ranks == world):
             if comm is not None:
                 comm.destroy()
