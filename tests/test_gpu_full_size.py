@@ -108,6 +108,17 @@ def test_c5_ecpairing_2_16_jobs(engine, k):
     _, is_one = engine.multi_pairing(p, q, np.arange(nj + 1, dtype=np.uint64) * np.uint64(k), skip_infinity=True, want_gt=False)
     expect = np.array([0 if j % 5 == 4 else 1 for j in range(nj)], dtype=np.uint8)
     assert np.array_equal(is_one, expect)
+    # the same jobs from BYTES (BASELINE.json configs[4] as the precompile sees it: EIP-197 192-byte pairs, decode + curve / subgroup
+    # checks + glued pairing), all 2^16 jobs in one call
+    dp, dq = engine.to_device_soa(p, 8), engine.to_device_soa(q, 16)
+    b1, b2 = engine.empty((n * 64,), np.uint8), engine.empty((n * 128,), np.uint8)
+    engine._call("sylow_hip_g1_to_be_bytes_batch", dp.ptr, None, b1.ptr, n)
+    engine._call("sylow_hip_g2_to_be_bytes_batch", dq.ptr, None, b2.ptr, n)
+    blob = np.concatenate([b1.download().reshape(n, 64), b2.download().reshape(n, 128)], axis=1).reshape(-1)
+    d_in, d_off = engine.to_device(blob), engine.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
+    d_res, d_st = engine.empty((nj,), np.uint8), engine.empty((nj,), np.uint8)
+    engine._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, n, d_res.ptr, d_st.ptr)
+    assert not d_st.download().any() and np.array_equal(d_res.download(), expect)
 
 
 def test_c2c_g2_scalar_mul_2_18_split_equals_generic(engine, coracle):
