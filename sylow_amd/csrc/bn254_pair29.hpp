@@ -23,6 +23,8 @@ namespace bn254 {
 namespace pl {
 
 struct W2 { F29 c; };
+BN_DEV const F29& f29_of(const W2& a) { return a.c; }      // for the window-table policies of bn254_pairing.hpp
+BN_DEV F29& f29_of(W2& a) { return a.c; }
 struct W6 { W2 c0, c1, c2; };
 struct W12 { W6 c0, c1; };
 

@@ -121,6 +121,38 @@ BN_NOINLINE G1P g1_add(G1P p, G1P q) { return proj_add<OpsFp>(p, q); }
 BN_NOINLINE void g2_double(G2P& r, const G2P& p) { r = proj_double<OpsFp2>(p); }
 BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp2>(p, q); }
 
+// ---- where a window table of 0P..8P lives (see G1TableGlobal below for why) ----
+typedef unsigned int g1tab_u32x4 __attribute__((ext_vector_type(4)));
+BN_DEV const F29& f29_of(const F29& a) { return a; }       // coordinate -> its 9 digits (the lane-pair W2 has its own overload)
+BN_DEV F29& f29_of(F29& a) { return a; }
+template <class PT>
+struct ProjTableLocal {
+  PT T[9];
+  BN_DEV void put(int m, const PT& v) { T[m] = v; }
+  BN_DEV PT get(int m) const { return T[m]; }
+};
+template <class PT>
+struct ProjTableGlobal {
+  typedef __attribute__((address_space(1))) g1tab_u32x4* gptr;
+  gptr base;                                           // this lane's 1 KB region
+  BN_DEV void put(int m, const PT& v) {
+    const F29 &x = f29_of(v.x), &y = f29_of(v.y), &z = f29_of(v.z);
+    const i32 w[28] = {x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8],
+                       y.v[0], y.v[1], y.v[2], y.v[3], y.v[4], y.v[5], y.v[6], y.v[7], y.v[8],
+                       z.v[0], z.v[1], z.v[2], z.v[3], z.v[4], z.v[5], z.v[6], z.v[7], z.v[8], 0};
+#pragma unroll
+    for (int c = 0; c < 7; ++c) base[7 * m + c] = g1tab_u32x4{(u32)w[4 * c], (u32)w[4 * c + 1], (u32)w[4 * c + 2], (u32)w[4 * c + 3]};
+  }
+  BN_DEV PT get(int m) const {
+    u32 w[28];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { const g1tab_u32x4 q = base[7 * m + c]; w[4 * c] = q.x; w[4 * c + 1] = q.y; w[4 * c + 2] = q.z; w[4 * c + 3] = q.w; }
+    PT r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { f29_of(r.x).v[i] = (i32)w[i]; f29_of(r.y).v[i] = (i32)w[9 + i]; f29_of(r.z).v[i] = (i32)w[18 + i]; }
+    return r;
+  }
+};
 // k*P for the batch kernels: signed fixed-window (w = 4) double-and-add with a WAVE-UNIFORM schedule.
 // The reference walks the 256 NAF digits of k (fp.rs:653-662) with a data-dependent add (group.rs:653-664); on a
 // 64-wide wavefront that makes every step pay for an addition (some lane always has a non-zero
@@ -131,8 +163,8 @@ BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp
 // 4 nwin bits (callers with a short fixed scalar, e.g. the 63-bit BN parameter of the subgroup check: 17 windows incl. the carry).
 // `dbl` / `add` build the table (out-of-line group operations keep that straight-line part small); `dbl_loop` / `add_loop` run in
 // the window loop (inlined there, no point travels through the stack frame: measured -16 % on the lane-pair G2 product).
-template <class O, class DBL, class ADD, class DBLL, class ADDL>
-BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin, DBLL dbl_loop, ADDL add_loop) {
+template <class O, class DBL, class ADD, class DBLL, class ADDL, class TAB>
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin, DBLL dbl_loop, ADDL add_loop, TAB& tab) {
   typedef Proj<typename O::F> Pt;
   // signed recoding: k = sum d_i 16^i, d_i in [-8, 7]; k < 2^254 so the top digit cannot overflow
   signed char dig[64];
@@ -143,16 +175,21 @@ BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const
     carry = d >= 8;
     dig[i] = (signed char)(d - (carry << 4));
   }
-  Pt T[9];
-  T[0] = proj_zero<O>();
-  T[1] = p;
-  T[2] = dbl(p);
-  T[3] = add(T[2], p);
-  T[4] = dbl(T[2]);
-  T[5] = add(T[4], p);
-  T[6] = dbl(T[3]);
-  T[7] = add(T[6], p);
-  T[8] = dbl(T[4]);
+  {
+    tab.put(0, proj_zero<O>());
+    tab.put(1, p);
+    const Pt t2 = dbl(p);
+    tab.put(2, t2);
+    const Pt t3 = add(t2, p);
+    tab.put(3, t3);
+    const Pt t4 = dbl(t2);
+    tab.put(4, t4);
+    tab.put(5, add(t4, p));
+    const Pt t6 = dbl(t3);
+    tab.put(6, t6);
+    tab.put(7, add(t6, p));
+    tab.put(8, dbl(t4));
+  }
   Pt res = proj_zero<O>();
 #pragma unroll 1
   for (int i = nwin - 1; i >= 0; --i) {
@@ -162,11 +199,16 @@ BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const
     }
     int d = dig[i];
     int m = d < 0 ? -d : d;
-    Pt q = T[m];
+    Pt q = tab.get(m);
     q.y = O::select(q.y, O::neg(q.y), d < 0);
     res = add_loop(res, q);
   }
   return res;
+}
+template <class O, class DBL, class ADD, class DBLL, class ADDL>
+BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin, DBLL dbl_loop, ADDL add_loop) {
+  ProjTableLocal<Proj<typename O::F>> tab;
+  return scalar_mul_window<O>(p, k, dbl, add, nwin, dbl_loop, add_loop, tab);
 }
 template <class O, class DBL, class ADD>
 BN_DEV Proj<typename O::F> scalar_mul_window(const Proj<typename O::F>& p, const u32 (&k)[8], DBL dbl, ADD add, int nwin = 64) {
@@ -351,7 +393,16 @@ BN_DEV void glv_digits(signed char (&dig)[33], const u32 (&m)[4]) {
 // at once -- every lane does 4 doublings and two complete additions per window (table entry 0 is the identity), 33 windows,
 // one table of 1P..8P; the phi-image of a table entry is a single multiplication of its X by beta.  The saturated projective
 // result is a representative of the same point (only affine-normalised values cross the boundary).
-BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
+// Where the window table of 0P..8P lives.  In the stack frame (G1TableLocal) a lookup is a dynamically indexed read of private memory:
+// the hardware interleaves a wavefront's private dwords lane by lane, so 64 lanes reading entry m of THEIR table touch up to nine different
+// 256-byte rows per instruction and fetch whole 64-byte sectors for 4 useful bytes each (rocprofv3: 59 KB of HBM traffic per G1 product,
+// 3.8 TB/s).  G1TableGlobal keeps each lane's table CONTIGUOUS in a leased global block (1 KB per lane: nine 112-byte entries of
+// 7 x 16 bytes), so a lookup is seven 16-byte loads from two or three sectors of the lane's own region.
+typedef ProjTableLocal<G1W> G1TableLocal;
+typedef ProjTableGlobal<G1W> G1TableGlobal;
+constexpr size_t G1_TABLE_BYTES_PER_LANE = 1024;
+template <class TAB>
+BN_DEV G1P g1_scalar_mul_t(G1P p, const u32 (&k)[8], TAB& tab) {
   u32 m1[4], m2[4];
   bool n1, n2;
   glv_decompose(m1, n1, m2, n2, k);
@@ -362,25 +413,29 @@ BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
   const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};
   auto dbl = [](const G1W& a) { return proj_double<OpsF29>(a); };
   auto add = [](const G1W& a, const G1W& b) { return proj_add<OpsF29>(a, b); };
-  G1W T[9];
-  T[0] = proj_zero<OpsF29>();
-  T[1] = G1W{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
   {
+    G1W t1{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
     // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0): the complete formulas keep Z = 0 only
     // for the canonical representative once two additions follow each other without a doubling in between
-    const bool pinf = OpsF29::is_zero(T[1].z);
-    T[1].x = OpsF29::select(T[1].x, OpsF29::zero(), pinf);
-    T[1].y = OpsF29::select(T[1].y, OpsF29::one(), pinf);
-    T[1].z = OpsF29::select(T[1].z, OpsF29::zero(), pinf);
+    const bool pinf = OpsF29::is_zero(t1.z);
+    t1.x = OpsF29::select(t1.x, OpsF29::zero(), pinf);
+    t1.y = OpsF29::select(t1.y, OpsF29::one(), pinf);
+    t1.z = OpsF29::select(t1.z, OpsF29::zero(), pinf);
+    if (n1) t1.y = OpsF29::neg(t1.y);                  // the table holds multiples of sign(k1) P
+    tab.put(0, proj_zero<OpsF29>());
+    tab.put(1, t1);
+    const G1W t2 = dbl(t1);
+    tab.put(2, t2);
+    const G1W t3 = add(t2, t1);
+    tab.put(3, t3);
+    const G1W t4 = dbl(t2);
+    tab.put(4, t4);
+    tab.put(5, add(t4, t1));
+    const G1W t6 = dbl(t3);
+    tab.put(6, t6);
+    tab.put(7, add(t6, t1));
+    tab.put(8, dbl(t4));
   }
-  if (n1) T[1].y = OpsF29::neg(T[1].y);                 // the table holds multiples of sign(k1) P
-  T[2] = dbl(T[1]);
-  T[3] = add(T[2], T[1]);
-  T[4] = dbl(T[2]);
-  T[5] = add(T[4], T[1]);
-  T[6] = dbl(T[3]);
-  T[7] = add(T[6], T[1]);
-  T[8] = dbl(T[4]);
   const bool flip2 = n1 != n2;                            // phi(table) carries sign(k1); k2 wants sign(k2)
   G1W res = proj_zero<OpsF29>();
 #pragma unroll 1
@@ -391,19 +446,28 @@ BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
     }
     {
       const int d = d1[i], m = d < 0 ? -d : d;
-      G1W q = T[m];
+      G1W q = tab.get(m);
       q.y = OpsF29::select(q.y, OpsF29::neg(q.y), d < 0);
       res = add(res, q);
     }
     {
       const int d = d2[i], m = d < 0 ? -d : d;
-      G1W q = T[m];
+      G1W q = tab.get(m);
       q.x = OpsF29::mul(q.x, beta);
       q.y = OpsF29::select(q.y, OpsF29::neg(q.y), (d < 0) != flip2);
       res = add(res, q);
     }
   }
   return G1P{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)};
+}
+BN_NOINLINE G1P g1_scalar_mul(G1P p, const u32 (&k)[8]) {
+  G1TableLocal tab;
+  return g1_scalar_mul_t(p, k, tab);
+}
+// `region`: this lane's G1_TABLE_BYTES_PER_LANE bytes of a leased global block
+BN_NOINLINE G1P g1_scalar_mul_ws(G1P p, const u32 (&k)[8], void* region) {
+  G1TableGlobal tab{(G1TableGlobal::gptr)region};
+  return g1_scalar_mul_t(p, k, tab);
 }
 BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
   out = scalar_mul_window<OpsFp2>(p, k, [](const G2P& a) { G2P r; g2_double(r, a); return r; },

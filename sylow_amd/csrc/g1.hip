@@ -2,14 +2,15 @@
 // hash-to-G1 (XMD-Keccak256 + SvdW), BLS signing, the G1 wire format and the EIP-196 ecAdd / ecMul byte adapters.
 #include "host.hpp"
 
-__global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+// tables: NULL = window tables in the stack frame, else a block of n * G1_TABLE_BYTES_PER_LANE bytes (lane i's table contiguous)
+__global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
   size_t i = TID;
   if (i >= n) return;
   bool inf = pinf && pinf[i];
   G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), inf ? fp_zero() : fp_one()};
   u32 k[8];
   load_scalar(k, ks, n, i);
-  G1P r = g1_scalar_mul(p, k);
+  G1P r = tables ? g1_scalar_mul_ws(p, k, tables + i * G1_TABLE_BYTES_PER_LANE) : g1_scalar_mul(p, k);
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, r);
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
@@ -240,14 +241,14 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, co
   store_fp(out, n, i, 4, fp_from_be48(em + 48));
 }
 // lib.rs:179-187
-__global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n) {
+__global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
   size_t i = TID;
   if (i >= n) return;
   G1P h;
   hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
   u32 k[8];
   load_scalar(k, sk, n, i);
-  G1P s = g1_scalar_mul(h, k);
+  G1P s = tables ? g1_scalar_mul_ws(h, k, tables + i * G1_TABLE_BYTES_PER_LANE) : g1_scalar_mul(h, k);
   Fp x, y; bool inf;
   g1_to_affine(x, y, inf, s);
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
@@ -377,10 +378,26 @@ int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc,
 }
 }  // namespace g1h
 
+// window tables of n lanes in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: ProjTableGlobal);
+// SYLOW_HIP_G1_TABLES=0 or a failed lease keeps them in the stack frame (NULL)
+static uint8_t* g1_window_tables(host::Lease& ws, size_t n, void* stream) {
+  static const bool global_tables = [] { const char* e = getenv("SYLOW_HIP_G1_TABLES"); return !(e && e[0] == '0'); }();
+  if (global_tables && ws.acquire(n * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
+  (void)hipGetLastError();
+  return nullptr;
+}
+
 extern "C" {
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  k_g1_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+  // window tables in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: G1TableGlobal); SYLOW_HIP_G1_TABLES=0 or a
+  // failed lease keeps them in the stack frame
+  host::Lease ws;
+  uint8_t* tables = g1_window_tables(ws, n, stream);
+  k_g1_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 int32_t sylow_hip_g1_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
@@ -438,7 +455,12 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
                                  uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
   ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
-  k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n); LAUNCHED();
+  host::Lease ws;
+  uint8_t* tables = g1_window_tables(ws, n, stream);
+  k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n, tables);
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
   ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;

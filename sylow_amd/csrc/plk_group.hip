@@ -29,10 +29,19 @@ struct OpsW2 {
 typedef Proj<W2> G2Q;
 BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
 BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
-BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64) {
-  out = scalar_mul_window<OpsW2>(p, k, [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; },
-                                 [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; }, nwin,
-                                 [](const G2Q& a) { return proj_double<OpsW2>(a); }, [](const G2Q& a, const G2Q& b) { return proj_add<OpsW2>(a, b); });
+// `region`: this lane's G1_TABLE_BYTES_PER_LANE bytes of a leased global block for the window table (NULL: the stack frame) -- a lane of
+// the pair holds its own coordinate of every entry, 27 words like a G1 point
+BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64, void* region = nullptr) {
+  auto dbl = [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; };
+  auto add = [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; };
+  auto dbl_loop = [](const G2Q& a) { return proj_double<OpsW2>(a); };
+  auto add_loop = [](const G2Q& a, const G2Q& b) { return proj_add<OpsW2>(a, b); };
+  if (region) {
+    ProjTableGlobal<G2Q> tab{(ProjTableGlobal<G2Q>::gptr)region};
+    out = scalar_mul_window<OpsW2>(p, k, dbl, add, nwin, dbl_loop, add_loop, tab);
+  } else {
+    out = scalar_mul_window<OpsW2>(p, k, dbl, add, nwin, dbl_loop, add_loop);
+  }
 }
 // k * Q for Q in the r-torsion (G2 proper): the 4-dimensional GLS split of bn254_pairing.hpp (gls4_decompose) -- four 64-bit
 // sub-scalars against Q, psi Q, psi^2 Q, psi^3 Q on one shared window schedule: 17 windows of 4 doublings and 4 complete additions
@@ -40,30 +49,31 @@ BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int n
 //   psi (X:Y:Z) = (e0 conj X : e1 conj Y : conj Z),  psi^2 = (beta X : -Y : Z) with beta in Fp,  psi^3 = (e3 conj X : -e1 conj Y : conj Z)
 // (conj is a field automorphism, so the maps act on projective coordinates; the minus signs fold into the digit's sign).
 // Only valid on the r-torsion: elsewhere psi is not multiplication by lam -- callers with arbitrary twist points use g2q_scalar_mul.
-BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
+template <class TAB>
+BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB& tab) {
   u32 m[4][2];
   bool neg[4];
   gls4_decompose(m, neg, k);
   signed char dig[4][17];
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) gls4_digits(dig[i], m[i]);
-  G2Q T[9];
-  T[0] = proj_zero<OpsW2>();
-  T[1] = p;
   {
+    G2Q t1 = p, t2, t3, t4, t;
     // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0) (see g1_scalar_mul)
-    const bool pinf = OpsW2::is_zero(T[1].z);
-    T[1].x = OpsW2::select(T[1].x, OpsW2::zero(), pinf);
-    T[1].y = OpsW2::select(T[1].y, OpsW2::one(), pinf);
-    T[1].z = OpsW2::select(T[1].z, OpsW2::zero(), pinf);
+    const bool pinf = OpsW2::is_zero(t1.z);
+    t1.x = OpsW2::select(t1.x, OpsW2::zero(), pinf);
+    t1.y = OpsW2::select(t1.y, OpsW2::one(), pinf);
+    t1.z = OpsW2::select(t1.z, OpsW2::zero(), pinf);
+    tab.put(0, proj_zero<OpsW2>());
+    tab.put(1, t1);
+    g2q_double(t2, t1); tab.put(2, t2);
+    g2q_add(t3, t2, t1); tab.put(3, t3);
+    g2q_double(t4, t2); tab.put(4, t4);
+    g2q_add(t, t4, t1); tab.put(5, t);
+    g2q_double(t, t3); tab.put(6, t);
+    g2q_add(t, t, t1); tab.put(7, t);
+    g2q_double(t, t4); tab.put(8, t);
   }
-  g2q_double(T[2], T[1]);
-  g2q_add(T[3], T[2], T[1]);
-  g2q_double(T[4], T[2]);
-  g2q_add(T[5], T[4], T[1]);
-  g2q_double(T[6], T[3]);
-  g2q_add(T[7], T[6], T[1]);
-  g2q_double(T[8], T[4]);
   // R-class lane-pair digits of the constants (value 2^261 mod p, balanced): e0 = xi^((p-1)/3), e1 = xi^((p-1)/2), e3 = e0 conj(e0 conj e0), beta = e0 conj e0
   const F29 e0a{{0x0c289449, 0x05f0a422, 0x0f85cd6c, 0x144ada8b, 0x053ef805, 0x01e2f615, 0x0b280ae6, 0x0c277edf, -774555}};
   const F29 e0b{{0x11142ef1, 0x0b31acc7, 0x1d5818bc, 0x180afc17, 0x1a63177e, 0x15765b3b, 0x118f742e, 0x063a509a, 0x00135e4e}};
@@ -83,7 +93,7 @@ BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
       const int d = dig[i][w], mag = d < 0 ? -d : d;
-      G2Q q = T[mag];
+      G2Q q = tab.get(mag);
       bool flip = (d < 0) != neg[i];
       if (i == 2) {
         q.x = w2_scale(q.x, beta);
@@ -99,6 +109,15 @@ BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8]) {
     }
   }
   out = res;
+}
+BN_NOINLINE void g2q_scalar_mul_gls(G2Q& out, const G2Q& p, const u32 (&k)[8], void* region = nullptr) {
+  if (region) {
+    ProjTableGlobal<G2Q> tab{(ProjTableGlobal<G2Q>::gptr)region};
+    g2q_scalar_mul_gls_t(out, p, k, tab);
+  } else {
+    ProjTableLocal<G2Q> tab;
+    g2q_scalar_mul_gls_t(out, p, k, tab);
+  }
 }
 // group.rs:475-495 (through the saturated core: one Fp2 inversion)
 BN_DEV void g2q_to_affine(S2& x, S2& y, bool& inf, const G2Q& p) {
@@ -201,25 +220,26 @@ __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __rest
   store_g2q_affine(oxy, oinf, n, i, odd, res);
 }
 
-__global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+// tables: NULL, or 2 n * G1_TABLE_BYTES_PER_LANE bytes (thread t's window table contiguous)
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   if (i >= n) return;
   u32 k[8];
   load_scalar(k, ks, n, i);
   G2Q r;
-  g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k);
+  g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k, 64, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
   store_g2q_affine(oxy, oinf, n, i, odd, r);
 }
 // the same for inputs in the r-torsion (G2Projective values of the reference are: G2Projective::new checks, g2.rs:460-525)
-__global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+__global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
   const size_t t = TID, i = t >> 1;
   const int odd = (int)(t & 1);
   if (i >= n) return;
   u32 k[8];
   load_scalar(k, ks, n, i);
   G2Q r;
-  g2q_scalar_mul_gls(r, load_g2q(pxy, pinf, n, i, odd), k);
+  g2q_scalar_mul_gls(r, load_g2q(pxy, pinf, n, i, odd), k, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
   store_g2q_affine(oxy, oinf, n, i, odd, r);
 }
 __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
@@ -519,16 +539,35 @@ int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8
 }
 }  // namespace plkh
 
+// window tables of `threads` lanes in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: ProjTableGlobal);
+// SYLOW_HIP_G1_TABLES=0 or a failed lease keeps them in the stack frame (NULL)
+static uint8_t* plkh_window_tables(host::Lease& ws, size_t threads, void* stream) {
+  static const bool global_tables = [] { const char* e = getenv("SYLOW_HIP_G1_TABLES"); return !(e && e[0] == '0'); }();
+  if (global_tables && ws.acquire(threads * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
+  (void)hipGetLastError();
+  return nullptr;
+}
+
 extern "C" {
 int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
-  plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+  host::Lease ws;
+  uint8_t* tables = plkh_window_tables(ws, 2 * n, stream);
+  plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
-  plk::k_g2_scalar_mul_gls<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n); LAUNCHED();
+  host::Lease ws;
+  uint8_t* tables = plkh_window_tables(ws, 2 * n, stream);
+  plk::k_g2_scalar_mul_gls<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 int32_t sylow_hip_g2_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
