@@ -14,7 +14,8 @@
 BN_DEV void load_plain2(Fp& e0, Fp& e1, const u64* __restrict__ base, size_t n, size_t i) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(base + (size_t)k * n + i);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(base + (size_t)k * n + i));
     e0.v[2 * k] = (u32)w.x; e0.v[2 * k + 1] = (u32)(w.x >> 32);
     e1.v[2 * k] = (u32)w.y; e1.v[2 * k + 1] = (u32)(w.y >> 32);
   }
@@ -22,10 +23,11 @@ BN_DEV void load_plain2(Fp& e0, Fp& e1, const u64* __restrict__ base, size_t n, 
 BN_DEV void store_plain2(u64* __restrict__ base, size_t n, size_t i, const Fp& e0, const Fp& e1) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    ulonglong2 w;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 w;
     w.x = (u64)e0.v[2 * k] | ((u64)e0.v[2 * k + 1] << 32);
     w.y = (u64)e1.v[2 * k] | ((u64)e1.v[2 * k + 1] << 32);
-    *reinterpret_cast<ulonglong2*>(base + (size_t)k * n + i) = w;
+    __builtin_nontemporal_store(w, reinterpret_cast<u64x2*>(base + (size_t)k * n + i));
   }
 }
 template <int OP, int FR>
