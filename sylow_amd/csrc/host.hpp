@@ -46,6 +46,7 @@ void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow
 namespace single {      // single.hip: one element per lane
 int32_t g2_scalar_mul(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t g2_normalize(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+int32_t g2_precompute(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream);
 int32_t g2_subgroup_check(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream);
 int32_t g2_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t g2_double(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);

@@ -338,6 +338,42 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
   g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
   emit();
 }
+// G2Affine::precompute for a batch (pairing.rs:676-708) on lane pairs: the 87 line triples of every point as canonical words, SoA
+// [87*24][n], triple t of point i at words 24t .. 24t+23 = (ell.0, ell.1, ell.2) as Fp2 each -- the reference's [Ell; 87] in its own
+// order and with its own (unscaled) values: the same walk as k_pair_lines without a G1 point
+__global__ void HEAVY_BOUNDS k_g2_precompute_pairs(const u64* qxy, u64* coeffs, size_t n) {
+  const size_t t = TID, i = t >> 1;
+  const int odd = (int)(t & 1);
+  if (i >= n) return;
+  const S2 qxs = load_s2(qxy, n, i, 0, odd), qys = load_s2(qxy, n, i, 8, odd);
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+  G2W r{qx, qy, w2_from_s2(s2_one())};
+  W2 l0, l1, l2;
+  int line = 0;
+  auto emit = [&]() {
+    store_s2(coeffs, n, i, 24 * line, odd, w2_to_s2(l0));
+    store_s2(coeffs, n, i, 24 * line + 8, odd, w2_to_s2(w2_reduce(l1)));      // D-class differences: carry-normalise before leaving the core
+    store_s2(coeffs, n, i, 24 * line + 16, odd, w2_to_s2(w2_reduce(l2)));
+    ++line;
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int it = 0; it < 64; ++it) {
+    g2_doubling_step29(r, l0, l1, l2);
+    emit();
+    if ((nz >> (63 - it)) & 1) {
+      g2_addition_step29(r, qx, ((ng >> (63 - it)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
+      emit();
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qxs, qys);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  emit();
+  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+  emit();
+}
 // PHASE B: the raw glued Miller value of every job of the batch.  kw = the wavefront's largest slot count; a lane pair with fewer
 // pairs reads the unit lines phase A wrote for its empty slots.  The accumulator is a LOCAL value (as a reference parameter it would
 // live in the caller's frame and every leaf call would force it back to memory), the table pointer is re-qualified as global memory
@@ -628,6 +664,11 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
   // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
   if (n_pairs <= 2 * n_jobs) { plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED(); }
   plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED();
+}
+int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
+  ARGCHK(q_xy && coeffs); if (!n) return SYLOW_HIP_OK;
+  if (host::single_lane()) return single::g2_precompute(q_xy, coeffs, n, stream);
+  plk::k_g2_precompute_pairs<<<GRID(2 * n)>>>(q_xy, coeffs, n); LAUNCHED();
 }
 int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
                                            uint64_t* f_out, void* stream) {

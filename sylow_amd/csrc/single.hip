@@ -630,10 +630,8 @@ int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* ou
   k_fp12_op<<<GRID(n)>>>(op, a, b, out, n); LAUNCHED();
 }
 }  // namespace single
-extern "C" {
-int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
-  ARGCHK(q_xy && coeffs); if (!n) return SYLOW_HIP_OK;
+namespace single {
+int32_t g2_precompute(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
   k_g2_precompute<<<GRID(n)>>>(q_xy, coeffs, n); LAUNCHED();
 }
-
-}  // extern "C"
+}  // namespace single

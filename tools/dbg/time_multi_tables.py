@@ -19,7 +19,7 @@ print("pairing n=%d: %.2f ms" % (n, timed(lambda: eng._call("sylow_hip_pairing_b
 print("miller  n=%d: %.2f ms" % (n, timed(lambda: eng._call("sylow_hip_miller_loop_batch", p.ptr, q.ptr, gt.ptr, n))))
 print("finexp  n=%d: %.2f ms" % (n, timed(lambda: eng._call("sylow_hip_final_exp_batch", gt.ptr, gt.ptr, n))))
 tab = eng.empty((87 * 24, n))
-print("g2_precompute (single-lane) n=%d: %.2f ms" % (n, timed(lambda: eng._call("sylow_hip_g2_precompute_batch", q.ptr, tab.ptr, n), 1)))
+print("g2_precompute n=%d: %.2f ms" % (n, timed(lambda: eng._call("sylow_hip_g2_precompute_batch", q.ptr, tab.ptr, n), 1)))
 f = eng.empty((48, n))
 for k in (1, 2, 4, 8):
     nj = n // k
