@@ -74,6 +74,8 @@ int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* o
 int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream);
 }  // namespace g1h
 namespace plkh {        // lane-pair units
+// plk_pairing.hip: one Fp12 operation on the lane-pair layer; op = 16 mul, 17 sqr, 18 sparse (b = 24 words), 19 cyclotomic sqr, 20..22 frobenius 1..3, 26 inv
+int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
 size_t line_table_bytes();                                                                             // plk_verify.hip
 size_t g2_comb_bytes();                                                                                // plk_group.hip

@@ -53,7 +53,14 @@ __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* o
   if (i >= n) return;
   S12 sx, sy, sr;
   load_s12(sx, a, n, i, odd);
-  if (b) load_s12(sy, b, n, i, odd);
+  if (b) {
+    if (op == OPW_SPARSE || op == OPW_SPARSE_UNIT) {      // three line coefficients: 24 words, whatever the width of the array behind them
+      sy.c0.c0 = load_s2(b, n, i, 0, odd); sy.c0.c1 = load_s2(b, n, i, 8, odd); sy.c0.c2 = load_s2(b, n, i, 16, odd);
+      sy.c1 = sy.c0;
+    } else {
+      load_s12(sy, b, n, i, odd);
+    }
+  }
   if (op >= OPW_S_MUL && op <= OPW_S_CYCSQR) {       // saturated lane-pair layer (bn254_pair.hpp)
     if (op == OPW_S_MUL) sr = s12_mul(sx, sy);
     else if (op == OPW_S_SQR) sr = s12_sqr(sx);
@@ -80,6 +87,13 @@ __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* o
   store_s12(out, n, i, odd, sr);
 }
 }  // namespace plk
+
+// Fp12 on the lane-pair layer for the public tower entry points (single.hip keeps the one-element-per-lane twins)
+namespace plkh {
+int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  plk::k_w12_op<<<GRID(2 * n)>>>(op, a, b, out, n); LAUNCHED();
+}
+}  // namespace plkh
 
 extern "C" {
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {

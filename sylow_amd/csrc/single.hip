@@ -601,24 +601,35 @@ int32_t sylow_hip_fp6_frobenius_batch(const uint64_t* a, uint64_t exponent, uint
   ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp6_op<<<GRID(n)>>>(OPX_FROB6 + (int)(exponent % 6), a, nullptr, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_MUL, a, b, out, n); LAUNCHED();
+  ARGCHK(a && b && out); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(16, a, b, out, n, stream);
+  k_fp12_op<<<GRID(n)>>>(OP12_MUL, a, b, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_SQR, a, nullptr, out, n); LAUNCHED();
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(17, a, nullptr, out, n, stream);
+  k_fp12_op<<<GRID(n)>>>(OP12_SQR, a, nullptr, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_inv_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_INV, a, nullptr, out, n); LAUNCHED();
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(26, a, nullptr, out, n, stream);
+  k_fp12_op<<<GRID(n)>>>(OP12_INV, a, nullptr, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_frobenius_batch(const uint64_t* a, int32_t exponent, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && out && exponent >= 1 && exponent <= 3); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(20 + exponent - 1, a, nullptr, out, n, stream);
   k_fp12_op<<<GRID(n)>>>(OP12_FROB1 + exponent - 1, a, nullptr, out, n); LAUNCHED();
 }
 int32_t sylow_hip_fp12_sparse_mul_batch(const uint64_t* f, const uint64_t* ell, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(f && ell && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_SPARSE, f, ell, out, n); LAUNCHED();
+  ARGCHK(f && ell && out); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(18, f, ell, out, n, stream);
+  k_fp12_op<<<GRID(n)>>>(OP12_SPARSE, f, ell, out, n); LAUNCHED();
 }
 // test hook (not in the public header's stable surface): Granger-Scott cyclotomic square
 int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream) {
-  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK; k_fp12_op<<<GRID(n)>>>(OP12_CYCSQR, a, nullptr, out, n); LAUNCHED();
+  ARGCHK(a && out); if (!n) return SYLOW_HIP_OK;
+  if (!host::single_lane()) return plkh::fp12_op(19, a, nullptr, out, n, stream);
+  k_fp12_op<<<GRID(n)>>>(OP12_CYCSQR, a, nullptr, out, n); LAUNCHED();
 }
 
 // test hook: raw k_fp12_op selector (8: product on the carry-free core, 9: cyclotomic square on it,
