@@ -127,9 +127,10 @@ BN_NOINLINE void glued_miller_chunks(W12& acc, const u64* pxy, const uint8_t* pi
 // is that small: one chunk, so no running product, and the two pair states are plain values -- the structure of the fused
 // verifier (plk_verify.hip) with both G2 points general.  Slot A is pair `lo`, slot B pair `lo + 1`; a missing or skipped pair is
 // a dead slot (generator point, unit line), exactly like the generic schedule, so the value is the same bit for bit.
-BN_NOINLINE void glued_miller_upto2(W12& f, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
+BN_NOINLINE void glued_miller_upto2(W12& fout, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                size_t lo, size_t hi, size_t n_pairs, int skip_infinity, int odd) {
   const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  W12 f;                                             // a LOCAL accumulator (a reference parameter would be re-read from memory around every leaf call)
   {
     S12 one = s12_one();
     w12_from_s12(f, one);
@@ -155,7 +156,7 @@ BN_NOINLINE void glued_miller_upto2(W12& f, const u64* pxy, const uint8_t* pinf,
   setup(B, lo + 1);
   // a skipped first pair leaves slot A dead and B live: both slots are walked whenever any lane has a live B
   const bool anyA = wave_max(A.live ? 1 : 0) != 0, anyB = wave_max(B.live ? 1 : 0) != 0;
-  if (!anyA && !anyB) return;
+  if (!anyA && !anyB) { fout = f; return; }
   W2 l0, l1, l2;
   auto apply = [&](const PairStateW& s) {
     const bool lv = s.live;
@@ -189,6 +190,7 @@ BN_NOINLINE void glued_miller_upto2(W12& f, const u64* pxy, const uint8_t* pinf,
     if (anyA) frob(A, step);
     if (anyB) frob(B, step);
   }
+  fout = f;
 }
 
 // The same value pair by pair: prod_i miller(P_i, Q_i) with every factor from the single-pair loop (miller_loop29g: invariants
