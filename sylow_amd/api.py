@@ -134,6 +134,10 @@ class G1Affine(_Points):
         xy, inf = engine().g1_add(self.xy, other.xy, self.infinity, other.infinity)
         return G1Affine(xy, inf)
 
+    def __sub__(self, other):                      # Sub (group.rs:614-624): self + (-other)
+        xy, inf = engine().g1_sub(self.xy, other.xy, self.infinity, other.infinity)
+        return G1Affine(xy, inf)
+
     def __neg__(self):
         y = engine().fp_neg(self.xy[:, 4:])
         return G1Affine(np.concatenate([self.xy[:, :4], y], axis=1), self.infinity)
@@ -200,6 +204,10 @@ class G2Affine(_Points):
         xy, inf = engine().g2_add(self.xy, other.xy, self.infinity, other.infinity)
         return G2Affine(xy, inf)._checked(self.in_subgroup and other.in_subgroup)
 
+    def __sub__(self, other):                      # Sub (group.rs:614-624)
+        xy, inf = engine().g2_sub(self.xy, other.xy, self.infinity, other.infinity)
+        return G2Affine(xy, inf)._checked(self.in_subgroup and other.in_subgroup)
+
     def double(self):
         xy, inf = engine().g2_double(self.xy, self.infinity)
         return G2Affine(xy, inf)._checked(self.in_subgroup)
@@ -228,6 +236,50 @@ class G2Affine(_Points):
 
 
 G2Projective = G2Affine
+
+
+
+class _Ext:
+    """Batch of extension-field elements, canonical limbs [n, 4 * degree] in the reference's nesting order; the operators of
+    FieldExtension<D, N, F> (extensions.rs:41-238) run on the GPU."""
+    DEGREE = 0
+
+    def __init__(self, v):
+        self.v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4 * self.DEGREE)
+
+    def __len__(self): return self.v.shape[0]
+    def __eq__(self, o): return (self.v == o.v).all(axis=1)
+    def __add__(self, o): return type(self)(engine().fext_op("add", self.v, o.v))
+    def __sub__(self, o): return type(self)(engine().fext_op("sub", self.v, o.v))
+    def __neg__(self): return type(self)(engine().fext_op("neg", self.v))
+    def scale(self, k): return type(self)(engine().fext_op("scale", self.v, np.ascontiguousarray(k, dtype=np.uint64).reshape(-1, 4)))
+
+
+class Fp2(_Ext):
+    DEGREE = 2
+    def __mul__(self, o): return Fp2(engine().fp2_mul(self.v, o.v))
+    def square(self): return Fp2(engine().fp2_sqr(self.v))
+    def inv(self): return Fp2(engine().fp2_inv(self.v))
+    def residue_mul(self): return Fp2(engine().fp2_residue_mul(self.v))          # x (9 + u), fp2.rs:99-107
+    def frobenius(self, exponent: int): return Fp2(engine().fp2_frobenius(self.v, exponent))   # fp2.rs:119-133
+
+
+class Fp6(_Ext):
+    DEGREE = 6
+    def __mul__(self, o): return Fp6(engine().fp6_mul(self.v, o.v))
+    def square(self): return Fp6(engine().fp6_sqr(self.v))                       # fp6.rs:213-236
+    def inv(self): return Fp6(engine().fp6_inv(self.v))
+    def residue_mul(self): return Fp6(engine().fp6_residue_mul(self.v))          # x v, fp6.rs:189-192
+    def frobenius(self, exponent: int): return Fp6(engine().fp6_frobenius(self.v, exponent))   # fp6.rs:205-211
+
+
+class Fp12(_Ext):
+    DEGREE = 12
+    def __mul__(self, o): return Fp12(engine().fp12_mul(self.v, o.v))
+    def square(self): return Fp12(engine().fp12_sqr(self.v))
+    def inv(self): return Fp12(engine().fp12_inv(self.v))
+    def frobenius(self, exponent: int): return Fp12(engine().fp12_frobenius(self.v, exponent))  # exponent in {1, 2, 3}
+    def sparse_mul(self, ell): return Fp12(engine().fp12_sparse_mul(self.v, ell))               # fp12.rs:426-503, ell = [n, 24]
 
 
 class Gt:

@@ -194,3 +194,25 @@ def test_aggregate_verify_api(api):
     sig1 = api.sign(np.repeat(one.secret_key, 12, 0), msgs)
     assert api.aggregate_verify(one.public_key, msgs, sig1) is True
     assert api.aggregate_verify(one.public_key, msgs, sig) is False
+
+
+def test_mirror_sub_and_tower_classes(api, coracle):
+    """Sub for points (group.rs:614-624) and the Fp2 / Fp6 / Fp12 value classes of the mirror: operators and the small items
+    (residue_mul, frobenius, square) against the oracle."""
+    from helpers import rand_fp_array
+    rng = Xoshiro(SEED + 310)
+    p, q = api.G1Projective.rand(6, seed=21), api.G1Projective.rand(6, seed=22)
+    assert ((p - q) + q == p).all() and (p - p).is_zero().all()
+    a, b = api.G2Projective.rand(4, seed=23), api.G2Projective.rand(4, seed=24)
+    assert ((a - b) + b == a).all() and (a - a).is_zero().all()
+    x2, y2 = api.Fp2(rand_fp_array(rng, 8, 2)), api.Fp2(rand_fp_array(rng, 8, 2))
+    assert np.array_equal((x2 * y2).v, coracle.fp2_op("mul", x2.v, y2.v)) and np.array_equal((x2 - y2).v, coracle.fp2_op("sub", x2.v, y2.v))
+    assert np.array_equal(x2.residue_mul().v, coracle.fp2_op("mul_xi", x2.v)) and np.array_equal(x2.frobenius(3).v, coracle.fp2_frobenius(x2.v, 3))
+    assert ((x2 * x2.inv()).v[:, 0] == 1).all()
+    x6 = api.Fp6(rand_fp_array(rng, 8, 6))
+    assert np.array_equal(x6.square().v, coracle.fp6_op("sqr", x6.v)) and np.array_equal(x6.residue_mul().v, coracle.fp6_residue_mul(x6.v))
+    assert np.array_equal(x6.frobenius(5).v, coracle.fp6_frobenius(x6.v, 5)) and np.array_equal((-x6).v, coracle.fp6_op("neg", x6.v))
+    x12, y12 = api.Fp12(rand_fp_array(rng, 4, 12)), api.Fp12(rand_fp_array(rng, 4, 12))
+    assert np.array_equal((x12 * y12).v, coracle.fp12_op("mul", x12.v, y12.v)) and np.array_equal(x12.square().v, coracle.fp12_op("sqr", x12.v))
+    assert np.array_equal(x12.frobenius(2).v, coracle.fp12_op("frobenius", x12.v, arg=2))
+    assert np.array_equal(((x12 + y12) - y12).v, x12.v)
