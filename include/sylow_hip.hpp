@@ -235,4 +235,37 @@ inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const st
   return ok;
 }
 
+// "are ALL of them valid?" as ONE boolean: the glued product of examples/verify_multiple_messages_same_signer.rs:41-60 (weights == nullptr)
+// or the sound small-exponent test with the caller's random weights (sylow_hip_bls_batch_verify_weighted).  One key per message, or one key.
+inline bool verify_all(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig,
+                       const std::vector<Fp>* weights = nullptr, Gt* product = nullptr) {
+  if (sig.size() != msgs.size() || (pubkey.size() != msgs.size() && pubkey.size() != 1)) throw Error("verify_all: length mismatch");
+  if (weights && weights->size() != msgs.size()) throw Error("verify_all: one weight per signature");
+  Messages m(msgs);
+  auto dpk = to_device_soa(pubkey); auto dsig = to_device_soa(sig);
+  DeviceBuffer dgt(sizeof(Gt) + 8), done(8);
+  if (weights) {
+    auto dw = to_device_soa(*weights);
+    check(sylow_hip_bls_batch_verify_weighted(dpk.as<uint64_t>(), nullptr, pubkey.size(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), nullptr,
+                                              dw.as<uint64_t>(), m.n, nullptr, dgt.as<uint64_t>(), done.as<uint8_t>(), nullptr), "sylow_hip_bls_batch_verify_weighted");
+  } else {
+    check(sylow_hip_bls_aggregate_verify_batch(dpk.as<uint64_t>(), nullptr, pubkey.size(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), dsig.as<uint64_t>(), nullptr,
+                                               m.n, nullptr, dgt.as<uint64_t>(), done.as<uint8_t>(), nullptr), "sylow_hip_bls_aggregate_verify_batch");
+  }
+  uint8_t one = 0;
+  check(sylow_hip_memcpy_d2h(&one, done.as<void>(), 1, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync");
+  if (product) *product = from_device_soa<Gt>(dgt, 1)[0];
+  return one != 0;
+}
+// Sub for &G1Projective (group.rs:614-624), elementwise on affine inputs
+inline std::vector<G1Affine> sub(const std::vector<G1Affine>& a, const std::vector<G1Affine>& b, std::vector<uint8_t>* inf_out = nullptr) {
+  if (a.size() != b.size()) throw Error("G1 - G1: length mismatch");
+  const size_t n = a.size();
+  auto da = to_device_soa(a); auto db = to_device_soa(b);
+  DeviceBuffer dout(n * sizeof(G1Affine) + 8), dinf(n + 8);
+  check(sylow_hip_g1_sub_batch(da.as<uint64_t>(), nullptr, db.as<uint64_t>(), nullptr, dout.as<uint64_t>(), dinf.as<uint8_t>(), n, nullptr), "sylow_hip_g1_sub_batch");
+  fetch_flags(inf_out, dinf, n);
+  return from_device_soa<G1Affine>(dout, n);
+}
+
 }  // namespace sylow

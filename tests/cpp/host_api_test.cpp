@@ -71,6 +71,18 @@ int main() {
     std::vector<uint8_t> gi = {1, 0}, qi = {0, 0};
     Gt skipped = glued_pairing({g1_generator(), g1_generator()}, {g2_generator(), g2_generator()}, &gi, &qi, true);
     std::printf("GLUEDSKIP %d\n", skipped == gt[0] ? 1 : 0);
+    // one boolean for a batch: unweighted product and the weighted (sound) test; P - P is the identity
+    std::vector<Fp> sk3 = {sk[0], Fp{{7, 0, 0, 0}}, Fp{{11, 0, 0, 0}}};
+    std::vector<std::vector<uint8_t>> m3 = {{1}, {2, 2}, {3, 3, 3}};
+    auto sig3 = sign(sk3, m3);
+    auto pk3 = mul(std::vector<G2Affine>(3, g2_generator()), sk3, nullptr, nullptr, true);
+    std::vector<Fp> w3 = {Fp{{0x9e3779b97f4a7c15ull, 1, 0, 0}}, Fp{{0xbf58476d1ce4e5b9ull, 2, 0, 0}}, Fp{{0x94d049bb133111ebull, 3, 0, 0}}};
+    const bool all_plain = verify_all(pk3, m3, sig3), all_weighted = verify_all(pk3, m3, sig3, &w3);
+    std::swap(sig3[0], sig3[1]);
+    const bool bad_weighted = verify_all(pk3, m3, sig3, &w3);
+    std::vector<uint8_t> dinf;
+    auto diff = sub({g1_generator()}, {g1_generator()}, &dinf);
+    std::printf("VERIFYALL %d%d%d SUB %d\n", all_plain ? 1 : 0, all_weighted ? 1 : 0, bad_weighted ? 1 : 0, dinf[0]);
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());

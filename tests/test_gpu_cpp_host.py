@@ -41,6 +41,8 @@ def test_cpp_host_layer_runs(kats, coracle):
     # one-sided identity = false, and the bare (0, 1) coordinates without the flag do not verify (pairing.rs:876-886)
     assert lines["IDENT"] == "10 10 11 01 01"
     assert lines["GLUEDSKIP"] == "1"
+    # one boolean per batch: the unweighted product passes, the weighted test passes and catches two swapped signatures; P - P = identity
+    assert lines["VERIFYALL"] == "110 SUB 1"
     sk0 = np.array([[5, 0, 0, 0]], dtype=np.uint64)
     sig_ref, _ = coracle.g1_to_affine(coracle.sign(sk0, [bytes([0, 0, 0, 20])]))
     want = [sum(int(sig_ref[0, 4 * i + k]) << (64 * k) for k in range(4)) for i in range(2)]
