@@ -199,6 +199,33 @@ def test_glued_miller_loop_raw_value(engine, coracle):
     assert np.array_equal(engine.final_exp(f), coracle.glued_pairing(proj1(p), proj2(q), off))
 
 
+def test_ragged_jobs_against_per_pair_miller_values(engine):
+    """A differential check that needs no CPU: 4096 jobs of 0..9 pairs (empty jobs, one-pair jobs and jobs longer than the table's
+    slots in the same wavefronts).  The raw glued value of a job must equal the Fp12 product of its pairs' single-pair Miller values
+    (miller_loop_batch: another kernel, no shared squarings, no tables), and the glued pairing its final exponentiation."""
+    g = np.random.default_rng(SEED % (1 << 31))
+    nj = 4096
+    sizes = g.integers(0, 10, size=nj)
+    sizes[:64] = g.permutation(np.repeat(np.arange(8), 8))            # one wavefront with every size
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(off[-1])
+    rng = Xoshiro(SEED + 77)
+    ka, kb = limbs([rng.fp() for _ in range(n)]), limbs([rng.fp() for _ in range(n)])
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), ka)
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), kb, subgroup=True)
+    f = engine.miller_loop(p, q)                                       # [n, 48]
+    one = np.zeros((nj, 48), dtype=np.uint64); one[:, 0] = 1
+    acc = one.copy()
+    for s_ in range(int(sizes.max())):
+        live = np.nonzero(sizes > s_)[0]
+        acc[live] = engine.fp12_mul(acc[live], f[off[live].astype(np.int64) + s_])
+    raw = engine.glued_miller_loop(p, q, off)
+    assert np.array_equal(raw, acc)
+    gt, is_one = engine.multi_pairing(p, q, off, skip_infinity=True)
+    assert np.array_equal(gt, engine.final_exp(acc))
+    assert np.array_equal(is_one.astype(bool), (sizes == 0))           # only the empty product is the identity here
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_both_multi_pair_routes_pass_the_same_tests(mode):
     """SYLOW_HIP_MULTI_TABLES=0 forces the in-register shared-squaring schedule for every job size, =1 the lines-to-HBM + table-driven
