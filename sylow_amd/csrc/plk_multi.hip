@@ -253,7 +253,7 @@ __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf
 }
 
 // ------------------------------------------------------------------ glued pairings through line tables in HBM ---------------
-// Jobs of three or more pairs.  Sharing the squarings of one accumulator among k pairs needs k working G2 points next to the
+// Jobs of two or more pairs (on average over the batch).  Sharing the squarings of one accumulator among k pairs needs k working G2 points next to the
 // accumulator, which 256 registers do not hold (the in-register schedule above parks them in the stack frame and runs no faster than
 // k separate loops).  So the work is cut where the data is smallest: PHASE A gives every (job, slot) its own lane pair, walks that
 // pair's G2 point through the 87 steps with NO accumulator alive, and streams the lines -- already scaled by P: (l0, l1 P.y, l2 P.x),
