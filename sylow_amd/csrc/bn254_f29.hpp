@@ -350,24 +350,33 @@ BN_NOINLINE Fp fp_pow_words(Fp a, u32 e0, u32 e1, u32 e2, u32 e3, u32 e4, u32 e5
   const u32 e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
   const F29 af = f29_from_fp(a);
   const F29 x = f29_reduce_from([&](int i) { return (i64)af.v[i]; });
+  // The window table lives in the lane's scratch frame (dynamic index).  Each entry is fetched ONCE into registers, before
+  // the last squaring of its window so that the squaring covers the latency, and pinned there: left to itself the compiler
+  // re-reads limbs at their points of use inside the product (~36 scratch loads per product, each one a full wait at two waves
+  // per SIMD -- the square root was scratch-latency-bound, profiles/r03_configs hash_to_g1 before / after).
   F29 tab[16];
-  tab[1] = x;
-#pragma unroll 1
-  for (int i = 2; i < 16; ++i) tab[i] = f29_mul(tab[i - 1], x);
+  tab[0] = x; tab[1] = x;
   F29 r = x;
+#pragma unroll 1
+  for (int i = 2; i < 16; ++i) { r = f29_mul(r, x); tab[i] = r; }
+  r = x;
   bool started = false;
 #pragma unroll 1
   for (int w = 7; w >= 0; --w) {
     const u32 word = e[w];
 #pragma unroll 1
     for (int nib = 7; nib >= 0; --nib) {
+      const u32 idx = (word >> (4 * nib)) & 15u;
       if (started) {
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) r = f29_sqr(r);
-      }
-      const u32 idx = (word >> (4 * nib)) & 15u;
-      if (idx) {
-        r = started ? f29_mul(r, tab[idx]) : tab[idx];
+        for (int j = 0; j < 3; ++j) r = f29_sqr(r);
+        F29 t = tab[idx];
+        r = f29_sqr(r);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) BN_CHAIN_NV(t.v[i]);
+        if (idx) r = f29_mul(r, t);
+      } else if (idx) {
+        r = tab[idx];
         started = true;
       }
     }
