@@ -157,48 +157,164 @@ __device__ inline Fp fp_from_be48(const uint8_t* b) {
 }
 
 // is_square (fp.rs:625-631: a^((p-1)/2) in {0, 1}) as a Jacobi symbol: the binary algorithm with a FIXED trip count and no
-// lane-dependent branches (every lane of the wavefront runs the same steps: at most 508, in blocks of 4 until all lanes are done), ~60 cheap instructions per step against
+// lane-dependent branches (every lane of the wavefront runs the same steps: at most 508, in blocks of 4 until all lanes are done), ~7 cheap instructions per live limb and step against
 // the ~320-product power.  Invariant: n odd, 0 <= a; each step either halves an even a (sign flips when n = 3, 5 mod 8) or,
 // for odd a, orders the pair (quadratic reciprocity: flip when both are 3 mod 4), subtracts and halves.  bits(a) + bits(n)
 // drops every step, so 2 * 254 steps always reach a = 0 with n = gcd.  The Montgomery factor R = (2^128)^2 is a square, so
 // the symbol of the Montgomery representative is the symbol of the value.  (0 / p) = 0 counts as a square, like the reference.
-BN_NOINLINE bool fp_is_square(Fp x) {
-  u32 a[8], n[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = x.v[i];
-  u32 t = 0;
-#pragma unroll 1
-  for (int blk = 0; blk < 508 / 4; ++blk) {
-    // every lane whose a has reached 0 only idles from here on (t and n are final): leave as soon as the whole wavefront is there
-    // (random inputs need ~360 steps, the slowest of 64 lanes ~380; the 508 bound is for the worst case)
-    if (!__any((a[0] | a[1] | a[2] | a[3] | a[4] | a[5] | a[6] | a[7]) != 0u)) break;
+// d = x - y on L limbs, returns the borrow as a mask (all ones when x < y): one v_sub_co / v_subb_co chain (written from 64-bit
+// arithmetic the compiler emits four instructions per limb, one of them a quarter-rate 64-bit add)
+template <int L> BN_DEV u32 sub_borrow(u32 (&d)[L], const u32 (&x)[8], const u32 (&y)[8]);
+template <> BN_DEV u32 sub_borrow<1>(u32 (&d)[1], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %2, %3\n\t"
+      "v_cndmask_b32 %1, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(b)
+      : "v"(x[0]), "v"(y[0])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<2>(u32 (&d)[2], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<3>(u32 (&d)[3], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %4, %7\n\t"
+      "v_subb_co_u32 %1, vcc, %5, %8, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %6, %9, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(y[0]), "v"(y[1]), "v"(y[2])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<4>(u32 (&d)[4], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %5, %9\n\t"
+      "v_subb_co_u32 %1, vcc, %6, %10, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %7, %11, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %8, %12, vcc\n\t"
+      "v_cndmask_b32 %4, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<5>(u32 (&d)[5], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %6, %11\n\t"
+      "v_subb_co_u32 %1, vcc, %7, %12, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %8, %13, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %9, %14, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %10, %15, vcc\n\t"
+      "v_cndmask_b32 %5, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<6>(u32 (&d)[6], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %7, %13\n\t"
+      "v_subb_co_u32 %1, vcc, %8, %14, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %9, %15, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %10, %16, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %11, %17, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %12, %18, vcc\n\t"
+      "v_cndmask_b32 %6, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<7>(u32 (&d)[7], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %8, %15\n\t"
+      "v_subb_co_u32 %1, vcc, %9, %16, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %10, %17, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %11, %18, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %12, %19, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %13, %20, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %14, %21, vcc\n\t"
+      "v_cndmask_b32 %7, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6])
+      : "vcc");
+  return b;
+}
+template <> BN_DEV u32 sub_borrow<8>(u32 (&d)[8], const u32 (&x)[8], const u32 (&y)[8]) {
+  u32 b;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "v_cndmask_b32 %8, 0, -1, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(b)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])
+      : "vcc");
+  return b;
+}
+// Four steps on the low L limbs (all lanes of the wavefront have a, n < 2^(32 L) where a is still non-zero).  Both differences are
+// formed (two independent borrow chains) and the non-negative one selected: ~7 single-rate instructions per limb and step.
+template <int L>
+BN_DEV void jacobi_steps4(u32 (&a)[8], u32 (&n)[8], u32& t) {
 #pragma unroll 2
   for (int it = 0; it < 4; ++it) {
     const u32 odd = 0u - (a[0] & 1u);
-    // d = a - n, lt = (a < n)
-    u32 d[8];
-    u64 br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const u64 w = (u64)a[i] - n[i] - br; d[i] = (u32)w; br = (w >> 32) & 1u; }
-    const u32 lt = 0u - (u32)br;
+    u32 d1[L], d2[L];
+    const u32 lt = sub_borrow<L>(d1, a, n);        // a - n, lt = (a < n)
+    (void)sub_borrow<L>(d2, n, a);                 // n - a
     const u32 sw = odd & lt;                       // odd a below n: continue with (n - a, a)
     t ^= sw & (a[0] >> 1) & (n[0] >> 1);          // both 3 mod 4
-    // |d| when swapping: (d ^ sw) - sw
-    u64 c = sw & 1u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      c += (u64)(d[i] ^ sw);
-      const u32 nd = (u32)c;
-      c >>= 32;
+    for (int i = 0; i < L; ++i) {
+      const u32 nd = lt ? d2[i] : d1[i];           // |a - n|
       n[i] = sw ? a[i] : n[i];
       a[i] = odd ? nd : a[i];
     }
     t ^= (n[0] >> 1) ^ (n[0] >> 2);               // halving an even value: (2 / n); irrelevant once a = 0 (then n = 1 or the symbol is 0)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
-    a[7] >>= 1;
+    for (int i = 0; i + 1 < L; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[L - 1] >>= 1;
   }
+}
+// blocks of 4 steps on L limbs while some lane with a != 0 still has a or n at least 2^(32 (L - 1)); neither value ever grows, so
+// once the top limb is clear for the whole wavefront the remaining steps run on L - 1 limbs (the operands lose ~1.4 bits per step:
+// the average step works on half the limbs)
+template <int L>
+BN_DEV void jacobi_level(u32 (&a)[8], u32 (&n)[8], u32& t, int& blk) {
+#pragma unroll 1
+  while (blk < 508 / 4) {
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) nz |= a[i];
+    const bool busy = nz != 0u && (L == 1 || (a[L - 1] | n[L - 1]) != 0u);
+    if (!__any(busy)) break;
+    jacobi_steps4<L>(a, n, t);
+    ++blk;
   }
+}
+BN_NOINLINE bool fp_is_square(Fp x) {
+  u32 a[8], n[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = x.v[i];
+  u32 t = 0;
+  int blk = 0;
+  // every lane whose a has reached 0 only idles (t and n are final); random inputs need ~360 steps, the slowest of 64 lanes ~380; the
+  // 508 bound is for the worst case
+  jacobi_level<8>(a, n, t, blk); jacobi_level<7>(a, n, t, blk); jacobi_level<6>(a, n, t, blk); jacobi_level<5>(a, n, t, blk);
+  jacobi_level<4>(a, n, t, blk); jacobi_level<3>(a, n, t, blk); jacobi_level<2>(a, n, t, blk); jacobi_level<1>(a, n, t, blk);
   const bool n_is_one = (n[0] == 1u) && ((n[1] | n[2] | n[3] | n[4] | n[5] | n[6] | n[7]) == 0u);
   return !(n_is_one && (t & 1u));
 }

@@ -534,9 +534,31 @@ BN_NOINLINE void miller_loop29(S12& fout, const Fp& pxs, const Fp& pys, const S2
 }
 
 // ---- final exponentiation, all of it on the carry-free core (one Fp inversion inside the easy part) -----------------------
-BN_NOINLINE void w12_mul_nl(W12& r, const W12& a, const W12& b) { r = w12_mul(a, b); }
-BN_NOINLINE void w12_cyclotomic_sqr_nl(W12& r, const W12& a) { r = w12_cyclotomic_sqr(a); }
-template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) { r = w12_frobenius<E>(a); }
+// Out-of-line Fp12 routines of the straight-line part.  Operands arrive by reference (an Fp12 is 54 registers per lane, the C ABI
+// passes 31): each routine fetches them ONCE, whole, into registers and pins them there -- one wait per routine; reading through the
+// references at the points of use costs a full memory wait in front of every product leaf (18 per Fp12 product).
+BN_DEV void w12_pin(W12& x) {
+  W2* const c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) BN_CHAIN_NV(c[j]->c.v[i]);
+}
+BN_NOINLINE void w12_mul_nl(W12& r, const W12& a, const W12& b) {
+  W12 x = a, y = b;
+  w12_pin(x); w12_pin(y);
+  r = w12_mul(x, y);
+}
+BN_NOINLINE void w12_cyclotomic_sqr_nl(W12& r, const W12& a) {
+  W12 x = a;
+  w12_pin(x);
+  r = w12_cyclotomic_sqr(x);
+}
+template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) {
+  W12 x = a;
+  w12_pin(x);
+  r = w12_frobenius<E>(x);
+}
 // pairing.rs:366-392: f^x then conjugate, f in the cyclotomic subgroup (f^-1 = conj f).  Width-4 signed-digit form of
 // x = 4965661367192848881: 14 non-zero digits in {+-1, +-3, +-5, +-7} -> 62 cyclotomic squarings + 13 products + 3 for the
 // table {f, f^3, f^5, f^7} (the reference's 256-step square-and-multiply reaches the same field element with 27 products).
@@ -588,7 +610,9 @@ BN_DEV W6 w6_inv(const W6& a) {                                          // inpu
   const W2 di = w2_inv(d);
   return W6{w2_mul(di, t0), w2_mul(di, t1), w2_mul(di, t2)};
 }
-BN_NOINLINE void w12_inv_nl(W12& r, const W12& a) {
+BN_NOINLINE void w12_inv_nl(W12& r, const W12& ain) {
+  W12 a = ain;
+  w12_pin(a);
   const W6 s0 = w6_mul(a.c0, a.c0), s1 = w6_mul(a.c1, a.c1);           // R
   // c0^2 - v c1^2 with v (x0, x1, x2) = (xi x2, x0, x1); normalised: w6_inv squares its coefficients
   const W6 d{w2_norm(w2_sub(s0.c0, w2_mul_xi(s1.c2))), w2_norm(w2_sub(s0.c1, s1.c0)), w2_norm(w2_sub(s0.c2, s1.c1))};
