@@ -79,7 +79,7 @@ def issue_fields(pmc_cfg):
     return {"issue_frac": pmc_cfg["issue_frac"], "issue_frac_vs_measured_issue_rates": pmc_cfg.get("issue_frac_vs_measured_issue_rates"),
             "valu_instr_per_unit": pmc_cfg.get("valu_instr_per_unit"), "int64_class_frac": pmc_cfg.get("int64_class_frac"),
             "issue_cycles_ideal_per_unit": pmc_cfg.get("issue_cycles_ideal_per_unit"), "simd_cycles_per_unit": pmc_cfg.get("simd_cycles_per_unit"),
-            "hbm_bytes_per_unit_measured": pmc_cfg.get("hbm_bytes_per_unit"), "profile_ms_per_launch": pmc_cfg.get("ms_per_launch_kernel_sum")}
+            "hbm_bytes_per_unit_measured": pmc_cfg.get("hbm_bytes_per_unit"), "profile_ms_per_launch": pmc_cfg.get("ms_per_launch", pmc_cfg.get("ms_per_launch_kernel_sum"))}
 
 
 def limbs_row(vals):

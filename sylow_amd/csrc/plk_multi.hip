@@ -763,49 +763,94 @@ int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint
 // `weights` (NULL = none): w_i as Fp values [4][n]; the product becomes prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) = e(sum w_i sig_i, G2gen)
 // prod_i e(-w_i H(m_i), pk_i) -- the small-exponent batch test (SURVEY.md e1 "alternative aggregate check"): with weights drawn after
 // the signatures are fixed, a batch that contains an invalid signature passes with probability at most 2^-(bits of the weights).
+// A short-lived side stream for work that does not depend on the long kernels of the caller's stream (here: the sum of the
+// signatures and the one Miller loop it feeds run beside the batch's hashing instead of after it).  open(): the side stream waits for
+// everything the caller's stream holds at this point; join(): the caller's stream waits for the side work.  Any failure to create the
+// stream or its events degrades to the caller's stream (same results, no overlap); SYLOW_HIP_AGG_FORK=0 forces that.
+namespace {
+struct Fork {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t open(hipStream_t main) {
+    static const bool off = [] { const char* e = getenv("SYLOW_HIP_AGG_FORK"); return e && e[0] == '0'; }();
+    if (off) return main;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; (void)hipGetLastError(); return main; }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      close();
+      return main;
+    }
+    return side;
+  }
+  int32_t join(hipStream_t main) {
+    if (!side) return SYLOW_HIP_OK;
+    hipError_t e = hipEventRecord(ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(side); return host::fail(e, "join of the side stream"); }
+    return SYLOW_HIP_OK;
+  }
+  void close() {     // destroying a stream / an event with work in flight is deferred by the runtime until that work completes
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+    ev_fork = ev_join = nullptr; side = nullptr;
+  }
+  ~Fork() { close(); }
+};
+}  // namespace
 static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                  const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, uint64_t* f_out, void* stream) {
   ARGCHK(f_out && (n == 0 || (pk_xy && msgs && msg_offsets && sig_xy && (n_pk == 1 || n_pk == n))));
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) { plk::k_fp12_set_one<<<1, 64, 0, st>>>(f_out); LAUNCHED(); }
-  // scratch (u64 words): H or -H [8][n], the summation tree [12][n], the two collapsed pairs G1 [8][2] / G2 [16][2], one product, flags
+  const bool one_key = n_pk == 1 && n != 1;
+  // scratch (u64 words): H or -H [8][n], the summation tree(s) [12][n], the two collapsed pairs G1 [8] + [8] / G2 [16] + [16], flags
   const size_t w_h = 8 * n, w_acc = 12 * n, w_flags = (2 * n + 4 + 7) / 8, w_sw = weights ? 8 * n : 0;
   host::Lease ws;
-  int32_t rc = ws.acquire((w_h + w_acc + w_sw + 16 + 32 + 48 + w_flags) * sizeof(u64), st);
+  int32_t rc = ws.acquire((w_h + (one_key ? 2 : 1) * w_acc + w_sw + 16 + 32 + w_flags) * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
-  u64 *hxy = (u64*)ws.p, *acc = hxy + w_h, *sw = acc + w_acc, *p2 = sw + w_sw, *q2 = p2 + 16, *prod_b = q2 + 32;
-  uint8_t *hinf = (uint8_t*)(prod_b + 48), *p2inf = hinf + n, *q2inf = p2inf + 2, *swinf = q2inf + 2;
-  const bool one_key = n_pk == 1 && n != 1;
+  u64 *hxy = (u64*)ws.p, *acc = hxy + w_h, *acc2 = acc + (one_key ? w_acc : 0), *sw = acc2 + w_acc, *pa2 = sw + w_sw, *pb2 = pa2 + 8, *qa2 = pb2 + 8, *qb2 = qa2 + 16;
+  uint8_t *hinf = (uint8_t*)(qb2 + 16), *p2inf = hinf + n, *q2inf = p2inf + 2, *swinf = q2inf + 2;
   host::Lease wa, wb;
   u64 *pa = nullptr, *pb = nullptr;
-  rc = g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
+  // The G2gen half -- e(sum_i sig_i, G2gen): a summation tree and ONE Miller loop on one lane pair, a few ms of pure latency -- depends on
+  // the signatures only: it runs on a side stream beside the hashing (with weights it needs w_i sig_i first and stays in line).
+  Fork fork;
+  hipStream_t sd = weights ? st : fork.open(st);
+  if (!weights) {
+    rc = g1h::sum(sig_xy, sig_inf, n, acc, pb2, p2inf + 1, 1, 0, 0, sd);
+    if (rc == SYLOW_HIP_OK) {
+      plk::k_g2_set_column<<<1, 64, 0, sd>>>(qb2, q2inf + 1, 1, 0, nullptr, nullptr);
+      rc = miller_product_tree(pb2, p2inf + 1, qb2, q2inf + 1, 1, 1, wb, &pb, sd);
+    }
+  }
+  if (rc == SYLOW_HIP_OK) rc = g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
   if (rc == SYLOW_HIP_OK && weights) {                      // H_i <- w_i H_i (in place), sig_i -> w_i sig_i (scratch)
     rc = sylow_hip_g1_scalar_mul_batch(hxy, hinf, weights, hxy, hinf, n, stream);
     if (rc == SYLOW_HIP_OK) rc = sylow_hip_g1_scalar_mul_batch(sig_xy, sig_inf, weights, sw, swinf, n, stream);
-    sig_xy = sw; sig_inf = swinf;
+    if (rc == SYLOW_HIP_OK) rc = g1h::sum(sw, swinf, n, acc, pb2, p2inf + 1, 1, 0, 0, stream);
+    if (rc == SYLOW_HIP_OK) {
+      plk::k_g2_set_column<<<1, 64, 0, st>>>(qb2, q2inf + 1, 1, 0, nullptr, nullptr);
+      rc = miller_product_tree(pb2, p2inf + 1, qb2, q2inf + 1, 1, 1, wb, &pb, stream);
+    }
   }
   if (rc == SYLOW_HIP_OK && !one_key) {
-    // e(sum sig, G2gen) as a one-pair product (stride 1 arrays = column 0 of stride-1 views), prod_i e(-H_i, pk_i) over the batch
-    rc = g1h::sum(sig_xy, sig_inf, n, acc, p2, p2inf, 1, 0, 0, stream);
-    if (rc == SYLOW_HIP_OK) { plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 1, 0, nullptr, nullptr); }
-    if (rc == SYLOW_HIP_OK) rc = miller_product_tree(hxy, hinf, pk_xy, pk_inf, n, 1, wa, &pa, stream);
-    if (rc == SYLOW_HIP_OK) rc = miller_product_tree(p2, p2inf, q2, q2inf, 1, 1, wb, &pb, stream);
-    if (rc == SYLOW_HIP_OK) plk::k_fp12_mul_pair<<<1, 64, 0, st>>>(pa, pb, f_out);
+    // prod_i e(-H_i, pk_i) over the batch
+    rc = miller_product_tree(hxy, hinf, pk_xy, pk_inf, n, 1, wa, &pa, stream);
   } else if (rc == SYLOW_HIP_OK) {
-    // one key: two pairs in all, (sum sig, G2gen) and (-sum H, pk), SoA stride 2
-    rc = g1h::sum(sig_xy, sig_inf, n, acc, p2, p2inf, 2, 0, 0, stream);
-    if (rc == SYLOW_HIP_OK) rc = g1h::sum(hxy, hinf, n, acc, p2, p2inf, 2, 1, /*negate=*/1, stream);
+    // one key: the other half collapses too -- e(-sum H, pk), one more single-pair loop
+    rc = g1h::sum(hxy, hinf, n, acc2, pa2, p2inf, 1, 0, /*negate=*/1, stream);
     if (rc == SYLOW_HIP_OK) {
-      plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 2, 0, nullptr, nullptr);
-      plk::k_g2_set_column<<<1, 64, 0, st>>>(q2, q2inf, 2, 1, pk_xy, pk_inf);
-      rc = miller_product_tree(p2, p2inf, q2, q2inf, 2, 1, wa, &pa, stream);
-    }
-    if (rc == SYLOW_HIP_OK) {
-      const hipError_t e = hipMemcpyAsync(f_out, pa, 48 * sizeof(u64), hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) rc = host::fail(e, "hipMemcpyAsync(aggregate product)");
+      plk::k_g2_set_column<<<1, 64, 0, st>>>(qa2, q2inf, 1, 0, pk_xy, pk_inf);
+      rc = miller_product_tree(pa2, p2inf, qa2, q2inf, 1, 1, wa, &pa, stream);
     }
   }
+  const int32_t rj = fork.join(st);
+  if (rc == SYLOW_HIP_OK) rc = rj;
+  if (rc == SYLOW_HIP_OK) plk::k_fp12_mul_pair<<<1, 64, 0, st>>>(pa, pb, f_out);
   const hipError_t e = hipGetLastError();
+  if (wb.slot >= 0) wb.st = st;      // the caller's stream has joined the side stream and still reads the block: its release is ordered there
   const int32_t r1 = wa.release(), r2 = wb.release(), r3 = ws.release();
   if (rc != SYLOW_HIP_OK) return rc;
   if (e != hipSuccess) return host::fail(e, "kernel launch");
