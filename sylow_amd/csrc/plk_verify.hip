@@ -159,10 +159,17 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   __shared__ i32 lds[PK_TABLE ? 36 : 54][256];
   const bool liveA = !(siginf && siginf[ii]);
   const bool liveB = !(hinf || (pkinf && pkinf[PK_TABLE ? 0 : ii]));
-  lds_put9(lds, 0, f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))));
-  lds_put9(lds, 1, f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4))));
-  lds_put9(lds, 2, f29_reduce(f29_from_fp(hxs)));
-  lds_put9(lds, 3, f29_reduce(f29_from_fp(fp_neg(hys))));                  // pair B is (-H, pk)
+  // A dead pair (a point at infinity on either side: its pairing is 1) keeps the loop's instruction stream and contributes nothing: its
+  // G1 coordinates are stored as ZERO, so that the two line coefficients they scale vanish and the line degenerates to its constant
+  // coefficient.  For pair A that coefficient is the table's small integer (replaced by 1 below).  For pair B without a key table it is
+  // the Fp2 value l0 of the stepped point -- a dead pair B steps the generator, whose 87 constants are non-zero
+  // (tests/test_oracle_kats.py::test_generator_line_constants_nonzero) -- and a factor in Fp2* changes neither the final exponentiation's
+  // value nor this kernel's boolean (c^(p^6 - 1) = 1 for c in Fp6*).  No per-line selects, no unit / zero constants held across the loop.
+  const F29 f29_zero{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  lds_put9(lds, 0, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))) : f29_zero);
+  lds_put9(lds, 1, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4))) : f29_zero);
+  lds_put9(lds, 2, liveB ? f29_reduce(f29_from_fp(hxs)) : f29_zero);
+  lds_put9(lds, 3, liveB ? f29_reduce(f29_from_fp(fp_neg(hys))) : f29_zero);   // pair B is (-H, pk)
   auto SX = [&]() { return lds_get9(lds, 0); };
   auto SY = [&]() { return lds_get9(lds, 1); };
   auto HX = [&]() { return lds_get9(lds, 2); };
@@ -170,12 +177,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   // a dead pair B steps the generator instead (any curve point keeps the arithmetic defined) and multiplies by the unit line
   auto key_x = [&]() { return (PK_TABLE || !liveB) ? s2_g2gen_x() : load_s2(pkxy, n, ii, 0, odd); };
   auto key_y = [&]() { return (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd); };
-  const W2 w_one = w2_from_s2(s2_one()), w_zero = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   G2W r;
   {
     const W2 qx = w2_from_s2(key_x()), qy = w2_from_s2(key_y());
     if (!PK_TABLE) { lds_put9(lds, 4, qx.c); lds_put9(lds, 5, qy.c); }
-    r = G2W{qx, qy, w_one};
+    r = G2W{qx, qy, w2_from_s2(s2_one())};
   }
   auto QX = [&]() { return W2{lds_get9(lds, PK_TABLE ? 0 : 4)}; };
   auto QY = [&](bool neg) {
@@ -191,14 +197,14 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   int idx = 0;
   auto lineA = [&]() {
     const W2 a1 = w2_scale(table_w2(tabA, idx, 0, odd), SY()), a2 = w2_scale(table_w2(tabA, idx, 1, odd), SX());
-    f = w12_sparse_mul_unit(f, liveA ? table_unit(tabA, idx) : 1, w2_select(w_zero, a1, liveA), w2_select(w_zero, a2, liveA));
+    f = w12_sparse_mul_unit(f, liveA ? table_unit(tabA, idx) : 1, a1, a2);
   };
   auto lineB = [&]() {
     if (PK_TABLE) {
       const W2 b1 = w2_scale(table_w2(tabB, idx, 0, odd), HY()), b2 = w2_scale(table_w2(tabB, idx, 1, odd), HX());
-      f = w12_sparse_mul_unit(f, liveB ? table_unit(tabB, idx) : 1, w2_select(w_zero, b1, liveB), w2_select(w_zero, b2, liveB));
+      f = w12_sparse_mul_unit(f, liveB ? table_unit(tabB, idx) : 1, b1, b2);
     } else {
-      f = w12_sparse_mul(f, w2_select(w_one, l0, liveB), w2_select(w_zero, w2_scale(l1, HY()), liveB), w2_select(w_zero, w2_scale(l2, HX()), liveB));
+      f = w12_sparse_mul(f, l0, w2_scale(l1, HY()), w2_scale(l2, HX()));
     }
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;

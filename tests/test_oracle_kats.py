@@ -209,3 +209,13 @@ def test_byte_formats_roundtrip():
     assert R.g1_from_be_bytes(b"\x11" * 64) is None                                        # off-curve (reth_bn128.rs:294-307)
     q = R.affine_from_proj(R.F2, R.proj_scalar_mul(R.F2, R.proj_from_affine(R.F2, R.G2_GEN_AFF), rng.fp()))
     assert R.affine_from_proj(R.F2, R.g2_from_be_bytes(R.g2_to_be_bytes(q))) == q
+
+
+def test_generator_line_constants_nonzero(coracle):
+    """The fused verify kernel lets a dead pair (a point at infinity) step the G2 generator with ZERO G1 coordinates: its lines reduce to
+    their constant coefficient ell_0, an Fp2 value the final exponentiation kills -- provided it is never zero.  The schedule is fixed,
+    so the 87 constants of the generator are checked once, here (pairing.rs:676-708 via both restatements)."""
+    co = R.g2_precompute(R.G2_GEN_AFF)
+    assert len(co) == 87 and all(ell[0] != (0, 0) for ell in co)
+    flat = ints(coracle.g2_precompute(pack(list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1]), 16)))
+    assert flat == [x for ell3 in co for e in ell3 for x in e]
