@@ -65,8 +65,11 @@ def test_all_valid_and_product_all_single_rank(engine, pairs):
 
 def _rccl():
     import torch  # noqa: F401  (makes torch's librccl resolvable first: one RCCL per process)
-    for name in ("librccl.so.1", os.path.join(os.path.dirname(__import__("torch").__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"):
+    from sylow_amd.rccl import warm_file
+    for name in (os.path.join(os.path.dirname(__import__("torch").__file__), "lib", "librccl.so"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"):
         try:
+            if os.path.isfile(name):
+                warm_file(name)          # a cold page cache turns the first communicator into minutes of 4 KB faults
             return ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             continue
