@@ -161,6 +161,28 @@ def test_fp_pow_sqrt_is_square_vs_oracle(engine, coracle):
     assert np.array_equal(engine.fp_pow(a[:64], e), coracle.fp_pow(a[:64], e))
 
 
+def test_is_square_and_sqrt_structured_inputs(engine):
+    """The Jacobi symbol steps on as many limbs as the wavefront still needs and the square-root chain fetches its window-table entries
+    ahead of use: inputs that exercise every limb count from the first step on (values below 2^32 .. 2^256), powers of two and their
+    neighbours, p - 2^b, guaranteed squares -- against Python's big-integer power (fp.rs:611-631)."""
+    import random
+    rnd = random.Random(4242)
+    vals = [0, 1, 2, 3, 4, 5, 7, 8, P - 1, P - 2, P - 3, (P - 1) // 2, (P + 1) // 2, (P + 1) // 4]
+    for b in range(1, 254):
+        vals += [1 << b, (1 << b) - 1, (1 << b) + 1, P - (1 << b)]
+    for nl in range(1, 9):
+        vals += [rnd.getrandbits(32 * nl) % P for _ in range(600)]
+    vals += [rnd.randrange(P) for _ in range(4000)]
+    vals += [v * v % P for v in vals[:1500]]
+    a = limbs(vals)
+    exp = np.array([1 if pow(v, (P - 1) // 2, P) in (0, 1) else 0 for v in vals], dtype=np.uint8)
+    assert np.array_equal(engine.fp_is_square(a), exp)
+    r, ok = engine.fp_sqrt(a)
+    assert np.array_equal(ok, exp)
+    roots = ints(r)
+    assert all(y * y % P == v for v, y, e in zip(vals, roots, exp) if e)
+
+
 def test_field_extension_componentwise_operators(engine, coracle):
     """FieldExtension Add / Sub / Neg / scale (extensions.rs:67-238) for Fp2, Fp6, Fp12 batches (scope row a8) against the oracle's
     Fp arithmetic coefficient by coefficient and pyref's tower operators, odd batch size included."""
