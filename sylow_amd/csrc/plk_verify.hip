@@ -140,8 +140,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
 
 // e(sig, G2gen) * e(-H(msg), pk) == 1 with one shared-squaring Miller loop and one final exponentiation (see the single-lane
 // k_bls_verify_fused in single.hip for the contract).  PK_TABLE: one public key for the whole batch, its lines precomputed.
-template <bool PK_TABLE>
+// HASHED: -H(m_i) was computed by k_hash_to_g1 beforehand (affine SoA hneg / hneg_inf; msgs / off / dp unused): one Keccak expansion per
+// element instead of one per lane of the pair, and the hashing code's registers and stack frame stay out of this kernel.
+template <bool PK_TABLE, bool HASHED>
 __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table, const uint8_t* msgs, const u64* off, DstPrime dp,
+                                                const u64* hneg, const uint8_t* hneg_inf,
                                                 const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
   __shared__ i32 tabA[LINE_TABLE_WORDS];
   __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
@@ -152,8 +155,13 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const int odd = (int)(t & 1);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
-  Fp hxs, hys; bool hinf;
-  hash_to_g1_pair(hxs, hys, hinf, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
+  Fp hxs, hys; bool hinf;                                                    // pair B is (-H, pk)
+  if (HASHED) {
+    hxs = load_fp(hneg, n, ii, 0); hys = load_fp(hneg, n, ii, 4); hinf = hneg_inf[ii] != 0;
+  } else {
+    hash_to_g1_pair(hxs, hys, hinf, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
+    hys = fp_neg(hys);
+  }
   // Loop invariants that are read once or twice per step live in LDS, [limb][thread] (see miller_loop29g): the signature's and
   // -H(m)'s coordinates for the line scalings and, without a key table, the key's for the addition steps.
   __shared__ i32 lds[PK_TABLE ? 36 : 54][256];
@@ -169,7 +177,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   lds_put9(lds, 0, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))) : f29_zero);
   lds_put9(lds, 1, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4))) : f29_zero);
   lds_put9(lds, 2, liveB ? f29_reduce(f29_from_fp(hxs)) : f29_zero);
-  lds_put9(lds, 3, liveB ? f29_reduce(f29_from_fp(fp_neg(hys))) : f29_zero);   // pair B is (-H, pk)
+  lds_put9(lds, 3, liveB ? f29_reduce(f29_from_fp(hys)) : f29_zero);
   auto SX = [&]() { return lds_get9(lds, 0); };
   auto SY = [&]() { return lds_get9(lds, 1); };
   auto HX = [&]() { return lds_get9(lds, 2); };
@@ -246,6 +254,34 @@ int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* ta
 }
 }  // namespace plkh
 
+// The fused check as two launches: -H(m_i) for the batch (g1.hip: k_hash_to_g1, one element per lane, 64 bytes per element through a leased
+// block), then the pairing kernel reading it.  SYLOW_HIP_VERIFY_HASH_INSIDE=1 keeps the hashing inside the pairing kernel (each lane of a
+// pair maps one of the two field elements, both expand the message): 1 % slower at 2^20, one launch.
+static bool verify_hash_inside() {
+  static const bool v = [] { const char* e = getenv("SYLOW_HIP_VERIFY_HASH_INSIDE"); return e && e[0] == '1'; }();
+  return v;
+}
+template <bool PK_TABLE>
+static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint8_t* msgs, const uint64_t* msg_offsets,
+                            const DstPrime& dp, const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, void* stream) {
+  if (verify_hash_inside()) {
+    plk::k_bls_verify_fused<PK_TABLE, false><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, msgs, msg_offsets, dp, nullptr, nullptr, sig_xy, sig_inf, gen, ok, n);
+    LAUNCHED();
+  }
+  host::Lease ws;
+  int32_t rc = ws.acquire(8 * n * sizeof(u64) + n, (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  u64* hneg = (u64*)ws.p;
+  uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
+  rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
+  if (rc == SYLOW_HIP_OK)
+    plk::k_bls_verify_fused<PK_TABLE, true><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, nullptr, nullptr, dp, hneg, hinf, sig_xy, sig_inf, gen, ok, n);
+  const hipError_t e = hipGetLastError();
+  const int32_t r2 = ws.release();
+  if (rc != SYLOW_HIP_OK) return rc;
+  return e != hipSuccess ? host::fail(e, "kernel launch") : r2;
+}
+
 extern "C" {
 // verify (lib.rs:223-236): pairing(sig, G2gen) == pairing(H(msg), pk).  The default entry point answers with ONE final
 // exponentiation: FE(a) == FE(b) <=> FE(a conj(b)) == 1 (FE is a homomorphism onto unitary elements, FE(conj b) = FE(b)^-1), and
@@ -259,7 +295,7 @@ static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
   if (rc != SYLOW_HIP_OK) return rc;
-  plk::k_bls_verify_fused<false><<<GRID(2 * n)>>>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+  return launch_fused<false>(pk_xy, pk_inf, nullptr, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n, stream);
 }
 int32_t sylow_hip_bls_verify_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                    const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
@@ -292,10 +328,9 @@ int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint
   if ((rc = ws.acquire(plk::LINE_TABLE_WORDS * sizeof(bn254::i32), st)) != SYLOW_HIP_OK) return rc;
   bn254::i32* table = (bn254::i32*)ws.p;
   plk::k_g2_lines29<<<1, plk::LINES_BLOCK, 0, st>>>(pk_xy, 1, 0, table);     // the key is a 1-element SoA array
-  plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n);
-  const hipError_t e = hipGetLastError();
-  rc = ws.release();
-  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
+  rc = launch_fused<true>(pk_xy, pk_inf, table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n, stream);
+  const int32_t r2 = ws.release();
+  return rc != SYLOW_HIP_OK ? rc : r2;
 }
 // The same check against a line table the host cached for the key (sylow_hip_g2_line_table: `G2PreComputed` cached per pk,
 // examples/verify_multiple_messages_same_signer.rs:41-60): no G2 arithmetic at all, nothing rebuilt per call.
@@ -311,6 +346,6 @@ int32_t sylow_hip_bls_verify_line_table_batch(const int32_t* pk_table, const uin
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
   if (rc != SYLOW_HIP_OK) return rc;
-  plk::k_bls_verify_fused<true><<<GRID(2 * n)>>>(nullptr, pk_inf, pk_table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n); LAUNCHED();
+  return launch_fused<true>(nullptr, pk_inf, pk_table, msgs, msg_offsets, dp, sig_xy, sig_inf, gen, ok, n, stream);
 }
 }  // extern "C"
