@@ -185,18 +185,7 @@ __global__ void k_g1_sum_finish(const u64* acc, size_t n, u64* oxy, uint8_t* oin
 }
 
 // ------------------------------------------------------------------ hash / BLS kernels ----------
-__global__ void __launch_bounds__(BLOCK) k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n, int negate) {
-  size_t i = TID;
-  if (i >= n) return;
-  G1P h;
-  bool ok = hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
-  Fp x, y; bool inf;
-  g1_to_affine(x, y, inf, h);
-  if (negate && !inf) y = fp_neg(y);                     // -H(m): the G1 side of the e(sig, G2gen) e(-H, pk) == 1 shapes
-  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
-  oinf[i] = inf ? 1 : 0;
-  if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
-}
+// k_hash_to_g1 lives in hash.hip (a unit of its own: compiled for four wavefronts per SIMD)
 // SvdW::unchecked_map_to_point (svdw.rs:180-262) on its own: u -> (x, y) on the curve; status CANNOT_HASH where the reference
 // returns MapError (cannot happen on this curve)
 __global__ void __launch_bounds__(BLOCK) k_svdw_map(const u64* u, u64* oxy, uint8_t* status, size_t n) {
@@ -362,10 +351,6 @@ size_t g1_comb_bytes() { return COMB1_WORDS * sizeof(bn254::i32); }
 int32_t build_g1_comb(bn254::i32* table, void* stream) {
   k_g1_comb_table<<<GRID((size_t)COMB_WIN * COMB_ENT)>>>(table); LAUNCHED();
 }
-int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
-  DstPrime dp; host::dst_arg(dp, nullptr, 0);
-  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate); LAUNCHED();
-}
 int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
   if (n) k_g1_sum_init<<<GRID(n)>>>(p_xy, p_inf, acc, n);
   size_t m = n;
@@ -435,7 +420,7 @@ int32_t sylow_hip_hash_to_g1_batch(const uint8_t* msgs, const uint64_t* msg_offs
                                    uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(msgs && msg_offsets && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
-  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, 0); LAUNCHED();
+  return g1h::hash_to_g1_dst(msgs, msg_offsets, dp, out_xy, out_inf, n, 0, stream);
 }
 int32_t sylow_hip_svdw_map_batch(const uint64_t* u, uint64_t* out_xy, uint8_t* status, size_t n, void* stream) {
   ARGCHK(u && out_xy); if (!n) return SYLOW_HIP_OK;

@@ -254,7 +254,7 @@ int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* ta
 }
 }  // namespace plkh
 
-// The fused check as two launches: -H(m_i) for the batch (g1.hip: k_hash_to_g1, one element per lane, 64 bytes per element through a leased
+// The fused check as two launches: -H(m_i) for the batch (hash.hip: k_hash_to_g1, one element per lane, four wavefronts per SIMD, 64 bytes per element through a leased
 // block), then the pairing kernel reading it.  SYLOW_HIP_VERIFY_HASH_INSIDE=1 keeps the hashing inside the pairing kernel (each lane of a
 // pair maps one of the two field elements, both expand the message): 1 % slower at 2^20, one launch.
 static bool verify_hash_inside() {
