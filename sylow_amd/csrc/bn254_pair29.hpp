@@ -194,6 +194,33 @@ BN_DEV W12 w12_mul(const W12& a, const W12& b) {
   r.c0.c2 = w2_norm(w2_add(t0.c2, t1.c1));
   return r;
 }
+// a * b for b with b.c1.c2 = 0 -- the product of two lines (w12_line_product): the middle Fp6 product has a zero coefficient on its
+// right-hand side, 5 products instead of 6 (17 for the Fp12 product instead of 18)
+BN_DEV W6 w6_mul_b2zero(const W6& a, const W6& b) {
+  const W2 v0 = w2_mul(a.c0, b.c0);
+  const W2 v1 = w2_mul(a.c1, b.c1);
+  const W2 t0 = w2_mul(w2_norm(w2_add(a.c1, a.c2)), b.c1);
+  const W2 t1 = w2_mul(w2_norm(w2_add(a.c0, a.c1)), w2_norm(w2_add(b.c0, b.c1)));
+  const W2 t2 = w2_mul(w2_norm(w2_add(a.c0, a.c2)), b.c0);
+  W6 r;
+  r.c0 = w2_xi_lin(w2_sub(t0, v1), 1, v0, 1);                            // v0 + xi (t0 - v1)
+  r.c1 = w2_reduce(w2_sub(w2_sub(t1, v0), v1));                          // t1 - v0 - v1
+  r.c2 = w2_reduce(w2_add(w2_sub(t2, v0), v1));                          // t2 - v0 + v1
+  return r;
+}
+BN_DEV W12 w12_mul_line_pair(const W12& a, const W12& b) {
+  const W6 t0 = w6_mul(a.c0, b.c0);
+  const W6 t1 = w6_mul_b2zero(a.c1, b.c1);
+  const W6 t2 = w6_mul(w6_add_norm(a.c0, a.c1), W6{w2_norm(w2_add(b.c0.c0, b.c1.c0)), w2_norm(w2_add(b.c0.c1, b.c1.c1)), b.c0.c2});
+  W12 r;
+  r.c1.c0 = w2_lin2(w2_sub(t2.c0, t0.c0), 1, t1.c0, -1);
+  r.c1.c1 = w2_lin2(w2_sub(t2.c1, t0.c1), 1, t1.c1, -1);
+  r.c1.c2 = w2_lin2(w2_sub(t2.c2, t0.c2), 1, t1.c2, -1);
+  r.c0.c0 = w2_xi_lin(t1.c2, 1, t0.c0, 1);                               // t0 + v t1
+  r.c0.c1 = w2_norm(w2_add(t0.c1, t1.c0));
+  r.c0.c2 = w2_norm(w2_add(t0.c2, t1.c1));
+  return r;
+}
 // complex squaring (fp12.rs:536-550): c0 = (a0 - a1)(a0 - v a1) + a0 a1 + v a0 a1, c1 = 2 a0 a1
 BN_DEV W12 w12_sqr(const W12& a) {
   const W6 d = w6_sub(a.c0, a.c1);                                       // D

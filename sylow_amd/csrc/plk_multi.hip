@@ -395,11 +395,11 @@ BN_NOINLINE void glued_miller_tables(W12& fout, const u32x4* at_generic, size_t 
     const gptr row = at + (size_t)line * line_step;
     int sl = 0;
 #pragma unroll 1
-    for (; sl + 1 < kw; sl += 2) {      // two slots' lines first multiplied together (6 products), then into f (18): 24 instead of 26
+    for (; sl + 1 < kw; sl += 2) {      // two slots' lines first multiplied together (6 products), then into f (17: one coefficient of the merged line is zero): 23 instead of 26
       const LineW L = line_get(row + (size_t)sl * LT_CHUNKS * stride, stride);
       const LineW M = line_get(row + (size_t)(sl + 1) * LT_CHUNKS * stride, stride);
       const W12 ll = w12_line_product(L.l0, L.l4, L.l2, M.l0, M.l4, M.l2);
-      f = w12_mul(f, ll);
+      f = w12_mul_line_pair(f, ll);
     }
     if (sl < kw) {
       const LineW L = line_get(row + (size_t)sl * LT_CHUNKS * stride, stride);
