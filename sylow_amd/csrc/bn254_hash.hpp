@@ -13,6 +13,11 @@ namespace bn254 {
 struct DstPrime {        // DST || I2OSP(len(DST), 1), already shortened if the tag was > 255 bytes
   uint8_t bytes[256];
   uint32_t len;          // length of DST' (<= 256)
+  // The one-block message of b_1 .. b_3 (hasher.rs:223-245: 32 bytes, the block counter, DST') with everything but the first 32 bytes
+  // filled in: byte 32 = 0 (the counter is OR-ed in), DST', Keccak's 0x01 .. 0x80 padding -- as the 17 little-endian rate words.
+  // Valid when 33 + len <= 135 (tail_ok); longer tags take the byte-wise absorber.
+  uint64_t tail[17];
+  uint32_t tail_ok;
 };
 
 __host__ __device__ inline u64 rotl64(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
@@ -110,6 +115,19 @@ inline void make_dst_prime(DstPrime& dp, const uint8_t* dst, size_t len) {
   for (size_t i = 0; i < len; ++i) dp.bytes[i] = dst[i];
   dp.bytes[len] = (uint8_t)len;
   dp.len = (uint32_t)len + 1;
+  uint8_t blk[136];
+  for (int i = 0; i < 136; ++i) blk[i] = 0;
+  dp.tail_ok = (33 + dp.len <= 135) ? 1u : 0u;
+  if (dp.tail_ok) {
+    for (uint32_t i = 0; i < dp.len; ++i) blk[33 + i] = dp.bytes[i];
+    blk[33 + dp.len] ^= 0x01;
+    blk[135] ^= 0x80;
+  }
+  for (int w = 0; w < 17; ++w) {
+    uint64_t v = 0;
+    for (int j = 0; j < 8; ++j) v |= (uint64_t)blk[8 * w + j] << (8 * j);
+    dp.tail[w] = v;
+  }
 }
 
 // hasher.rs:201-250 with len_in_bytes = 96 (ell = 3): out = b1 || b2 || b3
@@ -117,8 +135,17 @@ __device__ inline void expand_message_xmd96(uint8_t out[96], const uint8_t* msg,
   Keccak256 k;
   uint8_t b0[32];
   k.init();
-  // Z_pad: one whole rate block of zeros = one permutation of the zero state
-  keccak_f1600(k.s);
+  // Z_pad: one whole rate block of zeros = one permutation of the zero state -- a constant (Keccak-f[1600](0), first lane the
+  // well-known 0xF1258F7940E1DDE7), not worth 24 rounds per message
+  {
+    const u64 z[25] = {0xf1258f7940e1dde7ull, 0x84d5ccf933c0478aull, 0xd598261ea65aa9eeull, 0xbd1547306f80494dull, 0x8b284e056253d057ull,
+                       0xff97a42d7f8e6fd4ull, 0x90fee5a0a44647c4ull, 0x8c5bda0cd6192e76ull, 0xad30a6f71b19059cull, 0x30935ab7d08ffc64ull,
+                       0xeb5aa93f2317d635ull, 0xa9a6e6260d712103ull, 0x81a57c16dbcf555full, 0x43b831cd0347c826ull, 0x01f22f1a11a5569full,
+                       0x05e5635a21d9ae61ull, 0x64befef28cc970f2ull, 0x613670957bc46611ull, 0xb87c5a554fd00ecbull, 0x8c3ee88a1ccf32c8ull,
+                       0x940c7922ae3a2614ull, 0x1841f924a2c509e4ull, 0x16f53526e70465c2ull, 0x75f644e97f30a13bull, 0xeaf1ff7b5ceca249ull};
+#pragma unroll
+    for (int i = 0; i < 25; ++i) k.s[i] = z[i];
+  }
   k.update(msg, msg_len);
   k.put(0); k.put(96);          // l_i_b_str = I2OSP(96, 2)
   k.put(0);                     // I2OSP(0, 1)
@@ -126,6 +153,33 @@ __device__ inline void expand_message_xmd96(uint8_t out[96], const uint8_t* msg,
   k.finish(b0);
   uint8_t prev[32];
   for (int i = 0; i < 32; ++i) prev[i] = 0;
+  if (dp.tail_ok) {
+    // b_i = H((b_0 xor b_(i-1)) || i || DST'): one block whose words 4 .. 16 are the same for every message -- no byte loop
+    u64 x0[4], xp[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      u64 v = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v |= (u64)b0[8 * w + j] << (8 * j);
+      x0[w] = v;
+    }
+#pragma unroll 1
+    for (int blk = 1; blk <= 3; ++blk) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) k.s[w] = x0[w] ^ xp[w];
+#pragma unroll
+      for (int w = 4; w < 17; ++w) k.s[w] = dp.tail[w];
+      k.s[4] |= (u64)blk;
+#pragma unroll
+      for (int w = 17; w < 25; ++w) k.s[w] = 0;
+      keccak_f1600(k.s);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) xp[w] = k.s[w];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) out[32 * (blk - 1) + i] = (uint8_t)(xp[i >> 3] >> (8 * (i & 7)));
+    }
+    return;
+  }
 #pragma unroll 1
   for (int blk = 1; blk <= 3; ++blk) {
     k.init();
