@@ -470,8 +470,7 @@ BN_DEV Fp fp_pow_pp1_quarter(const Fp& a) {
 
 // a^((p-3)/4): one chain serves both the Legendre symbol (a * t^2 = a^((p-1)/2)) and the square-root candidate
 // (a * t = a^((p+1)/4)) of the same element
-BN_DEV Fp fp_pow_pm3_quarter(const Fp& a) {
-  return fp_pow_words(a, 0xb61f3f51u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu);
-}
+BN_NOINLINE Fp fp_pow_pm3_quarter_chain(Fp a);       // bn254_f29.hpp: the precomputed sliding-window schedule of this exponent
+BN_DEV Fp fp_pow_pm3_quarter(const Fp& a) { return fp_pow_pm3_quarter_chain(a); }
 
 }  // namespace bn254
