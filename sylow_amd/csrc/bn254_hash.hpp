@@ -374,16 +374,23 @@ BN_NOINLINE bool fp_is_square(Fp x) {
 }
 BN_DEV u32 fp_sgn0(const Fp& a) { return fp_from_mont(a).v[0] & 1; }   // fp.rs:636-644
 
-// svdw.rs:180-262 (RFC 9380 6.6.1, straight line) with A = 0, B = 3, Z = 1.  Returns false where
-// the reference would return MapError (cannot happen for this curve).
-BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
-  const Fp c1 = fp_const(C_SVDW[0]), c2 = fp_const(C_SVDW[1]), c3 = fp_const(C_SVDW[2]), c4 = fp_const(C_SVDW[3]), z = fp_const(C_SVDW[4]);
+// svdw.rs:180-262 (RFC 9380 6.6.1, straight line) with A = 0, B = 3, Z = 1, in two parts around the inversion tv3 = inv0(tv1 tv2):
+// svdw_front (tv1, tv2 and the value to invert) and svdw_back (everything after it).  Returns false where the reference would return
+// MapError (cannot happen for this curve).
+struct SvdwHalf { Fp u, tv1, tv2, d; };
+BN_DEV SvdwHalf svdw_front(const Fp& u) {
   const Fp one = fp_one();
+  const Fp t = fp_mul(fp_mul(u, u), fp_const(C_SVDW[0]));
+  SvdwHalf h;
+  h.u = u;
+  h.tv2 = fp_add(one, t);
+  h.tv1 = fp_sub(one, t);
+  h.d = fp_mul(h.tv1, h.tv2);
+  return h;
+}
+BN_NOINLINE bool svdw_back(Fp& xo, Fp& yo, Fp u, Fp tv1, Fp tv2, Fp tv3) {
+  const Fp c2 = fp_const(C_SVDW[1]), c3 = fp_const(C_SVDW[2]), c4 = fp_const(C_SVDW[3]), z = fp_const(C_SVDW[4]);
   const Fp b = fp_small(3);
-  Fp tv1 = fp_mul(fp_mul(u, u), c1);
-  Fp tv2 = fp_add(one, tv1);
-  tv1 = fp_sub(one, tv1);
-  Fp tv3 = fp_inv(fp_mul(tv1, tv2));
   Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
   Fp x1 = fp_sub(c2, tv4);
   Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
@@ -405,6 +412,25 @@ BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
   yo = y;
   return ok;
 }
+BN_NOINLINE bool svdw_map(Fp& xo, Fp& yo, Fp u) {
+  const SvdwHalf h = svdw_front(u);
+  return svdw_back(xo, yo, h.u, h.tv1, h.tv2, fp_inv(h.d));
+}
+
+// The two maps of one hash side by side up to their inversion, which they SHARE (Montgomery's trick: one safegcd + three products
+// instead of two safegcd; inv0 semantics kept: a zero operand is replaced by one going in and yields zero coming out), then the rest of
+// each map.  Same values as svdw_map(u0), svdw_map(u1) -- the inverse of a field element is unique.
+BN_DEV bool svdw_map2(Fp& x0, Fp& y0, Fp& x1, Fp& y1, const Fp& u0, const Fp& u1) {
+  const SvdwHalf a = svdw_front(u0), b = svdw_front(u1);
+  const bool za = fp_is_zero(a.d), zb = fp_is_zero(b.d);
+  const Fp one = fp_one(), zero = fp_zero();
+  const Fp da = fp_select(a.d, one, za), db = fp_select(b.d, one, zb);
+  const Fp t = fp_inv(fp_mul(da, db));
+  const Fp ia = fp_select(fp_mul(t, db), zero, za), ib = fp_select(fp_mul(t, da), zero, zb);
+  bool ok = svdw_back(x0, y0, a.u, a.tv1, a.tv2, ia);
+  ok = svdw_back(x1, y1, b.u, b.tv1, b.tv2, ib) && ok;
+  return ok;
+}
 
 // g1.rs:307-331: map(u0) + map(u1) with the complete projective addition; projective result
 __device__ inline bool hash_to_g1(G1P& out, const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
@@ -412,8 +438,7 @@ __device__ inline bool hash_to_g1(G1P& out, const uint8_t* msg, size_t msg_len, 
   expand_message_xmd96(em, msg, msg_len, dp);
   Fp u0 = fp_from_be48(em), u1 = fp_from_be48(em + 48);
   Fp x0, y0, x1, y1;
-  bool ok = svdw_map(x0, y0, u0);
-  ok = svdw_map(x1, y1, u1) && ok;
+  bool ok = svdw_map2(x0, y0, x1, y1, u0, u1);
   G1P a{x0, y0, fp_one()}, b{x1, y1, fp_one()};
   out = g1_add(a, b);
   return ok;

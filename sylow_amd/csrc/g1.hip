@@ -191,8 +191,12 @@ __global__ void k_g1_sum_finish(const u64* acc, size_t n, u64* oxy, uint8_t* oin
 __global__ void __launch_bounds__(BLOCK) k_svdw_map(const u64* u, u64* oxy, uint8_t* status, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  Fp x, y;
-  const bool ok = svdw_map(x, y, load_fp(u, n, i, 0));
+  // through svdw_map2 -- the form hash_to_g1 uses, two maps sharing one inversion -- with the neighbouring element as the second map
+  // (its result is dropped: element i^1 computes it again as ITS first), so that the entry point's parity tests cover the shared
+  // inversion, including the inv0 cases of either or both operands
+  const size_t j = (i ^ 1) < n ? (i ^ 1) : i;
+  Fp x, y, x2, y2;
+  const bool ok = svdw_map2(x, y, x2, y2, load_fp(u, n, i, 0), load_fp(u, n, j, 0));
   store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
   if (status) status[i] = ok ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_CANNOT_HASH;
 }

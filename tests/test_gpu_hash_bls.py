@@ -173,7 +173,9 @@ def test_svdw_map_and_compute_naf_entry_points(engine, coracle):
     """a30 / a6 of the scope table as entry points of their own: SvdW::unchecked_map_to_point (svdw.rs:180-262) against both oracles
     on edge and random field elements, and Fp::compute_naf (fp.rs:653-662) on raw 256-bit values incl. the wrap at 2^256."""
     rng = Xoshiro(SEED + 33)
-    us = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 3, 4] + [rng.fp() for _ in range(120)]
+    # +-1/2 are the u with tv1 tv2 = 0 (the inv0 case of svdw.rs:196); the device maps elements in neighbouring pairs that share one
+    # inversion: (P - 2, -1/2), (1/2, 3) exercise a zero on either side, the last two a zero on both
+    us = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 3, 4] + [rng.fp() for _ in range(120)] + [(P - 1) // 2, (P + 1) // 2, (P - 1) // 2]
     xy, st = engine.svdw_map(limbs(us))
     assert not st.any()
     assert np.array_equal(xy, coracle.svdw_map(limbs(us)))
