@@ -357,6 +357,9 @@ int32_t build_g1_comb(bn254::i32* table, void* stream) {
 }
 int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
   if (n) k_g1_sum_init<<<GRID(n)>>>(p_xy, p_inf, acc, n);
+  return sum_tree(acc, n, out_xy, out_inf, stride, col, negate, stream);
+}
+int32_t sum_tree(uint64_t* acc, size_t n, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
   size_t m = n;
   while (m > 1) {
     const size_t h = (m + 1) / 2;

@@ -9,11 +9,15 @@
 #include "host.hpp"
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n, int negate) {
+k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n, int negate, u64* proj) {
   size_t i = TID;
   if (i >= n) return;
   G1P h;
   bool ok = hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  if (proj) {                                            // projective [12][n], the summation tree's own layout: no inversion per element
+    store_fp(proj, n, i, 0, h.x); store_fp(proj, n, i, 4, h.y); store_fp(proj, n, i, 8, h.z);
+    return;
+  }
   Fp x, y; bool inf;
   g1_to_affine(x, y, inf, h);
   if (negate && !inf) y = fp_neg(y);                     // -H(m): the G1 side of the e(sig, G2gen) e(-H, pk) == 1 shapes
@@ -25,7 +29,13 @@ k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t
 namespace g1h {
 int32_t hash_to_g1_dst(const uint8_t* msgs, const uint64_t* msg_offsets, const DstPrime& dp, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
   if (!n) return SYLOW_HIP_OK;
-  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate); LAUNCHED();
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate, nullptr); LAUNCHED();
+}
+// H(m_i) projective, straight into a summation tree's scratch array acc [12][n] (library DST): the shape of "sum of the hashes"
+int32_t hash_to_g1_proj(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* acc, size_t n, void* stream) {
+  if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, nullptr, nullptr, nullptr, n, 0, acc); LAUNCHED();
 }
 int32_t hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
   DstPrime dp; host::dst_arg(dp, nullptr, 0);

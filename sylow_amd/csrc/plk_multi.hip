@@ -832,7 +832,10 @@ static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, s
       rc = miller_product_tree(pb2, p2inf + 1, qb2, q2inf + 1, 1, 1, wb, &pb, sd);
     }
   }
-  if (rc == SYLOW_HIP_OK) rc = g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
+  // one key and no weights: only the SUM of the hashes is needed -- they go projective straight into the summation tree's array
+  const bool hash_into_tree = one_key && !weights;
+  if (rc == SYLOW_HIP_OK) rc = hash_into_tree ? g1h::hash_to_g1_proj(msgs, msg_offsets, acc2, n, stream)
+                                              : g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
   if (rc == SYLOW_HIP_OK && weights) {                      // H_i <- w_i H_i (in place), sig_i -> w_i sig_i (scratch)
     rc = sylow_hip_g1_scalar_mul_batch(hxy, hinf, weights, hxy, hinf, n, stream);
     if (rc == SYLOW_HIP_OK) rc = sylow_hip_g1_scalar_mul_batch(sig_xy, sig_inf, weights, sw, swinf, n, stream);
@@ -847,7 +850,8 @@ static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, s
     rc = miller_product_tree(hxy, hinf, pk_xy, pk_inf, n, 1, wa, &pa, stream);
   } else if (rc == SYLOW_HIP_OK) {
     // one key: the other half collapses too -- e(-sum H, pk), one more single-pair loop
-    rc = g1h::sum(hxy, hinf, n, acc2, pa2, p2inf, 1, 0, /*negate=*/1, stream);
+    rc = hash_into_tree ? g1h::sum_tree(acc2, n, pa2, p2inf, 1, 0, /*negate=*/1, stream)
+                        : g1h::sum(hxy, hinf, n, acc2, pa2, p2inf, 1, 0, /*negate=*/1, stream);
     if (rc == SYLOW_HIP_OK) {
       plk::k_g2_set_column<<<1, 64, 0, st>>>(qa2, q2inf, 1, 0, pk_xy, pk_inf);
       rc = miller_product_tree(pa2, p2inf, qa2, q2inf, 1, 1, wa, &pa, stream);
