@@ -156,8 +156,8 @@ __global__ void HEAVY_BOUNDS k_g1_generator_mul(const u64* ks, const i32* __rest
 // ------------------------------------------------------------------ sum of a batch of G1 points ----------
 // sum_i P_i as a log-depth tree of complete additions on a projective scratch array acc [12][n] (canonical words): the G1 side of
 // aggregate verification (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen)).  init: affine + flags -> projective; level: element t
-// absorbs element t + h, in place (nobody else touches either); finish: element 0 -> affine, written to column `col` of an SoA
-// array of stride `stride`, optionally negated.
+// absorbs element t + h, in place (nobody else touches either); tail: the last levels in one block, then element 0 -> affine, written to
+// column `col` of an SoA array of stride `stride`, optionally negated.
 __global__ void __launch_bounds__(BLOCK) k_g1_sum_init(const u64* pxy, const uint8_t* pinf, u64* acc, size_t n) {
   size_t i = TID;
   if (i >= n) return;
@@ -174,8 +174,22 @@ __global__ void __launch_bounds__(BLOCK) k_g1_sum_level(u64* acc, size_t n, size
   const G1P r = g1_add(a, b);
   store_fp(acc, n, t, 0, r.x); store_fp(acc, n, t, 4, r.y); store_fp(acc, n, t, 8, r.z);
 }
-__global__ void k_g1_sum_finish(const u64* acc, size_t n, u64* oxy, uint8_t* oinf, size_t stride, size_t col, int negate) {
-  if (TID != 0) return;
+// the last levels (m <= 2 * BLOCK live elements) and the finish in ONE block: a level per barrier instead of a launch per level
+__global__ void __launch_bounds__(BLOCK) k_g1_sum_tail(u64* acc, size_t n, size_t m, u64* oxy, uint8_t* oinf, size_t stride, size_t col, int negate) {
+  const size_t t = threadIdx.x;
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    if (t + h < m) {
+      const G1P a{load_fp(acc, n, t, 0), load_fp(acc, n, t, 4), load_fp(acc, n, t, 8)};
+      const G1P b{load_fp(acc, n, t + h, 0), load_fp(acc, n, t + h, 4), load_fp(acc, n, t + h, 8)};
+      const G1P r = g1_add(a, b);
+      store_fp(acc, n, t, 0, r.x); store_fp(acc, n, t, 4, r.y); store_fp(acc, n, t, 8, r.z);
+    }
+    __threadfence_block();
+    __syncthreads();
+    m = h;
+  }
+  if (t != 0) return;
   const G1P p = n ? G1P{load_fp(acc, n, 0, 0), load_fp(acc, n, 0, 4), load_fp(acc, n, 0, 8)} : G1P{fp_zero(), fp_one(), fp_zero()};
   Fp x, y; bool inf;
   g1_to_affine(x, y, inf, p);
@@ -361,12 +375,12 @@ int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc,
 }
 int32_t sum_tree(uint64_t* acc, size_t n, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
   size_t m = n;
-  while (m > 1) {
+  while (m > 2 * BLOCK) {
     const size_t h = (m + 1) / 2;
     k_g1_sum_level<<<GRID(m - h)>>>(acc, n, m, h);
     m = h;
   }
-  k_g1_sum_finish<<<1, 64, 0, (hipStream_t)stream>>>(acc, n, out_xy, out_inf, stride, col, negate); LAUNCHED();
+  k_g1_sum_tail<<<1, BLOCK, 0, (hipStream_t)stream>>>(acc, n, m, out_xy, out_inf, stride, col, negate); LAUNCHED();
 }
 }  // namespace g1h
 

@@ -486,6 +486,34 @@ __global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* 
   }
   store_s12(out, n_out, i, odd, a);
 }
+// the last levels of a product tree (m <= BLOCK values, SoA stride `stride`, multiplied IN PLACE: value i absorbs value i + h, a level per
+// barrier instead of a launch per level); the product leaves in `out` with stride 1
+__global__ void HEAVY_BOUNDS k_fp12_tree_tail(u64* vals, size_t stride, size_t m, u64* out) {
+  const size_t i = threadIdx.x >> 1;
+  const int odd = (int)(threadIdx.x & 1);
+  while (m > 1) {
+    const size_t h = (m + 1) / 2;
+    if (i + h < m) {
+      S12 a, b;
+      load_s12(a, vals, stride, i, odd);
+      load_s12(b, vals, stride, i + h, odd);
+      W12 x, y, r;
+      w12_from_s12(x, a);
+      w12_from_s12(y, b);
+      w12_mul_nl(r, x, y);
+      w12_to_s12(a, r);
+      store_s12(vals, stride, i, odd, a);
+    }
+    __threadfence_block();
+    __syncthreads();
+    m = h;
+  }
+  if (i == 0) {
+    S12 a;
+    load_s12(a, vals, stride, 0, odd);
+    store_s12(out, 1, 0, odd, a);
+  }
+}
 // f = 1 (the empty Miller product), SoA stride 1
 __global__ void k_fp12_set_one(u64* out) {
   if (TID >= 2) return;
@@ -723,11 +751,15 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   else plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   u64 *cur = bufa, *nxt = bufb;
   size_t m = n_jobs;
-  while (m > 1) {
+  while (m > (size_t)BLOCK) {
     const size_t h = (m + 1) / 2;
     plk::k_fp12_tree_level<<<GRID(2 * h)>>>(cur, m, nxt, h);
     u64* tmp = cur; cur = nxt; nxt = tmp;
     m = h;
+  }
+  if (m > 1) {                                     // the rest of the tree in one block; the product lands in the other buffer, stride 1
+    plk::k_fp12_tree_tail<<<1, BLOCK, 0, st>>>(cur, m, m, nxt);
+    cur = nxt;
   }
   *result = cur;
   return SYLOW_HIP_OK;
@@ -887,11 +919,17 @@ int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64
   const u64* cur = parts;
   u64 *nxt = (u64*)ws.p, *other = nxt + n_a;
   size_t m = k;
-  while (m > 1) {
+  bool own = false;                                 // the caller's array is never multiplied in place: one out-of-place level first
+  while (m > 1 && (m > (size_t)BLOCK || !own)) {
     const size_t h = (m + 1) / 2;
     plk::k_fp12_tree_level<<<GRID(2 * h)>>>(cur, m, nxt, h);
     cur = nxt; u64* tmp = nxt; nxt = other; other = tmp;
     m = h;
+    own = true;
+  }
+  if (m > 1) {
+    plk::k_fp12_tree_tail<<<1, BLOCK, 0, st>>>((u64*)cur, m, m, nxt);
+    cur = nxt;
   }
   plk::k_final_exp_flag<<<1, 64, 0, st>>>(cur, 1, gt_out, is_one);
   return finish(ws);
