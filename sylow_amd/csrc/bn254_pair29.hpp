@@ -683,5 +683,118 @@ BN_NOINLINE void final_exponentiation29(S12& out, const S12& fin) {
   w12_to_s12(out, g);
 }
 
+
+// ---- ONE final exponentiation on a whole wavefront ("wide"): the tail of every one-boolean shape -----------------------------------
+// A single element on one lane pair is pure latency: the wavefront issues a multiply-add every ~8 cycles and 62 of its 64 lanes idle
+// (2.4-2.9 ms per final exponentiation).  Here ALL 32 lane pairs of a one-wavefront block hold the SAME element (replicated: same code,
+// same inputs), and the cyclotomic squarings of the three f^x chains -- 189 of them, six independent Fp2 products each -- are spread:
+// lane pair j < 6 forms product j, the products meet in LDS, lane pair j forms output coefficient j, the coefficients meet in LDS and
+// every lane pair holds the square again.  Same formulas, same operand classes and therefore the same digits as w12_cyclotomic_sqr.
+struct WideLds { i32 v[12][9][2]; };               // 6 products + 6 output coefficients, [slot][limb][lane parity]
+typedef __attribute__((address_space(3))) WideLds* WideLdsPtr;
+BN_DEV void wide_put(WideLdsPtr x, int slot, int odd, const W2& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x->v[slot][i][odd] = a.c.v[i];
+}
+BN_DEV W2 wide_get(WideLdsPtr x, int slot, int odd) {
+  W2 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.c.v[i] = x->v[slot][i][odd];
+  return r;
+}
+BN_DEV W2 w2_pick(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }                // c ? b : a
+BN_DEV W2 w2_sel3(int k, const W2& a, const W2& b, const W2& c) { return w2_pick(w2_pick(a, b, k == 1), c, k == 2); }
+BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  const int p = j < 6 ? j : 0, k = p >> 1;
+  const bool s = (p & 1) != 0;
+  const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  // product p: pair k of (z0, z1), (z2, z3), (z4, z5);  s = 0: m = a b,  s = 1: w = (a + b)(a + xi b)   (w_fp4_square)
+  {
+    const W2 a = w2_sel3(k, z0, z2, z4), b = w2_sel3(k, z1, z3, z5);
+    const W2 xs = w2_pick(a, w2_norm(w2_add(a, b)), s), ys = w2_pick(b, w2_xi_lin(b, 1, a, 1), s);
+    const W2 pr = w2_mul(xs, ys);
+    if (j < 6) wide_put(x, p, odd, pr);
+  }
+  __syncthreads();
+  // output p: 0: c0.c0 = 3 c0(0) - 2 z0   1: c1.c1 = 6 m(0) + 2 z1   2: c0.c1 = 3 c0(1) - 2 z4   3: c1.c2 = 6 m(1) + 2 z5
+  //           4: c1.c0 = 6 xi m(2) + 2 z2   5: c0.c2 = 3 c0(2) - 2 z3      with c0(k) = w(k) - m(k) - xi m(k)
+  {
+    const int ko = p >> 1;
+    const W2 m = wide_get(x, 2 * ko, odd), w = wide_get(x, 2 * ko + 1, odd);
+    const W2 z = p == 0 ? z0 : p == 1 ? z1 : p == 2 ? z4 : p == 3 ? z5 : p == 4 ? z2 : z3;
+    const W2 ra = w2_lin2(w2_xi_lin(m, -1, w2_sub(w, m), 1), 3, z, -2);
+    const W2 rb = w2_lin2(m, 6, z, 2);
+    const W2 rc = w2_xi_lin(m, 6, z, 2);
+    const W2 r = (p == 1 || p == 3) ? rb : p == 4 ? rc : ra;
+    if (j < 6) wide_put(x, 6 + p, odd, r);
+  }
+  __syncthreads();
+  W12 r;
+  r.c0.c0 = wide_get(x, 6, odd); r.c1.c1 = wide_get(x, 7, odd); r.c0.c1 = wide_get(x, 8, odd);
+  r.c1.c2 = wide_get(x, 9, odd); r.c1.c0 = wide_get(x, 10, odd); r.c0.c2 = wide_get(x, 11, odd);
+  return r;
+}
+// exp_by_neg_z29 with the loop's squarings spread over the wavefront (the products against the power table stay replicated)
+BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
+  const WideLdsPtr x = (WideLdsPtr)xg;
+  W12 tab[4];
+  tab[0] = f;
+  {
+    W12 f2;
+    w12_cyclotomic_sqr_nl(f2, f);
+    w12_mul_nl(tab[1], f2, f);
+    w12_mul_nl(tab[2], tab[1], f2);
+    w12_mul_nl(tab[3], tab[2], f2);
+  }
+  W12 res = f;
+  const u64 nz = BN_X_W4_NZ, ng = BN_X_W4_NEG, i0 = BN_X_W4_I0, i1 = BN_X_W4_I1;
+#pragma unroll 1
+  for (int i = 61; i >= 0; --i) {
+    res = w12_cyclotomic_sqr_wide(res, x);
+    if ((nz >> i) & 1) {
+      W12 m = tab[((i0 >> i) & 1) | (((i1 >> i) & 1) << 1)];
+      if ((ng >> i) & 1) m = w12_conj(m);
+      res = w12_mul(res, m);
+    }
+  }
+  r = w12_conj(res);
+}
+// final_exponentiation29 for a one-wavefront block whose 32 lane pairs all hold the same element
+BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* x) {
+  W12 in, t, a, b, d, e, g;
+  {
+    w12_from_s12(t, fin);
+    w12_inv_nl(b, t);
+    a = w12_conj(t);
+    w12_mul_nl(d, a, b);
+    w12_frobenius_nl<2>(a, d);
+    w12_mul_nl(in, a, d);
+  }
+  exp_by_neg_z29_wide(a, in, x);
+  w12_cyclotomic_sqr_nl(b, a);
+  w12_cyclotomic_sqr_nl(t, b);
+  w12_mul_nl(d, t, b);
+  exp_by_neg_z29_wide(e, d, x);
+  w12_cyclotomic_sqr_nl(t, e);
+  exp_by_neg_z29_wide(g, t, x);
+  d = w12_conj(d);
+  g = w12_conj(g);
+  w12_mul_nl(t, g, e);
+  w12_mul_nl(a, t, d);
+  w12_mul_nl(d, a, b);
+  w12_mul_nl(t, a, e);
+  w12_mul_nl(e, in, t);
+  w12_frobenius_nl<1>(t, d);
+  w12_mul_nl(b, t, e);
+  w12_frobenius_nl<2>(t, a);
+  w12_mul_nl(e, t, b);
+  t = w12_conj(in);
+  w12_mul_nl(a, t, d);
+  w12_frobenius_nl<3>(t, a);
+  w12_mul_nl(g, t, e);
+  w12_to_s12(out, g);
+}
+
 }  // namespace pl
 }  // namespace bn254

@@ -543,13 +543,17 @@ __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t c
   store_s2(qxy, stride, col, 8, odd, src_xy ? load_s2(src_xy, 1, 0, 8, odd) : s2_g2gen_y());
   if (!odd) qinf[col] = (src_xy && src_inf && src_inf[0]) ? 1 : 0;
 }
-__global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one) {
+// ONE element, launched as <<<1, 64>>>: all 32 lane pairs of the wavefront hold it and share the squarings of the hard part
+// (final_exponentiation29_wide); wide = 0: lane pair 0 alone (the plain routine, the other lanes leave)
+__global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one, int wide) {
+  __shared__ WideLds lds;
   const size_t t = TID;
   const int odd = (int)(t & 1);
-  if (t >= 2) return;
+  if (!wide && t >= 2) return;
   S12 f, g;
   if (n_in) load_s12(f, fin, n_in, 0, odd); else f = s12_one();      // empty product = identity (pairing.rs:1218-1219)
-  final_exponentiation29(g, f);
+  if (wide) final_exponentiation29_wide(g, f, &lds); else final_exponentiation29(g, f);
+  if (t >= 2) return;
   if (gout) store_s12(gout, 1, 0, odd, g);
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[0] = one ? 1 : 0;
@@ -648,6 +652,11 @@ static bool use_tables(size_t n_jobs, size_t n_pairs) {
   if (m == 0) return false;
   if (m == 1) return n_pairs != 0;
   return n_pairs >= 2 * n_jobs;
+}
+// SYLOW_HIP_WIDE_TAIL=0: the single final exponentiation of the one-boolean shapes on one lane pair (default: on the whole wavefront)
+static int wide_tail() {
+  static const int v = [] { const char* e = getenv("SYLOW_HIP_WIDE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
 }
 static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                     size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
@@ -773,12 +782,12 @@ int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_i
                                         size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK((gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy)));
   hipStream_t st = (hipStream_t)stream;
-  if (n_pairs == 0) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(nullptr, 0, gt_out, is_one); LAUNCHED(); }
+  if (n_pairs == 0) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(nullptr, 0, gt_out, is_one, wide_tail()); LAUNCHED(); }
   host::Lease ws;
   u64* prod = nullptr;
   int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, skip_infinity, ws, &prod, stream);
   if (rc != SYLOW_HIP_OK) return rc;
-  plk::k_final_exp_flag<<<1, 64, 0, st>>>(prod, 1, gt_out, is_one);
+  plk::k_final_exp_flag<<<1, 64, 0, st>>>(prod, 1, gt_out, is_one, wide_tail());
   return finish(ws);
 }
 int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
@@ -911,7 +920,7 @@ int32_t sylow_hip_bls_weighted_partial_batch(const uint64_t* pk_xy, const uint8_
 int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK((gt_out || is_one) && (parts || !k));
   hipStream_t st = (hipStream_t)stream;
-  if (k <= 1) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(parts, k, gt_out, is_one); LAUNCHED(); }
+  if (k <= 1) { plk::k_final_exp_flag<<<1, 64, 0, st>>>(parts, k, gt_out, is_one, wide_tail()); LAUNCHED(); }
   host::Lease ws;
   const size_t n_a = 48 * ((k + 1) / 2), n_b = 48 * ((k + 3) / 4);
   int32_t rc = ws.acquire((n_a + n_b) * sizeof(u64), st);
@@ -931,7 +940,7 @@ int32_t sylow_hip_fp12_product_final_exp(const uint64_t* parts, size_t k, uint64
     plk::k_fp12_tree_tail<<<1, BLOCK, 0, st>>>((u64*)cur, m, m, nxt);
     cur = nxt;
   }
-  plk::k_final_exp_flag<<<1, 64, 0, st>>>(cur, 1, gt_out, is_one);
+  plk::k_final_exp_flag<<<1, 64, 0, st>>>(cur, 1, gt_out, is_one, wide_tail());
   return finish(ws);
 }
 
