@@ -690,7 +690,7 @@ BN_NOINLINE void final_exponentiation29(S12& out, const S12& fin) {
 // same inputs), and the cyclotomic squarings of the three f^x chains -- 189 of them, six independent Fp2 products each -- are spread:
 // lane pair j < 6 forms product j, the products meet in LDS, lane pair j forms output coefficient j, the coefficients meet in LDS and
 // every lane pair holds the square again.  Same formulas, same operand classes and therefore the same digits as w12_cyclotomic_sqr.
-struct WideLds { i32 v[12][9][2]; };               // 6 products + 6 output coefficients, [slot][limb][lane parity]
+struct WideLds { i32 v[63][9][2]; };               // [slot][limb][lane parity]; squaring: 6 products + 6 outputs; product: slots 12 .. 62
 typedef __attribute__((address_space(3))) WideLds* WideLdsPtr;
 BN_DEV void wide_put(WideLdsPtr x, int slot, int odd, const W2& a) {
 #pragma unroll
@@ -735,7 +735,69 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
   r.c1.c2 = wide_get(x, 9, odd); r.c1.c0 = wide_get(x, 10, odd); r.c0.c2 = wide_get(x, 11, odd);
   return r;
 }
-// exp_by_neg_z29 with the loop's squarings spread over the wavefront (the products against the power table stay replicated)
+// a * b with the 18 products of the Karatsuba-over-Karatsuba form (w12_mul / w6_mul) on 18 lane pairs.  Inputs and result replicated.
+// Slots: the operands' coefficients IA / IB (lane pair c < 6 writes coefficient c of each), the coefficient sums of the third Fp6 product
+// SA / SB, the products P[6 g + h] (g: which Fp6 product, h: v0 v1 v2 and the three cross products), the nine Fp6 coefficients T[3 g + c],
+// the six outputs.  Every value goes through exactly the operations of w12_mul, so the digits are the same.
+constexpr int WL_IA = 12, WL_IB = 18, WL_SA = 24, WL_SB = 27, WL_P = 30, WL_T = 48, WL_OUT = 57;
+BN_DEV W2 w12_coef(const W12& a, int c) {      // c = 3 * half + i
+  const W2 lo = w2_sel3(c % 3, a.c0.c0, a.c0.c1, a.c0.c2), hi = w2_sel3(c % 3, a.c1.c0, a.c1.c1, a.c1.c2);
+  return w2_pick(lo, hi, c >= 3);
+}
+BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  {   // stage 0: coefficients and the sums a.c0 + a.c1, b.c0 + b.c1 into LDS
+    const int c = j < 6 ? j : 0;
+    const W2 ac = w12_coef(a, c), bc = w12_coef(b, c);
+    const int i = c % 3;
+    const W2 sa = w2_norm(w2_add(w2_sel3(i, a.c0.c0, a.c0.c1, a.c0.c2), w2_sel3(i, a.c1.c0, a.c1.c1, a.c1.c2)));
+    const W2 sb = w2_norm(w2_add(w2_sel3(i, b.c0.c0, b.c0.c1, b.c0.c2), w2_sel3(i, b.c1.c0, b.c1.c1, b.c1.c2)));
+    if (j < 6) { wide_put(x, WL_IA + c, odd, ac); wide_put(x, WL_IB + c, odd, bc); }
+    if (j < 3) wide_put(x, WL_SA + i, odd, sa);
+    if (j >= 3 && j < 6) wide_put(x, WL_SB + i, odd, sb);
+  }
+  __syncthreads();
+  {   // stage 1: product w = 6 g + h
+    const int w = j < 18 ? j : 0, g = w / 6, h = w % 6;
+    const int i0 = h < 3 ? h : h == 3 ? 1 : 0, i1 = h < 3 ? h : h == 4 ? 1 : 2;
+    const int ba = g == 0 ? WL_IA : g == 1 ? WL_IA + 3 : WL_SA, bb = g == 0 ? WL_IB : g == 1 ? WL_IB + 3 : WL_SB;
+    const W2 xa = wide_get(x, ba + i0, odd), xb = wide_get(x, ba + i1, odd);
+    const W2 ya = wide_get(x, bb + i0, odd), yb = wide_get(x, bb + i1, odd);
+    const W2 xs = w2_pick(xa, w2_norm(w2_add(xa, xb)), h >= 3), ys = w2_pick(ya, w2_norm(w2_add(ya, yb)), h >= 3);
+    const W2 pr = w2_mul(xs, ys);
+    if (j < 18) wide_put(x, WL_P + w, odd, pr);
+  }
+  __syncthreads();
+  {   // stage 2: Fp6 coefficient u = 3 g + c of the three Fp6 products (w6_mul)
+    const int u = j < 9 ? j : 0, g = u / 3, c = u % 3, base = WL_P + 6 * g;
+    const W2 v0 = wide_get(x, base, odd), v1 = wide_get(x, base + 1, odd), v2 = wide_get(x, base + 2, odd), q = wide_get(x, base + 3 + c, odd);
+    const W2 r0 = w2_xi_lin(w2_sub(w2_sub(q, v1), v2), 1, v0, 1);               // v0 + xi (q0 - v1 - v2)
+    const W2 r1 = w2_xi_lin(v2, 1, w2_sub(w2_sub(q, v0), v1), 1);               // (q1 - v0 - v1) + xi v2
+    const W2 r2 = w2_reduce(w2_add(w2_sub(w2_sub(q, v0), v2), v1));             // q2 - v0 - v2 + v1
+    if (j < 9) wide_put(x, WL_T + u, odd, w2_sel3(c, r0, r1, r2));
+  }
+  __syncthreads();
+  {   // stage 3: output o (w12_mul): c1.ci = T2.ci - T0.ci - T1.ci;  c0.c0 = T0.c0 + xi T1.c2;  c0.c1 = T0.c1 + T1.c0;  c0.c2 = T0.c2 + T1.c1
+    const int o = j < 6 ? j : 0, i = o % 3;
+    const int pa = o >= 3 ? i : o, pb = o >= 3 ? 3 + i : o == 0 ? 5 : o == 1 ? 3 : 4, pc = o >= 3 ? 6 + i : 0;
+    const W2 ta = wide_get(x, WL_T + pa, odd), tb = wide_get(x, WL_T + pb, odd), tc = wide_get(x, WL_T + pc, odd);
+    const W2 ra = w2_lin2(w2_sub(tc, ta), 1, tb, -1);
+    const W2 rb = w2_xi_lin(tb, 1, ta, 1);
+    const W2 rc = w2_norm(w2_add(ta, tb));
+    if (j < 6) wide_put(x, WL_OUT + o, odd, o >= 3 ? ra : o == 0 ? rb : rc);
+  }
+  __syncthreads();
+  W12 r;
+  r.c0.c0 = wide_get(x, WL_OUT, odd); r.c0.c1 = wide_get(x, WL_OUT + 1, odd); r.c0.c2 = wide_get(x, WL_OUT + 2, odd);
+  r.c1.c0 = wide_get(x, WL_OUT + 3, odd); r.c1.c1 = wide_get(x, WL_OUT + 4, odd); r.c1.c2 = wide_get(x, WL_OUT + 5, odd);
+  return r;
+}
+BN_NOINLINE void w12_mul_wide_nl(W12& r, const W12& a, const W12& b, WideLds* xg) {
+  W12 p = a, q = b;
+  w12_pin(p); w12_pin(q);
+  r = w12_mul_wide(p, q, (WideLdsPtr)xg);
+}
+// exp_by_neg_z29 with the loop's squarings and products spread over the wavefront
 BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
   const WideLdsPtr x = (WideLdsPtr)xg;
   W12 tab[4];
@@ -743,9 +805,9 @@ BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
   {
     W12 f2;
     w12_cyclotomic_sqr_nl(f2, f);
-    w12_mul_nl(tab[1], f2, f);
-    w12_mul_nl(tab[2], tab[1], f2);
-    w12_mul_nl(tab[3], tab[2], f2);
+    w12_mul_wide_nl(tab[1], f2, f, xg);
+    w12_mul_wide_nl(tab[2], tab[1], f2, xg);
+    w12_mul_wide_nl(tab[3], tab[2], f2, xg);
   }
   W12 res = f;
   const u64 nz = BN_X_W4_NZ, ng = BN_X_W4_NEG, i0 = BN_X_W4_I0, i1 = BN_X_W4_I1;
@@ -755,7 +817,7 @@ BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
     if ((nz >> i) & 1) {
       W12 m = tab[((i0 >> i) & 1) | (((i1 >> i) & 1) << 1)];
       if ((ng >> i) & 1) m = w12_conj(m);
-      res = w12_mul(res, m);
+      res = w12_mul_wide(res, m, x);
     }
   }
   r = w12_conj(res);
@@ -767,32 +829,32 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
     w12_from_s12(t, fin);
     w12_inv_nl(b, t);
     a = w12_conj(t);
-    w12_mul_nl(d, a, b);
+    w12_mul_wide_nl(d, a, b, x);
     w12_frobenius_nl<2>(a, d);
-    w12_mul_nl(in, a, d);
+    w12_mul_wide_nl(in, a, d, x);
   }
   exp_by_neg_z29_wide(a, in, x);
   w12_cyclotomic_sqr_nl(b, a);
   w12_cyclotomic_sqr_nl(t, b);
-  w12_mul_nl(d, t, b);
+  w12_mul_wide_nl(d, t, b, x);
   exp_by_neg_z29_wide(e, d, x);
   w12_cyclotomic_sqr_nl(t, e);
   exp_by_neg_z29_wide(g, t, x);
   d = w12_conj(d);
   g = w12_conj(g);
-  w12_mul_nl(t, g, e);
-  w12_mul_nl(a, t, d);
-  w12_mul_nl(d, a, b);
-  w12_mul_nl(t, a, e);
-  w12_mul_nl(e, in, t);
+  w12_mul_wide_nl(t, g, e, x);
+  w12_mul_wide_nl(a, t, d, x);
+  w12_mul_wide_nl(d, a, b, x);
+  w12_mul_wide_nl(t, a, e, x);
+  w12_mul_wide_nl(e, in, t, x);
   w12_frobenius_nl<1>(t, d);
-  w12_mul_nl(b, t, e);
+  w12_mul_wide_nl(b, t, e, x);
   w12_frobenius_nl<2>(t, a);
-  w12_mul_nl(e, t, b);
+  w12_mul_wide_nl(e, t, b, x);
   t = w12_conj(in);
-  w12_mul_nl(a, t, d);
+  w12_mul_wide_nl(a, t, d, x);
   w12_frobenius_nl<3>(t, a);
-  w12_mul_nl(g, t, e);
+  w12_mul_wide_nl(g, t, e, x);
   w12_to_s12(out, g);
 }
 
