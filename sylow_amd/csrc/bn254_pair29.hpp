@@ -858,5 +858,47 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
   w12_to_s12(out, g);
 }
 
+// The Miller loop of ONE pair on a whole wavefront (the other tail of the one-boolean shapes): the G2 steps run replicated, the
+// accumulator's squaring and its product with each line are w12_mul_wide -- a line (l0, l4 = l1 y_P, l2 = l2 x_P) is the Fp12 element
+// (l0, 0, l2; 0, l4, 0) of mul_by_024 (fp12.rs:426-503), and spread over 18 lane pairs the dense product costs less than the 13-product
+// sparse form on one.  Same field values step by step, so the raw Miller value (canonical at the exit) is the reference's.
+BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys, WideLds* xg) {
+  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
+  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+  const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+  G2W r{qx, qy, w2_from_s2(s2_one())};
+  W12 f;
+  {
+    S12 one = s12_one();
+    w12_from_s12(f, one);
+  }
+  W2 l0, l1, l2;
+  auto line = [&]() {
+    W12 ln;
+    ln.c0.c0 = l0; ln.c0.c1 = zero; ln.c0.c2 = w2_scale(l2, px);
+    ln.c1.c0 = zero; ln.c1.c1 = w2_scale(l1, py); ln.c1.c2 = zero;
+    w12_mul_wide_nl(f, f, ln, xg);
+  };
+  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    w12_mul_wide_nl(f, f, f, xg);
+    g2_doubling_step29(r, l0, l1, l2);
+    line();
+    if ((nz >> (63 - i)) & 1) {
+      g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
+      line();
+    }
+  }
+  S2 q1x, q1y, q2x, q2y;
+  g2_psi_affine(q1x, q1y, qxs, qys);
+  g2_psi_affine(q2x, q2y, q1x, q1y);
+  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  line();
+  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+  line();
+  w12_to_s12(fout, f);
+}
+
 }  // namespace pl
 }  // namespace bn254

@@ -543,6 +543,22 @@ __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t c
   store_s2(qxy, stride, col, 8, odd, src_xy ? load_s2(src_xy, 1, 0, 8, odd) : s2_g2gen_y());
   if (!odd) qinf[col] = (src_xy && src_inf && src_inf[0]) ? 1 : 0;
 }
+// The raw Miller value of ONE pair (SoA stride-1 views of P, Q and the output), launched as <<<1, 64>>>: miller_loop29_wide.  An identity
+// on either side gives 1 (the skip_infinity reading; the reference-replay reading of a G2 identity stays on the generic kernels).
+__global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* fout) {
+  __shared__ WideLds lds;
+  const size_t t = TID;
+  const int odd = (int)(t & 1);
+  S12 f;
+  if ((pinf && pinf[0]) || (qinf && qinf[0])) {
+    f = s12_one();
+  } else {
+    const Fp px = load_fp(pxy, 1, 0, 0), py = load_fp(pxy, 1, 0, 4);
+    const S2 qx = load_s2(qxy, 1, 0, 0, odd), qy = load_s2(qxy, 1, 0, 8, odd);
+    miller_loop29_wide(f, px, py, qx, qy, &lds);
+  }
+  if (t < 2) store_s12(fout, 1, 0, odd, f);
+}
 // ONE element, launched as <<<1, 64>>>: all 32 lane pairs of the wavefront hold it and share the squarings of the hard part
 // (final_exponentiation29_wide); wide = 0: lane pair 0 alone (the plain routine, the other lanes leave)
 __global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one, int wide) {
@@ -750,6 +766,12 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   int32_t rc = ws.acquire((n_off + n_a + n_b) * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
+  // ONE pair (the collapsed halves of the aggregate verifiers): pure latency on one lane pair -- the whole wavefront takes it
+  if (n_pairs == 1 && skip_infinity && wide_tail() && !host::single_lane()) {
+    plk::k_miller_single_wide<<<1, 64, 0, st>>>(p_xy, p_inf, q_xy, q_inf, bufa);
+    *result = bufa;
+    return SYLOW_HIP_OK;
+  }
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk);
   // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
   if (chunk >= 2 && multi_tables_mode() != 0) {
