@@ -231,13 +231,15 @@ def test_both_multi_pair_routes_pass_the_same_tests(mode):
     """SYLOW_HIP_MULTI_TABLES=0 forces the in-register shared-squaring schedule for every job size, =1 the lines-to-HBM + table-driven
     route; the default picks by the batch's average job size, so neither is covered for all shapes by the plain run.
     Each route must pass this whole file and the EIP-197 vectors (the in-register route also the aggregate products, there with
-    SYLOW_HIP_AGG_FORK=0 as well: the aggregate verifiers without their side stream)."""
+    SYLOW_HIP_AGG_FORK=0 and SYLOW_HIP_WIDE_TAIL=0 as well: the aggregate verifiers without their side stream and with the single-element
+    Miller loop / final exponentiation on one lane pair)."""
     if os.environ.get("SYLOW_HIP_MULTI_TABLES") is not None or os.environ.get("SYLOW_HIP_SINGLE_LANE"):
         pytest.skip("already inside a forced-route / single-lane run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SYLOW_HIP_MULTI_TABLES=mode)
     if mode == "0":
         env["SYLOW_HIP_AGG_FORK"] = "0"
+        env["SYLOW_HIP_WIDE_TAIL"] = "0"         # and the single-element tails on one lane pair instead of the whole wavefront
     # mode 0 also re-runs the batch-wide products (their chunks take the table route by default); mode 1 sends one-pair jobs through tables
     files = ["tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py"] + (["tests/test_gpu_aggregate.py"] if mode == "0" else [])
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files,
