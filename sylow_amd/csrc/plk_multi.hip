@@ -462,11 +462,13 @@ __global__ void HEAVY_BOUNDS k_final_exp_jobs(const u64* fin, size_t n_in, size_
 // values ((prod f_i)^2 = prod f_i^2), so the batch is cut into chunks of KPROD pairs per lane pair (k_multi_pairing with
 // raw_miller = 1), the chunk values are multiplied together by a log-depth tree of Fp12 products, and one lane pair runs the
 // final exponentiation.
-__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs, size_t chunk) {
+// range (device, NULL = [0, n_pairs)): the product covers pairs [range[0], range[1]) only -- one job of a multi-pairing batch
+__global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs, size_t chunk, const u64* range) {
   const size_t j = TID;
   if (j > n_jobs) return;
-  const size_t v = j * chunk;
-  off[j] = v < n_pairs ? v : n_pairs;
+  const size_t lo = range ? (size_t)range[0] : 0, hi = range ? (size_t)range[1] : n_pairs;
+  const size_t v = lo + j * chunk;
+  off[j] = v < hi ? v : (hi > lo ? hi : lo);
 }
 // out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out
 __global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* out, size_t n_out) {
@@ -545,16 +547,18 @@ __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t c
 }
 // The raw Miller value of ONE pair (SoA stride-1 views of P, Q and the output), launched as <<<1, 64>>>: miller_loop29_wide.  An identity
 // on either side gives 1 (the skip_infinity reading; the reference-replay reading of a G2 identity stays on the generic kernels).
-__global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* fout) {
+__global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, size_t stride, const u64* range, u64* fout) {
   __shared__ WideLds lds;
   const size_t t = TID;
   const int odd = (int)(t & 1);
+  const size_t i = range ? (size_t)range[0] : 0;
+  const bool empty = range && range[1] <= range[0];
   S12 f;
-  if ((pinf && pinf[0]) || (qinf && qinf[0])) {
+  if (empty || (pinf && pinf[i]) || (qinf && qinf[i])) {
     f = s12_one();
   } else {
-    const Fp px = load_fp(pxy, 1, 0, 0), py = load_fp(pxy, 1, 0, 4);
-    const S2 qx = load_s2(qxy, 1, 0, 0, odd), qy = load_s2(qxy, 1, 0, 8, odd);
+    const Fp px = load_fp(pxy, stride, i, 0), py = load_fp(pxy, stride, i, 4);
+    const S2 qx = load_s2(qxy, stride, i, 0, odd), qy = load_s2(qxy, stride, i, 8, odd);
     miller_loop29_wide(f, px, py, qx, qy, &lds);
   }
   if (t < 2) store_s12(fout, 1, 0, odd, f);
@@ -674,6 +678,9 @@ static int wide_tail() {
   static const int v = [] { const char* e = getenv("SYLOW_HIP_WIDE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
 }
+static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity);
+static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
+                                  size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream);
 static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                     size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -721,6 +728,7 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
+  if (single_job_route(n_jobs, n_pairs, skip_infinity)) return single_job_product(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_pairs, gt_out, is_one, stream);
   if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, stream);
   // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
   // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
@@ -753,7 +761,7 @@ int32_t sylow_hip_glued_miller_loop_precomputed_batch(const uint64_t* coeffs, si
 // Chunked Miller loops + product tree: leaves ONE raw Miller product (SoA stride 1 = 48 contiguous words) in the leased workspace.
 // n_pairs > 0.  The caller releases the lease after enqueueing whatever consumes *result.
 static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, size_t n_pairs,
-                                   int32_t skip_infinity, host::Lease& ws, u64** result, void* stream) {
+                                   int32_t skip_infinity, host::Lease& ws, u64** result, void* stream, const u64* range = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   // pairs per lane pair: as few as keep the whole product inside ONE round of the GPU (2^16 lane pairs resident), at most KPROD --
   // a small product is latency-bound (one pair per lane pair on the single-pair loop: one Miller loop deep), a large one
@@ -768,11 +776,11 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
   // ONE pair (the collapsed halves of the aggregate verifiers): pure latency on one lane pair -- the whole wavefront takes it
   if (n_pairs == 1 && skip_infinity && wide_tail() && !host::single_lane()) {
-    plk::k_miller_single_wide<<<1, 64, 0, st>>>(p_xy, p_inf, q_xy, q_inf, bufa);
+    plk::k_miller_single_wide<<<1, 64, 0, st>>>(p_xy, p_inf, q_xy, q_inf, 1, range, bufa);
     *result = bufa;
     return SYLOW_HIP_OK;
   }
-  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk);
+  plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk, range);
   // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
   if (chunk >= 2 && multi_tables_mode() != 0) {
     rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, stream);
@@ -799,6 +807,21 @@ static int32_t finish(host::Lease& ws) {
   const hipError_t e = hipGetLastError();
   const int32_t rc = ws.release();
   return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
+}
+// ONE job (a single ecPairing call, a single Groth16-style check): every pair on a lane pair of its own, a product tree, and the final
+// exponentiation on the whole wavefront -- one Miller loop deep instead of k (4 pairs: 7.9 -> 3.3 ms).  The job's pair range stays on the
+// device (pair_offsets[0 .. 1]).  EIP-197 reading of identities only (skip_infinity).
+static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity) {
+  return n_jobs == 1 && n_pairs >= 1 && skip_infinity && wide_tail() && !host::single_lane();
+}
+static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
+                                  size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  host::Lease ws;
+  u64* prod = nullptr;
+  int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, 1, ws, &prod, stream, pair_offsets);
+  if (rc != SYLOW_HIP_OK) return rc;
+  plk::k_final_exp_flag<<<1, 64, 0, (hipStream_t)stream>>>(prod, 1, gt_out, is_one, wide_tail());
+  return finish(ws);
 }
 int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
                                         size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream) {
@@ -986,6 +1009,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
     if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
+    else if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_pairs, nullptr, isone, stream);
     else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, stream);
     else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);

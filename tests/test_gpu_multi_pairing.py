@@ -226,6 +226,34 @@ def test_ragged_jobs_against_per_pair_miller_values(engine):
     assert np.array_equal(is_one.astype(bool), (sizes == 0))           # only the empty product is the identity here
 
 
+def test_single_job_route_equals_the_generic_one(engine, coracle):
+    """A batch of ONE job with skip_infinity (a single ecPairing call) takes a route of its own: every pair on its own lane pair, a
+    product tree, the final exponentiation on a whole wavefront.  Its job may be any sub-range of the pair arrays, empty included, with
+    identities inside: same Gt and flag as the same job inside a two-job batch (the generic kernels) and as the oracle."""
+    rng = Xoshiro(SEED + 77)
+    n = 14
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs([rng.fp() for _ in range(n)]))
+    pinf = np.zeros(n, np.uint8); qinf = np.zeros(n, np.uint8)
+    pinf[4] = 1; qinf[7] = 1
+    one = np.zeros((1, 48), np.uint64); one[0, 0] = 1
+    for lo, hi in ((0, 1), (2, 3), (2, 4), (3, 6), (1, 9), (0, 14), (5, 5), (4, 5), (7, 8)):
+        g1, o1 = engine.multi_pairing(p, q, [lo, hi], p_inf=pinf, q_inf=qinf, skip_infinity=True)
+        g2, o2 = engine.multi_pairing(p, q, [lo, hi, hi], p_inf=pinf, q_inf=qinf, skip_infinity=True)
+        assert np.array_equal(g1, g2[:1]) and o1[0] == o2[0], (lo, hi)
+        live = [i for i in range(lo, hi) if not (pinf[i] or qinf[i])]
+        if live:
+            exp = coracle.glued_pairing(proj1(p[live]), proj2(q[live]), np.array([0, len(live)], dtype=np.uint64))
+            assert np.array_equal(g1, exp), (lo, hi)
+        else:
+            assert np.array_equal(g1, one) and o1[0] == 1, (lo, hi)
+    # e(aP, Q) e(-aP, Q) = 1 through the single-job route
+    pp = np.concatenate([p[:1], p[:1]])
+    pp[1, 4:] = engine.fp_neg(p[:1, 4:])[0]
+    _, o = engine.multi_pairing(pp, np.concatenate([q[:1], q[:1]]), [0, 2], skip_infinity=True)
+    assert o[0] == 1
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_both_multi_pair_routes_pass_the_same_tests(mode):
     """SYLOW_HIP_MULTI_TABLES=0 forces the in-register shared-squaring schedule for every job size, =1 the lines-to-HBM + table-driven
