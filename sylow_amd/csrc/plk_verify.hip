@@ -291,6 +291,9 @@ static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf
                                     const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::bls_verify_fused(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
+  // ONE verification is pure latency on one lane pair (6.5 ms): as a one-element aggregate -- the same product e(sig, G2gen) e(-H, pk),
+  // the same reading of identities -- its two Miller loops and the final exponentiation run on whole wavefronts (3.2 ms)
+  if (n == 1) return sylow_hip_bls_aggregate_verify_batch(pk_xy, pk_inf, 1, msgs, msg_offsets, sig_xy, sig_inf, 1, nullptr, nullptr, ok, stream);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);

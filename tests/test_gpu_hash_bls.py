@@ -63,6 +63,26 @@ def test_sign_verify_vs_oracle(engine, coracle):
         assert verify(pk_xy, msgs, sig_xy, pk_inf=inf, sig_inf=inf).tolist() == [1] * n
 
 
+def test_single_verification_equals_the_batch_kernel(engine):
+    """A batch of ONE verification takes the latency route (a one-element aggregate on whole wavefronts): element by element it must give the
+    flag the batch kernel gives for the same tuple -- valid, corrupted, every combination of identity flags, a key outside the r-torsion."""
+    rng = Xoshiro(SEED + 31)
+    msgs = messages()[:8]
+    n = len(msgs)
+    sk = limbs([rng.fp() for _ in range(n)])
+    sig, _ = engine.bls_sign(sk, msgs)
+    pk, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    bad, _ = engine.g1_add(sig, np.repeat(pack([1, 2], 8), n, 0))
+    mixed = sig.copy(); mixed[[1, 5]] = bad[[1, 5]]
+    pk2 = pk.copy(); pk2[3] = pk[4]                                       # wrong key
+    pinf = np.array([0, 0, 1, 0, 0, 1, 0, 1], np.uint8); sinf = np.array([0, 0, 0, 1, 0, 1, 0, 0], np.uint8)
+    for keys, sigs, kw in ((pk, sig, {}), (pk, mixed, {}), (pk2, sig, {}), (pk, mixed, dict(pk_inf=pinf, sig_inf=sinf))):
+        batch = engine.bls_verify(keys, msgs, sigs, **kw)
+        for i in range(n):
+            one_kw = {k: v[i:i + 1] for k, v in kw.items()}
+            assert engine.bls_verify(keys[i:i + 1], msgs[i:i + 1], sigs[i:i + 1], **one_kw)[0] == batch[i], (i, kw.keys())
+
+
 def test_verify_batch_planted_pattern_large(engine):
     """2^12 tuples, 1/64 corrupted at PRNG-chosen indices: flags must equal the planted pattern, and
     the device-side AND (flags_all) must see it."""
