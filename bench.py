@@ -284,6 +284,22 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs=None):
             "kernel": "k_evm_decode_pairs + plk::k_pair_lines + plk::k_glued_from_tables + plk::k_final_exp_jobs"}
     for name, e in res.items():                      # both roofs for every configuration
         e.update(issue_fields((pmc_cfgs or {}).get(name)))
+    # C1 (BASELINE.json configs[0], the reference's own bench shapes benches/pairing.rs:5-10, benches/sig.rs:10-21) as SINGLE device calls:
+    # latency, not throughput -- one Miller loop / final exponentiation spread over a wavefront ("the tails")
+    p1 = eng.empty((8, 1)).upload(np.ascontiguousarray(p.download()[:, :1]))
+    q1 = eng.empty((16, 1)).upload(np.ascontiguousarray(q.download()[:, :1]))
+    gt1 = eng.empty((48, 1))
+    msg = np.frombuffer((20).to_bytes(4, "big"), dtype=np.uint8).copy()
+    dm, doff = eng.to_device(msg), eng.to_device(np.array([0, 4], dtype=np.uint64))
+    sk1 = eng.empty((4, 1)).upload(eng.xoshiro_fp_soa(SEED, 1))
+    g2 = eng.empty((16, 1)).upload(limbs_row(G2).T.copy())
+    pk1, pk1i, sig1, sig1i, ok1 = eng.empty((16, 1)), eng.empty((1,), np.uint8), eng.empty((8, 1)), eng.empty((1,), np.uint8), eng.empty((1,), np.uint8)
+    eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2.ptr, None, sk1.ptr, pk1.ptr, pk1i.ptr, 1)
+    t_pair = hip_timed(torch, stream, lambda: eng._call("sylow_hip_pairing_batch", p1.ptr, None, q1.ptr, None, gt1.ptr, 1), 5)
+    t_sign = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_sign_batch", sk1.ptr, dm.ptr, doff.ptr, sig1.ptr, sig1i.ptr, 1), 5)
+    t_ver = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_verify_batch", pk1.ptr, None, dm.ptr, doff.ptr, sig1.ptr, None, ok1.ptr, 1), 5)
+    res["C1_single_calls"] = {"pairing_ms": t_pair * 1e3, "sign_ms": t_sign * 1e3, "verify_ms": t_ver * 1e3, "verify_ok": int(ok1.download()[0]),
+                              "note": "one element per call, HIP-event timed: latency of the single-wavefront routes"}
     return res
 
 

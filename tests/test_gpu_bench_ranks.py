@@ -83,3 +83,5 @@ def test_single_rank_bench_self_check():
     assert all(v["pattern_ok"] == 1 for k, v in cfg.items() if k.startswith("C5_"))
     assert out["aux"]["bls_all_valid"] == 1 and out["aux"]["aggregate_all_valid"] == 1 and out["aux"]["aggregate_same_signer_all_valid"] == 1
     assert "C2c_g2_scalar_mul_2^13" in cfg
+    c1 = cfg["C1_single_calls"]                         # one pairing / sign / verify per call: the single-wavefront latency routes
+    assert c1["verify_ok"] == 1 and 0 < c1["pairing_ms"] < 50 and 0 < c1["verify_ms"] < 50
