@@ -563,6 +563,49 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
   }
   if (t < 2) store_s12(fout, 1, 0, odd, f);
 }
+// Small batches, one WAVEFRONT per element (grid = n blocks of 64): block b takes pair b of set A, block n + b pair b of set B (B optional).
+// qxy NULL = the G2 generator for every pair of that set.  An identity on either side gives 1.  Raw Miller values, SoA stride n.
+__global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
+                                                 const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n) {
+  __shared__ WideLds lds;
+  const bool second = blockIdx.x >= n;
+  const size_t i = second ? blockIdx.x - n : blockIdx.x;
+  const u64 *pxy = second ? pb : pa, *qxy = second ? qb : qa;
+  const uint8_t *pinf = second ? pb_inf : pa_inf, *qinf = second ? qb_inf : qa_inf;
+  u64* fout = second ? fb : fa;
+  const int odd = (int)(threadIdx.x & 1);
+  S12 f;
+  if ((pinf && pinf[i]) || (qinf && qinf[i])) {
+    f = s12_one();
+  } else {
+    const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+    const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
+    miller_loop29_wide(f, px, py, qx, qy, &lds);
+  }
+  if (threadIdx.x < 2) store_s12(fout, n, i, odd, f);
+}
+// final_exponentiation(fa_b * fb_b) (fb optional), one wavefront per element: Gt values (SoA stride n) and / or "== identity" flags
+__global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb, size_t n, u64* gout, uint8_t* is_one) {
+  __shared__ WideLds lds;
+  const size_t i = blockIdx.x;
+  const int odd = (int)(threadIdx.x & 1);
+  S12 f, g;
+  load_s12(f, fa, n, i, odd);
+  if (fb) {
+    S12 h;
+    load_s12(h, fb, n, i, odd);
+    W12 x, y, r;
+    w12_from_s12(x, f);
+    w12_from_s12(y, h);
+    w12_mul_wide_nl(r, x, y, &lds);
+    w12_to_s12(f, r);
+  }
+  final_exponentiation29_wide(g, f, &lds);
+  if (threadIdx.x >= 2) return;
+  if (gout) store_s12(gout, n, i, odd, g);
+  const bool one = s12_is_one(g);
+  if (is_one && !odd) is_one[i] = one ? 1 : 0;
+}
 // ONE element, launched as <<<1, 64>>>: all 32 lane pairs of the wavefront hold it and share the squarings of the hard part
 // (final_exponentiation29_wide); wide = 0: lane pair 0 alone (the plain routine, the other lanes leave)
 __global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one, int wide) {
@@ -678,6 +721,27 @@ static int wide_tail() {
   static const int v = [] { const char* e = getenv("SYLOW_HIP_WIDE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
 }
+namespace plkh {
+// Small batches on one wavefront per element (k_miller_wide_batch / k_final_exp_wide_batch): up to this many elements the latency route
+// beats the one-lane-pair kernels (2 n + n blocks against 2048 resident wavefronts; measured crossover ~ 3 k verifications)
+size_t wide_batch_max() { return wide_tail() && !host::single_lane() ? 2048 : 0; }
+// pairing(P_i, Q_i), i < n: raw values through `scratch` (48 n words), Gt values to gt_out (SoA stride n)
+int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  plk::k_miller_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(p_xy, p_inf, q_xy, q_inf, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+  plk::k_final_exp_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(scratch, nullptr, n, gt_out, nullptr);
+  LAUNCHED();
+}
+// ok_i = [ e(sig_i, G2gen) e(hneg_i, pk_i) == 1 ], i < n; scratch: 96 n words
+int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* hneg, const uint8_t* hneg_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
+                          uint64_t* scratch, uint8_t* ok, size_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  u64 *fa = scratch, *fb = scratch + 48 * n;
+  plk::k_miller_wide_batch<<<dim3((unsigned)(2 * n)), dim3(64), 0, st>>>(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n);
+  plk::k_final_exp_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(fa, fb, n, nullptr, ok);
+  LAUNCHED();
+}
+}  // namespace plkh
 static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity);
 static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                   size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream);

@@ -109,9 +109,16 @@ int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n,
 int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && gt_out); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::pairing(p_xy, p_inf, q_xy, q_inf, gt_out, n, stream);
-  // ONE pairing is pure latency on one lane pair (5.4 ms): the one-pair product spreads it over a wavefront (2.25 ms); same Gt, an
-  // identity on either side gives the identity of Gt either way (pairing.rs:876-886)
-  if (n == 1) return sylow_hip_pairing_product_batch(p_xy, p_inf, q_xy, q_inf, 1, 1, gt_out, nullptr, stream);
+  // a few pairings are pure latency on one lane pair each: a wavefront per pairing instead; same Gt, an identity on either side gives the
+  // identity of Gt either way (pairing.rs:876-886)
+  if (n <= plkh::wide_batch_max()) {      // small batches: one wavefront per pairing (2.3 ms against 5.4 ms on one lane pair each)
+    host::Lease ws;
+    int32_t rc = ws.acquire(48 * n * sizeof(u64), (hipStream_t)stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    rc = plkh::pairing_wide_batch(p_xy, p_inf, q_xy, q_inf, (u64*)ws.p, gt_out, n, stream);
+    const int32_t r2 = ws.release();
+    return rc != SYLOW_HIP_OK ? rc : r2;
+  }
   plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
 }
 // test hook: raw Fp12 selector.  0..11: the single-lane layer (single.hip: 8 product on the carry-free core, 9 cyclotomic square on

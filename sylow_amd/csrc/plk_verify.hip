@@ -291,9 +291,20 @@ static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf
                                     const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::bls_verify_fused(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
-  // ONE verification is pure latency on one lane pair (6.5 ms): as a one-element aggregate -- the same product e(sig, G2gen) e(-H, pk),
-  // the same reading of identities -- its two Miller loops and the final exponentiation run on whole wavefronts (3.2 ms)
-  if (n == 1) return sylow_hip_bls_aggregate_verify_batch(pk_xy, pk_inf, 1, msgs, msg_offsets, sig_xy, sig_inf, 1, nullptr, nullptr, ok, stream);
+  // a few verifications are pure latency on one lane pair each (6.8 ms): the same product e(sig, G2gen) e(-H, pk) with the same reading of
+  // identities on one wavefront per Miller loop and per final exponentiation (3 ms)
+  if (n <= plkh::wide_batch_max() / 2) {  // small batches: -H(m_i), then a wavefront per Miller loop and per final exponentiation
+    host::Lease ws;
+    int32_t rc = ws.acquire((8 + 96) * n * sizeof(u64) + n, (hipStream_t)stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    u64* hneg = (u64*)ws.p;
+    u64* scratch = hneg + 8 * n;
+    uint8_t* hinf = (uint8_t*)(scratch + 96 * n);
+    rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
+    if (rc == SYLOW_HIP_OK) rc = plkh::verify_wide_batch(pk_xy, pk_inf, hneg, hinf, sig_xy, sig_inf, scratch, ok, n, stream);
+    const int32_t r2 = ws.release();
+    return rc != SYLOW_HIP_OK ? rc : r2;
+  }
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);

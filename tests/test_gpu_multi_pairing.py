@@ -269,7 +269,11 @@ def test_both_multi_pair_routes_pass_the_same_tests(mode):
         env["SYLOW_HIP_AGG_FORK"] = "0"
         env["SYLOW_HIP_WIDE_TAIL"] = "0"         # and the single-element tails on one lane pair instead of the whole wavefront
     # mode 0 also re-runs the batch-wide products (their chunks take the table route by default); mode 1 sends one-pair jobs through tables
-    files = ["tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py"] + (["tests/test_gpu_aggregate.py"] if mode == "0" else [])
+    files = ["tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py"]
+    if mode == "0":
+        # without the wide routes every small batch of the pairing / BLS / ragged-wavefront tests runs on the one-lane-pair kernels again
+        # (k_pairing, k_bls_verify_fused: by default only batches above 2048 / 1024 elements reach them)
+        files += ["tests/test_gpu_aggregate.py", "tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_lane_pair.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files,
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
