@@ -606,6 +606,37 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[i] = one ? 1 : 0;
 }
+// final_exponentiation(prod of the raw values of job j's pairs), one wavefront per job: raw SoA stride n_pairs (k_miller_wide_batch),
+// job j owns pairs [offsets[j], offsets[j + 1]) (an empty job is the identity); Gt values (SoA stride n_jobs) and / or flags
+__global__ void HEAVY_BOUNDS k_final_exp_wide_jobs(const u64* raw, size_t n_pairs, const u64* offsets, size_t n_jobs, u64* gout, uint8_t* is_one) {
+  __shared__ WideLds lds;
+  const size_t j = blockIdx.x;
+  const int odd = (int)(threadIdx.x & 1);
+  const size_t lo = offsets[j], hi = offsets[j + 1];
+  S12 f, g;
+  if (hi <= lo) {
+    f = s12_one();
+  } else {
+    load_s12(f, raw, n_pairs, lo, odd);
+    if (hi - lo > 1) {
+      W12 acc, y;
+      w12_from_s12(acc, f);
+#pragma unroll 1
+      for (size_t i = lo + 1; i < hi; ++i) {
+        S12 h;
+        load_s12(h, raw, n_pairs, i, odd);
+        w12_from_s12(y, h);
+        w12_mul_wide_nl(acc, acc, y, &lds);
+      }
+      w12_to_s12(f, acc);
+    }
+  }
+  final_exponentiation29_wide(g, f, &lds);
+  if (threadIdx.x >= 2) return;
+  if (gout) store_s12(gout, n_jobs, j, odd, g);
+  const bool one = s12_is_one(g);
+  if (is_one && !odd) is_one[j] = one ? 1 : 0;
+}
 // ONE element, launched as <<<1, 64>>>: all 32 lane pairs of the wavefront hold it and share the squarings of the hard part
 // (final_exponentiation29_wide); wide = 0: lane pair 0 alone (the plain routine, the other lanes leave)
 __global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one, int wide) {
@@ -744,7 +775,7 @@ int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const ui
 }  // namespace plkh
 static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity);
 static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
-                                  size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream);
+                                  size_t n_jobs, size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream);
 static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                     size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -792,7 +823,7 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
-  if (single_job_route(n_jobs, n_pairs, skip_infinity)) return single_job_product(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_pairs, gt_out, is_one, stream);
+  if (single_job_route(n_jobs, n_pairs, skip_infinity)) return single_job_product(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, gt_out, is_one, stream);
   if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, stream);
   // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
   // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
@@ -872,19 +903,30 @@ static int32_t finish(host::Lease& ws) {
   const int32_t rc = ws.release();
   return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
-// ONE job (a single ecPairing call, a single Groth16-style check): every pair on a lane pair of its own, a product tree, and the final
-// exponentiation on the whole wavefront -- one Miller loop deep instead of k (4 pairs: 7.9 -> 3.3 ms).  The job's pair range stays on the
-// device (pair_offsets[0 .. 1]).  EIP-197 reading of identities only (skip_infinity).
+// FEW jobs with few pairs (a single ecPairing call, a single Groth16-style check, a handful of them): one wavefront per pair for the
+// Miller loops, one per job for the product of its pairs and the final exponentiation -- 1.1 + 1.3 ms of latency whatever the job size,
+// against a whole glued loop and a final exponentiation on one lane pair per job (one job of 4 pairs: 7.9 ms).  The jobs' pair ranges
+// stay on the device.  EIP-197 reading of identities only (skip_infinity).
 static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity) {
-  return n_jobs == 1 && n_pairs >= 1 && skip_infinity && wide_tail() && !host::single_lane();
+  const size_t cap = plkh::wide_batch_max();
+  return cap != 0 && n_pairs >= 1 && n_pairs <= cap && n_jobs <= cap / 2 && skip_infinity;
 }
 static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
-                                  size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+                                  size_t n_jobs, size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
   host::Lease ws;
-  u64* prod = nullptr;
-  int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, 1, ws, &prod, stream, pair_offsets);
+  if (n_jobs == 1 && n_pairs > 256) {               // one LONG job: a log-depth product tree instead of a chain of products on one wavefront
+    u64* prod = nullptr;
+    int32_t rc = miller_product_tree(p_xy, p_inf, q_xy, q_inf, n_pairs, 1, ws, &prod, stream, pair_offsets);
+    if (rc != SYLOW_HIP_OK) return rc;
+    plk::k_final_exp_flag<<<1, 64, 0, st>>>(prod, 1, gt_out, is_one, wide_tail());
+    return finish(ws);
+  }
+  int32_t rc = ws.acquire(48 * n_pairs * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
-  plk::k_final_exp_flag<<<1, 64, 0, (hipStream_t)stream>>>(prod, 1, gt_out, is_one, wide_tail());
+  u64* raw = (u64*)ws.p;
+  plk::k_miller_wide_batch<<<dim3((unsigned)n_pairs), dim3(64), 0, st>>>(p_xy, p_inf, q_xy, q_inf, raw, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs);
+  plk::k_final_exp_wide_jobs<<<dim3((unsigned)n_jobs), dim3(64), 0, st>>>(raw, n_pairs, pair_offsets, n_jobs, gt_out, is_one);
   return finish(ws);
 }
 int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
@@ -1073,7 +1115,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
     if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
-    else if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_pairs, nullptr, isone, stream);
+    else if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, nullptr, isone, stream);
     else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, stream);
     else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
