@@ -335,6 +335,8 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from sylow_amd.rccl import quiet_init_env
+        quiet_init_env()                                   # one node: no MSCCL stores to parse, loopback bootstrap (defaults only)
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":

@@ -858,6 +858,42 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
   w12_to_s12(out, g);
 }
 
+// g2_doubling_step29 with its ten products in three levels: five on five lane pairs (x y, x^2, y^2, z^2, (y + z)^2), the twist-constant
+// product replicated (one product: nothing to spread), four on four lane pairs (b h, a (b - f), g^2, e^2).  Inputs and outputs replicated;
+// the squares are taken with the product leaf (same values).  Products of level 1 meet in the P slots, those of level 3 in the T slots.
+BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  {
+    const W2 yz = w2_norm(w2_add(r.y, r.z));
+    const int p = j < 5 ? j : 0;
+    const W2 a = w2_pick(w2_pick(w2_pick(r.x, r.y, p == 2), r.z, p == 3), yz, p == 4);        // 0, 1: x   2: y   3: z   4: y + z
+    const W2 b = w2_pick(a, r.y, p == 0);                                                       // 0: y, else the same operand (a square)
+    const W2 pr = w2_mul(a, b);
+    if (j < 5) wide_put(x, WL_P + p, odd, pr);
+  }
+  __syncthreads();
+  const W2 xy = wide_get(x, WL_P, odd), xx = wide_get(x, WL_P + 1, odd), b = wide_get(x, WL_P + 2, odd), c = wide_get(x, WL_P + 3, odd),
+           s = wide_get(x, WL_P + 4, odd);
+  const W2 a = w2_halve(xy);
+  l2 = w2_norm(w2_triple(xx));
+  const W2 h = w2_norm(w2_sub(s, w2_add(b, c)));
+  const W2 e = w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));
+  l1 = w2_neg(h);
+  l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);
+  const W2 f = w2_norm(w2_triple(e));
+  const W2 g = w2_halve(w2_norm(w2_add(b, f)));
+  {
+    const int p = j < 4 ? j : 0;
+    const W2 u = w2_pick(w2_pick(w2_pick(b, a, p == 1), g, p == 2), e, p == 3);                 // 0: b   1: a   2: g   3: e
+    const W2 v = w2_pick(w2_pick(w2_pick(h, w2_sub(b, f), p == 1), g, p == 2), e, p == 3);     // 0: h   1: b - f   2: g   3: e
+    const W2 pr = w2_mul(u, v);
+    if (j < 4) wide_put(x, WL_T + p, odd, pr);
+  }
+  __syncthreads();
+  r.z = wide_get(x, WL_T, odd);
+  r.x = wide_get(x, WL_T + 1, odd);
+  r.y = w2_lin2(wide_get(x, WL_T + 2, odd), 1, wide_get(x, WL_T + 3, odd), -3);
+}
 // The Miller loop of ONE pair on a whole wavefront (the other tail of the one-boolean shapes): the G2 steps run replicated, the
 // accumulator's squaring and its product with each line are w12_mul_wide -- a line (l0, l4 = l1 y_P, l2 = l2 x_P) is the Fp12 element
 // (l0, 0, l2; 0, l4, 0) of mul_by_024 (fp12.rs:426-503), and spread over 18 lane pairs the dense product costs less than the 13-product
@@ -883,7 +919,7 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
     w12_mul_wide_nl(f, f, f, xg);
-    g2_doubling_step29(r, l0, l1, l2);
+    g2_doubling_step29_wide(r, l0, l1, l2, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
       g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);

@@ -29,9 +29,19 @@ def warm_file(path: str) -> None:
         pass
 
 
+def quiet_init_env() -> None:
+    """Defaults (never overriding the caller's environment) that keep communicator construction short on ONE node: the path's collectives are a
+    4-byte all-reduce and a 384-byte all-gather, so the MSCCL / MSCCL++ algorithm stores RCCL would otherwise parse at init are of no use, and
+    the bootstrap socket needs no interface scan (all ranks are local: loopback)."""
+    os.environ.setdefault("RCCL_MSCCL_ENABLE", "0")
+    os.environ.setdefault("RCCL_MSCCLPP_ENABLE", "0")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
+
 def _load_rccl():
     """The RCCL shared object of this process: torch's bundled copy when torch is importable (its soname is what collective.hip
     dlopens too), else the system one."""
+    quiet_init_env()
     names = []
     try:
         import torch

@@ -65,7 +65,8 @@ def test_all_valid_and_product_all_single_rank(engine, pairs):
 
 def _rccl():
     import torch  # noqa: F401  (makes torch's librccl resolvable first: one RCCL per process)
-    from sylow_amd.rccl import warm_file
+    from sylow_amd.rccl import quiet_init_env, warm_file
+    quiet_init_env()
     for name in (os.path.join(os.path.dirname(__import__("torch").__file__), "lib", "librccl.so"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"):
         try:
             if os.path.isfile(name):
