@@ -894,6 +894,51 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
   r.x = wide_get(x, WL_T + 1, odd);
   r.y = w2_lin2(wide_get(x, WL_T + 2, odd), 1, wide_get(x, WL_T + 3, odd), -3);
 }
+// g2_addition_step29 with its thirteen products in four levels (2 + 4 + 3 + 4 lane pairs); inputs and outputs replicated.  Levels 1 and 3
+// meet in the P slots, levels 2 and 4 in the T slots (a barrier separates every reuse).
+BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  {   // level 1: z bx, z by
+    const W2 pr = w2_mul(r.z, w2_pick(bx, by, j == 1));
+    if (j < 2) wide_put(x, WL_P + j, odd, pr);
+  }
+  __syncthreads();
+  const W2 d = w2_sub(r.x, wide_get(x, WL_P, odd)), e = w2_sub(r.y, wide_get(x, WL_P + 1, odd));      // D
+  l1 = d;
+  l2 = w2_neg(e);
+  const W2 dn = w2_norm(d), en = w2_norm(e);
+  {   // level 2: e bx, d by, dn^2, en^2
+    const int p = j < 4 ? j : 0;
+    const W2 u = w2_pick(w2_pick(w2_pick(e, d, p == 1), dn, p == 2), en, p == 3);
+    const W2 v = w2_pick(w2_pick(w2_pick(bx, by, p == 1), dn, p == 2), en, p == 3);
+    const W2 pr = w2_mul(u, v);
+    if (j < 4) wide_put(x, WL_T + p, odd, pr);
+  }
+  __syncthreads();
+  l0 = w2_xi_lin(w2_sub(wide_get(x, WL_T, odd), wide_get(x, WL_T + 1, odd)), 1, bx, 0);               // xi (e bx - d by)
+  const W2 f = wide_get(x, WL_T + 2, odd), e2 = wide_get(x, WL_T + 3, odd);
+  {   // level 3: dn f, x f, z en^2
+    const int p = j < 3 ? j : 0;
+    const W2 u = w2_pick(w2_pick(dn, r.x, p == 1), r.z, p == 2);
+    const W2 v = w2_pick(f, e2, p == 2);
+    const W2 pr = w2_mul(u, v);
+    if (j < 3) wide_put(x, WL_P + p, odd, pr);
+  }
+  __syncthreads();
+  const W2 h = wide_get(x, WL_P, odd), i = wide_get(x, WL_P + 1, odd), ze2 = wide_get(x, WL_P + 2, odd);
+  const W2 jj = w2_norm(w2_sub(w2_add(ze2, h), w2_add(i, i)));                                           // z e^2 + h - 2 i
+  {   // level 4: z h, dn j, en (i - j), h y
+    const int p = j < 4 ? j : 0;
+    const W2 u = w2_pick(w2_pick(w2_pick(r.z, dn, p == 1), en, p == 2), h, p == 3);
+    const W2 v = w2_pick(w2_pick(w2_pick(h, jj, p == 1), w2_sub(i, jj), p == 2), r.y, p == 3);
+    const W2 pr = w2_mul(u, v);
+    if (j < 4) wide_put(x, WL_T + 4 + p, odd, pr);
+  }
+  __syncthreads();
+  r.z = wide_get(x, WL_T + 4, odd);
+  r.x = wide_get(x, WL_T + 5, odd);
+  r.y = w2_norm(w2_sub(wide_get(x, WL_T + 6, odd), wide_get(x, WL_T + 7, odd)));                         // e (i - j) - h y
+}
 // The Miller loop of ONE pair on a whole wavefront (the other tail of the one-boolean shapes): the G2 steps run replicated, the
 // accumulator's squaring and its product with each line are w12_mul_wide -- a line (l0, l4 = l1 y_P, l2 = l2 x_P) is the Fp12 element
 // (l0, 0, l2; 0, l4, 0) of mul_by_024 (fp12.rs:426-503), and spread over 18 lane pairs the dense product costs less than the 13-product
@@ -922,16 +967,16 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
     g2_doubling_step29_wide(r, l0, l1, l2, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
-      g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
+      g2_addition_step29_wide(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, (WideLdsPtr)xg);
       line();
     }
   }
   S2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qxs, qys);
   g2_psi_affine(q2x, q2y, q1x, q1y);
-  g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
+  g2_addition_step29_wide(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2, (WideLdsPtr)xg);
   line();
-  g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2);
+  g2_addition_step29_wide(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2, (WideLdsPtr)xg);
   line();
   w12_to_s12(fout, f);
 }
