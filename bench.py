@@ -10,11 +10,18 @@ resident in HBM (nothing crosses PCIe inside the timed region).  Batches shard t
 is the 4-byte MIN(=AND) all-reduce of the aggregate BLS-verify flag (sylow_amd/sharding.py),
 exercised in the untimed `aux` leg.
 
+The metric has two halves and BOTH run through the same loop (W warm-up steps, then exactly K steps between barrier + synchronize,
+HIP events around every step on the launch stream): K steps of 2^L pairings (`value`, `ms_per_step`), then K steps of 2^L BLS
+verifications incl. the AND over ranks (`config.bls_verifies_per_s`, `config.bls_verify_ms_per_step`; lib.rs:223-236).
+
 One JSON line is printed by rank 0:
- * `roofline`      the contract's HBM pricing of the dominant kernel (576 algorithmic bytes per pairing) -- a pairing is
-                   ~2x10^4 field multiplications on 576 bytes, so this fraction is tiny by nature;
- * `issue_roofline` the roof that binds it: VALU issue cycles (cycle-weighted by instruction class, <= 1);
- * `aux`           BLS verify at batch 2^20 (BASELINE configs[3]) incl. the AND over ranks, and at N = 1 the other single-GPU
+ * `roofline`      the roof that BINDS the dominant kernel, plk::k_pairing: VALU issue (cycle-weighted by instruction class) --
+                   `achieved` = ideal issue cycles of one launch / its live HIP-event duration, `peak` = 1024 SIMDs x 2.4 GHz,
+                   `frac_clock_free` = the same ratio taken inside one rocprofv3 pass (no clock enters); the contract's HBM pricing
+                   (576 algorithmic bytes per pairing: ~2x10^4 field multiplications on 576 bytes, tiny by nature) stays beside it as
+                   `hbm_*`, `traffic` = HBM bytes per launch from the PMC counters; the verify kernel's figures are `verify_*`;
+ * `aux`           the other BLS shapes at batch 2^20 (two-pairing form, same signer, aggregates, strong scaling), the batch-size sweep,
+                   the end-to-end (host arrays in, host results out) pipeline, and at N = 1 the other single-GPU
                    configs (C2a Fp mul/add -- the HBM-bound kernels --, C2b G1 scalar-mul, C3 2^18 pairings, C5 byte-level
                    ecPairing) each with its own algorithmic GB/s and fraction of the HBM roof;
  * `cpu_baseline`  the C oracle (a port of the reference) on the host cores, the sign shape, the cargo probe, and an oracle
@@ -36,6 +43,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 1024                         # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9                 # MI355X_MICROARCH.md: peak engine clock 2400 MHz
+ISSUE_PEAK = N_SIMD * PEAK_CLOCK_HZ   # SIMD issue cycles per second, whole chip
 PAIRING_BYTES = 576                   # 64 (G1 affine) + 128 (G2 affine) + 384 (Gt)  -- SURVEY.md §8(d)
 VERIFY_BYTES = 225                    # pk 128 + sig 64 + 32-byte msg + flag
 FP_OP_BYTES = 96                      # 2 x 32 in + 32 out
@@ -302,6 +311,69 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs=None):
                               "note": "one element per call, HIP-event timed: latency of the single-wavefront routes"}
     return res
 
+def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n):
+    """Per-element time against the batch size for the two headline operations (HIP events on the launch stream, device-resident SoA
+    inputs re-packed to each size's stride outside the clock): where single ecPairing calls, Groth16-size batches and the metric's
+    2^20 sit on the same curve (examples/reth_bn128.rs:156-217)."""
+    rows = []
+    for m in (1, 64, 1 << 10, 1 << 11, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+        if m > n:
+            break
+        reps = 20 if m <= (1 << 12) else 5 if m <= (1 << 16) else 3
+        pm, qm = eng.empty((8, m)).upload(np.ascontiguousarray(p_h[:, :m])), eng.empty((16, m)).upload(np.ascontiguousarray(q_h[:, :m]))
+        pkm, sgm = eng.empty((16, m)).upload(np.ascontiguousarray(pk_h[:, :m])), eng.empty((8, m)).upload(np.ascontiguousarray(sig_h[:, :m]))
+        gtm, okm, offm = eng.empty((48, m)), eng.empty((m,), np.uint8), eng.to_device(off[:m + 1])
+        tp = hip_timed(torch, stream, lambda: eng._call("sylow_hip_pairing_batch", pm.ptr, None, qm.ptr, None, gtm.ptr, m), reps)
+        tv = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_verify_batch", pkm.ptr, None, dm.ptr, offm.ptr, sgm.ptr, None, okm.ptr, m), reps)
+        rows.append({"n": m, "pairing_ms": tp * 1e3, "pairing_us_per_element": tp * 1e6 / m, "pairings_per_s": m / tp,
+                     "verify_ms": tv * 1e3, "verify_us_per_element": tv * 1e6 / m, "verifies_per_s": m / tv, "verify_all_ok": int(okm.download().all()), "reps": reps})
+        del pm, qm, pkm, sgm, gtm, okm, offm
+    mono = lambda key: int(all(rows[i + 1][key] <= rows[i][key] * 1.02 for i in range(len(rows) - 1)))
+    return {"rows": rows, "pairing_us_per_element_monotone": mono("pairing_us_per_element"), "verify_us_per_element_monotone": mono("verify_us_per_element"),
+            "note": "per-element time must not rise with n (2 % tolerance): one call per row, mean of `reps` back-to-back calls"}
+
+
+def end_to_end(eng, p_h, q_h, gt_h, pk_h, sig_h, msgs_np, off, dev_pairings_per_s, dev_verifies_per_s):
+    """HOST arrays in, HOST results out (the value-typed API of pairing.rs:870-893 / lib.rs:223-236): sylow_hip_pairing_host and
+    sylow_hip_bls_verify_host cut the batch into chunks that alternate between two streams so that the copies run beside the kernels.
+    Element-major ("array of structs") host arrays, pageable and page-locked; wall clock around the synchronous call; results compared
+    with what the device-resident launches wrote."""
+    n = p_h.shape[1]
+    lib = eng.lib
+    from sylow_amd import _lib
+    res = {}
+    src = {"p": np.ascontiguousarray(p_h.T), "q": np.ascontiguousarray(q_h.T), "pk": np.ascontiguousarray(pk_h.T), "sig": np.ascontiguousarray(sig_h.T)}
+    blob = np.ascontiguousarray(msgs_np.reshape(-1))
+    gt_ref = np.ascontiguousarray(gt_h.T)
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            h = {k: eng.pinned_empty(v.shape) for k, v in src.items()}
+            for k, v in src.items():
+                h[k][:] = v
+            gt_out, ok_out = eng.pinned_empty((n, 48)), eng.pinned_empty((n,), np.uint8)
+        else:
+            h = src
+            gt_out, ok_out = np.empty((n, 48), dtype=np.uint64), np.empty((n,), dtype=np.uint8)
+        call_p = lambda: _lib.check(lib.sylow_hip_pairing_host(h["p"].ctypes.data, None, h["q"].ctypes.data, None, gt_out.ctypes.data, n, 0), "pairing_host")
+        call_v = lambda: _lib.check(lib.sylow_hip_bls_verify_host(h["pk"].ctypes.data, None, blob.ctypes.data, off.ctypes.data, h["sig"].ctypes.data, None,
+                                                                   ok_out.ctypes.data, n, 0), "bls_verify_host")
+        for name, call in (("pairing", call_p), ("verify", call_v)):
+            call()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                call()
+                ts.append(time.perf_counter() - t0)
+            dev = dev_pairings_per_s if name == "pairing" else dev_verifies_per_s
+            res[f"{name}_{kind}"] = {"per_s": n / float(np.mean(ts)), "ms": float(np.mean(ts)) * 1e3, "ms_min": min(ts) * 1e3, "ms_max": max(ts) * 1e3,
+                                     "frac_of_device_resident_rate": n / float(np.mean(ts)) / dev}
+        res[f"pairing_{kind}"]["bit_equal_to_device_resident"] = int(np.array_equal(gt_out, gt_ref))
+        res[f"verify_{kind}"]["all_ok"] = int(ok_out.all())
+        del gt_out, ok_out
+    res["note"] = ("2^%d elements, chunks of 2^16 on two streams; bytes per pairing 192 up + 384 down, per verify 192 + message up, 1 down; "
+                   "device-resident rates are this run's headline figures" % (n.bit_length() - 1))
+    return res
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -361,19 +433,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    elapsed = sharding.max_over_ranks(elapsed, dist)
+    def timed_loop(fn):
+        """The contract's loop: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; wall time is
+        the MAX over ranks; every step also sits between two HIP events on the launch stream (this rank's device time per step)."""
+        for _ in range(args.warmup):
+            fn()
+        fence()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        fence()
+        dt = time.perf_counter() - t0
+        ms = [a.elapsed_time(b) for a, b in ev]
+        return sharding.max_over_ranks(dt, dist), float(np.mean(ms)), float(np.min(ms)), float(np.max(ms))
+
+    elapsed, kern_ms, kern_ms_min, kern_ms_max = timed_loop(step)
 
     # rows of what the timed launches wrote, for the oracle spot check in the CPU leg
     check = None
@@ -392,70 +469,78 @@ def main():
     rccl_ranks = comm.ranks if comm is not None else None
     comm_ptr = comm.value if comm is not None else None
 
-    def timed_ranks(fn, reps=3):
-        """(seconds per call with the slowest rank's clock -- barrier + synchronize on both sides --, this rank's HIP-event ms per call)"""
+    spreads = {}
+
+    def timed_ranks(fn, reps=3, name=None):
+        """(seconds per call with the slowest rank's clock -- barrier + synchronize on both sides --, this rank's mean HIP-event ms per call);
+        every call sits between its own pair of events: [min, max] ms go to aux.kernel_ms_spread under `name`."""
         fn()
         fence()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         t0 = time.perf_counter()
-        a.record(stream)
-        for _ in range(reps):
+        for a, b in ev:
+            a.record(stream)
             fn()
-        b.record(stream)
+            b.record(stream)
         fence()
         dt = (time.perf_counter() - t0) / reps
-        return sharding.max_over_ranks(dt, dist), a.elapsed_time(b) / reps
+        ms = [a.elapsed_time(b) for a, b in ev]
+        if name:
+            spreads[name] = [float(np.min(ms)), float(np.max(ms)), reps]
+        return sharding.max_over_ranks(dt, dist), float(np.mean(ms))
 
-    # ---- untimed aux leg: batched BLS verify + aggregate AND over ranks (RCCL MIN) ----------------
+    # ---- the metric's second half: BLS verifies at the same batch, the same W + K loop (BASELINE.json configs[3], lib.rs:223-236) ----
+    nv = n
+    rng = np.random.default_rng(7 + rank)
+    msgs_np = rng.integers(0, 256, size=(nv, 32), dtype=np.uint8)
+    off = (np.arange(nv + 1, dtype=np.uint64) * np.uint64(32))
+    dm, doff = eng.to_device(msgs_np.reshape(-1)), eng.to_device(off)
+    sk = eng.empty((4, nv)).upload(eng.xoshiro_fp_soa(SEED + 4 + 1000 * rank, nv))
+    g2 = eng.empty((16, nv)).upload(np.repeat(limbs_row(G2).T, nv, axis=1))
+    pk, pki = eng.empty((16, nv)), eng.empty((nv,), np.uint8)
+    sig, sigi = eng.empty((8, nv)), eng.empty((nv,), np.uint8)
+    ok = eng.empty((nv,), np.uint8)
+    eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr, nv)
+    dtsg, sign_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv), 3, "bls_sign")
+    if args.plant_bad == rank:                # sig_j <- sig_{j+1}: a valid point, the wrong signature
+        s_h = sig.download()
+        j = (nv // world) // 3               # inside this rank's block of the strong-scaling leg too
+        s_h[:, j] = s_h[:, (j + 1) % nv]
+        sig.upload(s_h)
+    # torch's first device allocation initialises its allocator (seconds on a cold box): keep it outside the clocks
+    flag_dev = torch.ones(1, dtype=torch.int32, device="cuda")          # the device word the native calls write; results are kept apart
+    flag = flag2 = flag3 = flag_dev                                      # (a host-side backend returns a host copy)
+
+    def and_over_ranks(okbuf, m, out):
+        """AND of this rank's flags AND-ed over all ranks: the native entry point (device-side AND + 4-byte ncclAllReduce(min) on the
+        rank's own ncclComm_t) when a communicator exists, else the device-side AND + the process group's MIN."""
+        if comm is not None:
+            eng._call("sylow_hip_all_valid", okbuf.ptr, m, comm_ptr, out.data_ptr())
+            return out
+        eng._call("sylow_hip_flags_all", okbuf.ptr, m, out.data_ptr())
+        return sharding.and_reduce_(out, dist)
+
+    def verify_weak():
+        nonlocal flag
+        eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
+        flag = and_over_ranks(ok, nv, flag_dev)      # AND over ranks: 4 bytes over xGMI (RCCL MIN)
+
+    v_elapsed, verify_ms, verify_ms_min, verify_ms_max = timed_loop(verify_weak)
+    all_valid_weak = int(flag.item())
+    n_bad_fused = int(nv - int(ok.download().sum()))
+
+    # ---- untimed aux leg: the other BLS shapes, strong scaling, aggregates ----------------
     aux = {}
     if not args.no_aux:
-        nv = min(n, 1 << 20)                      # BASELINE.json configs[3]: BLS verifies at batch 2^20
-        rng = np.random.default_rng(7 + rank)
-        msgs_np = rng.integers(0, 256, size=(nv, 32), dtype=np.uint8)
-        off = (np.arange(nv + 1, dtype=np.uint64) * np.uint64(32))
-        dm, doff = eng.to_device(msgs_np.reshape(-1)), eng.to_device(off)
-        sk = eng.empty((4, nv)).upload(eng.xoshiro_fp_soa(SEED + 4 + 1000 * rank, nv))
-        g2 = eng.empty((16, nv)).upload(np.repeat(limbs_row(G2).T, nv, axis=1))
-        pk, pki = eng.empty((16, nv)), eng.empty((nv,), np.uint8)
-        sig, sigi = eng.empty((8, nv)), eng.empty((nv,), np.uint8)
-        ok = eng.empty((nv,), np.uint8)
-        eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2.ptr, None, sk.ptr, pk.ptr, pki.ptr, nv)
-        dtsg, sign_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv))
-        if args.plant_bad == rank:                # sig_j <- sig_{j+1}: a valid point, the wrong signature
-            s_h = sig.download()
-            j = nv // 3
-            s_h[:, j] = s_h[:, (j + 1) % nv]
-            sig.upload(s_h)
-        # torch's first device allocation initialises its allocator (seconds on a cold box): keep it outside the clocks
-        flag_dev = torch.ones(1, dtype=torch.int32, device="cuda")          # the device word the native calls write; results are kept apart
-        flag = flag2 = flag3 = flag_dev                                      # (a host-side backend returns a host copy)
-
-        def and_over_ranks(okbuf, m, out):
-            """AND of this rank's flags AND-ed over all ranks: the native entry point (device-side AND + 4-byte ncclAllReduce(min) on the
-            rank's own ncclComm_t) when a communicator exists, else the device-side AND + the process group's MIN."""
-            if comm is not None:
-                eng._call("sylow_hip_all_valid", okbuf.ptr, m, comm_ptr, out.data_ptr())
-                return out
-            eng._call("sylow_hip_flags_all", okbuf.ptr, m, out.data_ptr())
-            return sharding.and_reduce_(out, dist)
-
-        def verify_weak():
-            nonlocal flag
-            eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
-            flag = and_over_ranks(ok, nv, flag_dev)      # AND over ranks: 4 bytes over xGMI (RCCL MIN)
-
-        dtv, verify_ms = timed_ranks(verify_weak)
-        all_valid_weak = int(flag.item())
-
         def verify_two():
             nonlocal flag2
             eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv)
             flag2 = and_over_ranks(ok, nv, flag_dev)
 
-        dtf, verify2_ms = timed_ranks(verify_two, 1)
+        dtf, verify2_ms = timed_ranks(verify_two, 3, "bls_verify_two_pairings")
         all_valid_two = int(flag2.item())
         n_bad = int(nv - int(ok.download().sum()))
-        dts, same_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), 2)
+        dts, same_ms = timed_ranks(lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), 3, "same_signer")
 
         # ---- STRONG scaling, BASELINE.json configs[3] as written: ONE batch of 2^20 verifies (and of 2^20 pairings) sharded over the
         # ranks as contiguous blocks (sharding.shard_bounds); every element is independent and synthetic, so rank r's block is the first
@@ -478,9 +563,9 @@ def main():
                 eng._call("sylow_hip_bls_verify_batch", pk_s.ptr, None, dm_s.ptr, doff_s.ptr, sig_s.ptr, None, ok_s.ptr, ms)
             flag3 = and_over_ranks(ok_s, ms, flag_dev)
 
-        dtvs, _ = timed_ranks(verify_strong)
+        dtvs, _ = timed_ranks(verify_strong, 3, "strong_verify")
         all_valid_strong = int(flag3.item())
-        dtps, _ = timed_ranks(lambda: ms and eng._call("sylow_hip_pairing_batch", p_s.ptr, None, q_s.ptr, None, gt_s.ptr, ms))
+        dtps, _ = timed_ranks(lambda: ms and eng._call("sylow_hip_pairing_batch", p_s.ptr, None, q_s.ptr, None, gt_s.ptr, ms), 3, "strong_pairing")
         strong = {"scaling": "strong", "batch_total": n_total, "shard_this_rank": ms, "bls_verifies_per_s": n_total / dtvs, "pairings_per_s": n_total / dtps,
                   "bls_all_valid": all_valid_strong,
                   "note": "ONE batch of %d sharded over %d rank(s) as contiguous blocks; time = slowest rank between barriers; verify includes the AND over ranks" % (n_total, world)}
@@ -494,7 +579,7 @@ def main():
         na = nv
         gt1, is1 = eng.empty((48, 1)), eng.empty((1,), np.uint8)
         agg = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, comm_ptr, gt1.ptr, is1.ptr)
-        dta, agg_ms = timed_ranks(agg, 2)
+        dta, agg_ms = timed_ranks(agg, 3, "aggregate")
         agg_ok = int(is1.download()[0]) if comm is not None else sharding.all_valid(int(is1.download()[0]), dist)
         # the same with ONE signer for the whole batch: both halves collapse (n hashes, two G1 sums, a two-pair product)
         k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
@@ -505,17 +590,18 @@ def main():
         eng._call("sylow_hip_bls_sign_batch", sk1.ptr, dm.ptr, doff.ptr, sig1.ptr, sig1i.ptr, nv)
         eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2one.ptr, None, sk1one.ptr, pk1.ptr, pk1i.ptr, 1)
         agg1 = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk1.ptr, None, 1, dm.ptr, doff.ptr, sig1.ptr, None, nv, comm_ptr, gt1.ptr, is1.ptr)
-        dta1, agg1_ms = timed_ranks(agg1, 2)
+        dta1, agg1_ms = timed_ranks(agg1, 3, "aggregate_same_signer")
         agg1_ok = int(is1.download()[0])
         del sk1, sig1, sig1i
         aux = {"aggregate_verify_sigs_per_s": world * na / dta, "aggregate_all_valid": agg_ok, "aggregate_batch_per_gpu": na,
                "aggregate_same_signer_sigs_per_s": world * nv / dta1, "aggregate_same_signer_all_valid": agg1_ok,
                "aggregate_path": ("native: sylow_hip_bls_aggregate_verify_batch over this rank's ncclComm_t (all-gather of %d partial products)" % rccl_ranks) if comm is not None
                                  else "per-rank product, booleans AND-ed through the process group",
-               "bls_signs_per_s": world * nv / dtsg, "bls_verifies_per_s": world * nv / dtv, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
-               "bls_all_valid": all_valid_weak, "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES / dtv / 1e9,
-               "bls_verify_frac_of_hbm": world * nv * VERIFY_BYTES / dtv / 1e9 / (HBM_PEAK_GBS * world),
+               "bls_signs_per_s": world * nv / dtsg, "bls_verifies_per_s": world * nv * args.steps / v_elapsed, "same_signer_shape_checks_per_s": world * nv / dts, "bls_verify_batch_per_gpu": nv,
+               "bls_all_valid": all_valid_weak, "bls_verify_algorithmic_GBps": world * nv * VERIFY_BYTES * args.steps / v_elapsed / 1e9,
+               "bls_verify_frac_of_hbm": world * nv * VERIFY_BYTES * args.steps / v_elapsed / 1e9 / (HBM_PEAK_GBS * world),
                "bls_verifies_per_s_two_pairings": world * nv / dtf, "bls_all_valid_two_pairings": all_valid_two, "bad_flags_this_rank": n_bad,
+               "kernel_ms_spread": spreads,
                "kernel_ms_rank0": {"bls_sign": sign_ms, "bls_verify": verify_ms, "bls_verify_two_pairings": verify2_ms, "same_signer": same_ms,
                                    "aggregate": agg_ms, "aggregate_same_signer": agg1_ms},
                "and_path": "native: sylow_hip_all_valid (device AND + ncclAllReduce(min) on this rank's ncclComm_t)" if comm is not None
@@ -526,48 +612,68 @@ def main():
                                                                                ("same_signer_shape", "bls_verify_same_signer_shape_2^20"),
                                                                                ("aggregate", "aggregate_verify_2^20"), ("aggregate_same_signer", "aggregate_same_signer_2^20"))
                               if nv == 1 << 20 and pmc_cfgs.get(v)},
-               "timing": "every figure: mean of 2-3 calls after a warm call, slowest rank's wall clock between barrier + synchronize; kernel_ms_rank0 = HIP events on the launch stream",
+               "timing": "bls_verifies_per_s: the contract loop (--warmup, --steps); every other figure: mean of 3 calls after a warm call, slowest rank's wall clock between barrier + synchronize; kernel_ms_rank0 = HIP events on the launch stream, kernel_ms_spread = [min, max, calls] of the per-call events",
                "note": "verify = sylow_hip_bls_verify_batch: the boolean of lib.rs:223-236 as e(sig,G2gen)*e(-H,pk)==1 (hash + shared-squaring 2-pair Miller loop + ONE final exponentiation); "
                        "two_pairings = the same boolean evaluated literally (hash + two full pairings + compare); "
                        "aggregate = prod_i e(sig_i,G2gen) e(-H(m_i),pk_i) == identity as one boolean: hash + G1 sum of the signatures + product tree over the n key pairs + one final exponentiation; "
                        "aggregate_same_signer = one key: hash + two G1 sums + a two-pair product"}
         if world == 1 and not args.force_dist:
+            p_h, q_h, pk_h, sig_h = p.download(), q.download(), pk.download(), sig.download()
+            aux["size_sweep"] = size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n)
+            aux["e2e"] = end_to_end(eng, p_h, q_h, gt.download(), pk_h, sig_h, msgs_np, off, n * args.steps / elapsed, nv * args.steps / v_elapsed)
+            del p_h, q_h, pk_h, sig_h
             del dm, doff, sk, g2, pk, pki, sig, sigi, ok, pk1, pk1i, g2one, sk1one
             aux["configs"] = single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs)
 
     if rank == 0:
         total = world * n * args.steps
         value = total / elapsed
-        achieved = PAIRING_BYTES * n / (kern_ms * 1e-3) / 1e9
-        main_cfg = pmc_cfgs.get("pairing_2^%d" % args.log2n)
+        verifies_per_s = world * nv * args.steps / v_elapsed
+        kern_s = kern_ms * 1e-3
+        hbm_achieved = PAIRING_BYTES * n / kern_s / 1e9
+        main_cfg = pmc_cfgs.get("pairing_2^%d" % args.log2n) or {}
+        ver_cfg = pmc_cfgs.get("bls_verify_2^%d" % args.log2n) or {}
+        have_issue = main_cfg.get("issue_frac") is not None
+        issue_cycles = main_cfg["issue_cycles_ideal_per_unit"] * n if have_issue else None       # ideal VALU issue cycles of one launch
+        pmc_note = (pmc["source"] if main_cfg else
+                    "profiles/pmc_current.json was measured on another build of the kernels (source hash differs): re-run tools/prof_configs.sh"
+                    if pmc is not None else "no profiles/pmc_current.json")
+        # every value in `config` / `roofline` is a scalar: the driver's record keeps scalars of these two objects and drops nested ones
         out = {
-            "metric": "BN254 optimal-ate pairings/s", "value": value, "unit": "pairings/s",
+            "metric": "BN254 pairings/s (value) and BLS verifies/s (config.bls_verifies_per_s) at batch=2^%d per GPU" % args.log2n,
+            "value": value, "unit": "pairings/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32/u32 limbs (9x29-bit carry-free core + 8x32-bit Montgomery, exact integer)", "data": "synthetic",
-            "config": {"workload": f"pairing_batch: 2^{args.log2n} independent e(a_i*G1, b_i*G2) per GPU per step "
-                                   "(BASELINE.json configs[2] shape at the metric's batch=2^20), affine SoA inputs resident in HBM",
-                       "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "achieved_note": "ALGORITHMIC bytes (576 per pairing) / kernel time; the HBM-bound kernels of the path are aux.configs C2a",
-                         "traffic": (main_cfg["hbm_bytes_per_unit"] * n) if main_cfg and main_cfg.get("hbm_bytes_per_unit") else None,
-                         "traffic_note": (("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, " + pmc["source"] + ")") if main_cfg else
-                                          ("profiles/pmc_current.json was measured on another build of the kernels (source hash differs): re-run tools/prof_configs.sh"
-                                           if pmc is not None else None)),
-                         "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": PAIRING_BYTES * n},
+            "config": {"workload": f"2^{args.log2n} pairings e(a_i*G1, b_i*G2) per GPU per step, then 2^{args.log2n} BLS verifies per GPU per step; SoA inputs resident in HBM",
+                       "batch_per_gpu": n, "parallelism": f"independent shards x{world}, no data-path collective",
+                       "bls_verifies_per_s": verifies_per_s, "bls_verify_ms_per_step": v_elapsed / args.steps * 1e3,
+                       "bls_verify_steps": args.steps, "bls_verify_warmup": args.warmup, "bls_verify_batch_per_gpu": nv,
+                       "bls_all_valid": all_valid_weak, "bls_bad_flags_this_rank": n_bad_fused,
+                       "bls_verify_note": "sylow_hip_bls_verify_batch + AND over ranks (lib.rs:223-236 as e(sig,G2gen) e(-H(m),pk) == 1), same loop as the pairings",
+                       "timed_region_s": elapsed + v_elapsed},
+            "roofline": {"bound": "valu-issue", "unit": "G SIMD issue cycles/s",
+                         "achieved": issue_cycles / kern_s / 1e9 if have_issue else None, "peak": ISSUE_PEAK / 1e9,
+                         "frac": issue_cycles / kern_s / ISSUE_PEAK if have_issue else None,
+                         "frac_clock_free": main_cfg.get("issue_frac"), "frac_vs_measured_issue_rates": main_cfg.get("issue_frac_vs_measured_issue_rates"),
+                         "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "kernel_ms_min": kern_ms_min, "kernel_ms_max": kern_ms_max,
+                         "kernel_ms_profiled": main_cfg.get("ms_per_launch_kernel_sum", main_cfg.get("ms_per_launch")),
+                         "valu_instr_per_pairing": main_cfg.get("valu_instr_per_unit"), "int64_class_frac": main_cfg.get("int64_class_frac"),
+                         "issue_cycles_ideal_per_pairing": main_cfg.get("issue_cycles_ideal_per_unit"), "simd_cycles_per_pairing": main_cfg.get("simd_cycles_per_unit"),
+                         "note": "achieved = (SQ_INSTS_VALU_INT64 x 4 + other VALU x 2 issue cycles per pairing, rocprofv3 PMC) x batch / live HIP-event kernel time; "
+                                 "peak = 1024 SIMDs x 2.4 GHz; frac_clock_free = issue cycles / (GRBM_GUI_ACTIVE / 8 x 1024) inside one profiled pass",
+                         "pmc_source": pmc_note,
+                         "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+                         "hbm_note": "ALGORITHMIC bytes (576 per pairing) / kernel time: HBM cannot bind a pairing; the HBM-bound kernels of the path are aux.configs C2a",
+                         "algorithmic_bytes_per_launch": PAIRING_BYTES * n,
+                         "traffic": (main_cfg["hbm_bytes_per_unit"] * n) if main_cfg.get("hbm_bytes_per_unit") else None,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
+                         "verify_kernel": "k_hash_to_g1 + plk::k_bls_verify_fused", "verify_kernel_ms": verify_ms, "verify_kernel_ms_min": verify_ms_min,
+                         "verify_kernel_ms_max": verify_ms_max, "verify_per_s": verifies_per_s,
+                         "verify_issue_frac_clock_free": ver_cfg.get("issue_frac"), "verify_valu_instr_per_unit": ver_cfg.get("valu_instr_per_unit"),
+                         "verify_frac": (ver_cfg["issue_cycles_ideal_per_unit"] * nv / (verify_ms * 1e-3) / ISSUE_PEAK) if ver_cfg.get("issue_cycles_ideal_per_unit") else None,
+                         "verify_hbm_bytes_per_unit_measured": ver_cfg.get("hbm_bytes_per_unit")},
         }
-        if main_cfg and main_cfg.get("issue_frac") is not None:
-            # cycle-weighted issue roofline: sum over instruction classes of (wave-instructions x issue cycles of the class) over the SIMD
-            # cycles of the launch, both from the same rocprofv3 pass (clock-free); the live kernel time is shown beside the profiled one
-            out["issue_roofline"] = {"bound": "valu-issue", "unit": "SIMD issue cycles per launch",
-                                     "achieved": main_cfg["issue_cycles_ideal_per_unit"] * n, "peak": main_cfg["simd_cycles_per_unit"] * n,
-                                     "frac": main_cfg["issue_frac"], "frac_vs_measured_issue_rates": main_cfg.get("issue_frac_vs_measured_issue_rates"),
-                                     "valu_instr_per_pairing": main_cfg["valu_instr_per_unit"], "int64_class_frac": main_cfg.get("int64_class_frac"),
-                                     "kernel_ms_live": kern_ms, "kernel_ms_profiled": main_cfg.get("ms_per_launch_kernel_sum"),
-                                     "note": "frac = (SQ_INSTS_VALU_INT64 x 4 + other VALU x 2 issue cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the profiled "
-                                             "launch (" + pmc["source"] + "): a property of the build, no clock enters; v_mul_lo_u32 (4 cycles, ~2 % of the stream) "
-                                             "is counted in the 2-cycle class, so the fraction is a slight under-estimate"}
         if aux:
             out["aux"] = aux
         if not args.no_cpu and world == 1:

@@ -397,6 +397,33 @@ int32_t sylow_hip_bls_batch_verify_weighted(const uint64_t* pk_xy, const uint8_t
 int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 
+/* ---- value-typed forms: HOST arrays in, HOST results out (pipeline.hip) ------------------------------------------------------
+ * The reference's API takes and returns values (pairing(&G1Projective, &G2Projective) -> Gt, pairing.rs:870-893;
+ * verify(&G2Projective, &[u8], &G1Projective) -> bool, lib.rs:223-236): a host that switches holds arrays of structs in HOST memory.
+ * These two calls are the batched forms on such arrays -- EVERY pointer is a HOST pointer, element-major ("array of structs", what a
+ * Rust Vec<[u64; W]> is): p_aos [n][8] (x, y), q_aos / pk_aos [n][16], sig_aos [n][8], gt_aos [n][48], flags [n] (NULL = none), msgs +
+ * msg_offsets [n + 1] as in sylow_hip_bls_verify_batch, ok [n].  The batch is cut into chunks of `chunk` elements (0 = 2^16: one resident
+ * set of lane pairs) that alternate between two internal streams, each chunk H2D -> AoS->SoA -> the same kernels as the device-pointer
+ * entry points -> D2H, issued so that the copy engines move chunk k - 1 out and chunk k + 1 in while chunk k computes.  Synchronous:
+ * the results are in host memory when the call returns.  Bit-identical to upload + sylow_hip_pairing_batch /
+ * sylow_hip_bls_verify_batch + download.  Pageable memory works; pinned memory (sylow_hip_host_malloc) makes every copy asynchronous. */
+int32_t sylow_hip_pairing_host(const uint64_t* p_aos, const uint8_t* p_inf, const uint64_t* q_aos, const uint8_t* q_inf,
+                               uint64_t* gt_aos, size_t n, size_t chunk);
+int32_t sylow_hip_bls_verify_host(const uint64_t* pk_aos, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                  const uint64_t* sig_aos, const uint8_t* sig_inf, uint8_t* ok, size_t n, size_t chunk);
+/* The same two pipelines fed with the reference's WIRE format, which is how a Rust host gets points across without relying on sylow's
+ * (non-repr(C)) memory layout: p_be / sig_be [n][64] = G1Affine::to_be_bytes (g1.rs:151-180), q_be / pk_be [n][128] =
+ * G2Affine::to_be_bytes (g2.rs:319-359).  Decoding and validation run on the device inside the pipeline (from_be_bytes + curve check;
+ * G2 also the r-torsion check of G2Projective::new, g2.rs:460-525); status_* [n] (HOST) receive SYLOW_HIP_ST_* per element, and an
+ * element that failed enters the computation as the identity (its Gt is one; its `ok` is the reference's answer for identities). */
+int32_t sylow_hip_pairing_host_bytes(const uint8_t* p_be, const uint8_t* q_be, uint64_t* gt_aos, uint8_t* status_p, uint8_t* status_q,
+                                     size_t n, size_t chunk);
+int32_t sylow_hip_bls_verify_host_bytes(const uint8_t* pk_be, const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sig_be,
+                                        uint8_t* ok, uint8_t* status_pk, uint8_t* status_sig, size_t n, size_t chunk);
+/* page-locked host memory for the staging side of the calls above (hipHostMalloc / hipHostFree) */
+int32_t sylow_hip_host_malloc(void** hptr, size_t bytes);
+int32_t sylow_hip_host_free(void* hptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,18 @@ inline std::vector<Gt> pairing(const std::vector<G1Affine>& p, const std::vector
                                const std::vector<uint8_t>* p_inf = nullptr, const std::vector<uint8_t>* q_inf = nullptr) {
   if (p.size() != q.size()) throw Error("pairing: length mismatch");
   const size_t n = p.size();
+  if ((p_inf && p_inf->size() != n) || (q_inf && q_inf->size() != n)) throw Error("identity flags: length mismatch");
+  // host vectors in, host vector out: the chunked, double-buffered pipeline (copies of chunk k - 1 / k + 1 beside the kernels of chunk k)
+  std::vector<Gt> out(n);
+  check(sylow_hip_pairing_host(reinterpret_cast<const uint64_t*>(p.data()), p_inf ? p_inf->data() : nullptr, reinterpret_cast<const uint64_t*>(q.data()),
+                               q_inf ? q_inf->data() : nullptr, reinterpret_cast<uint64_t*>(out.data()), n, 0), "sylow_hip_pairing_host");
+  return out;
+}
+// the same through explicit upload -> sylow_hip_pairing_batch -> download on one stream (what the pipeline must equal bit for bit)
+inline std::vector<Gt> pairing_unpipelined(const std::vector<G1Affine>& p, const std::vector<G2Affine>& q,
+                                           const std::vector<uint8_t>* p_inf = nullptr, const std::vector<uint8_t>* q_inf = nullptr) {
+  if (p.size() != q.size()) throw Error("pairing: length mismatch");
+  const size_t n = p.size();
   auto dp = to_device_soa(p); auto dq = to_device_soa(q);
   DeviceBuffer dgt(n * sizeof(Gt) + 8);
   Flags dpi(p_inf, n), dqi(q_inf, n);
@@ -225,6 +237,19 @@ inline std::vector<G1Affine> sign(const std::vector<Fp>& k, const std::vector<st
 inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig,
                                    const std::vector<uint8_t>* pk_inf = nullptr, const std::vector<uint8_t>* sig_inf = nullptr) {
   if (pubkey.size() != msgs.size() || sig.size() != msgs.size()) throw Error("verify: length mismatch");
+  const size_t n = msgs.size();
+  if ((pk_inf && pk_inf->size() != n) || (sig_inf && sig_inf->size() != n)) throw Error("identity flags: length mismatch");
+  std::vector<uint8_t> blob; std::vector<uint64_t> off(1, 0);
+  for (auto& m : msgs) { blob.insert(blob.end(), m.begin(), m.end()); off.push_back(blob.size()); }
+  if (blob.empty()) blob.push_back(0);
+  std::vector<uint8_t> ok(n);
+  check(sylow_hip_bls_verify_host(reinterpret_cast<const uint64_t*>(pubkey.data()), pk_inf ? pk_inf->data() : nullptr, blob.data(), off.data(),
+                                  reinterpret_cast<const uint64_t*>(sig.data()), sig_inf ? sig_inf->data() : nullptr, ok.data(), n, 0), "sylow_hip_bls_verify_host");
+  return ok;
+}
+inline std::vector<uint8_t> verify_unpipelined(const std::vector<G2Affine>& pubkey, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<G1Affine>& sig,
+                                               const std::vector<uint8_t>* pk_inf = nullptr, const std::vector<uint8_t>* sig_inf = nullptr) {
+  if (pubkey.size() != msgs.size() || sig.size() != msgs.size()) throw Error("verify: length mismatch");
   Messages m(msgs);
   auto dpk = to_device_soa(pubkey); auto dsig = to_device_soa(sig);
   Flags dpi(pk_inf, m.n), dsi(sig_inf, m.n);
@@ -234,6 +259,16 @@ inline std::vector<uint8_t> verify(const std::vector<G2Affine>& pubkey, const st
   if (m.n) { check(sylow_hip_memcpy_d2h(ok.data(), dok.as<void>(), m.n, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync"); }
   return ok;
 }
+// page-locked host storage for the pipeline's staging side (every copy asynchronous): a minimal allocator for std::vector
+template <class T> struct PinnedAllocator {
+  using value_type = T;
+  PinnedAllocator() = default;
+  template <class U> PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n) { void* p = nullptr; check(sylow_hip_host_malloc(&p, n * sizeof(T)), "sylow_hip_host_malloc"); return static_cast<T*>(p); }
+  void deallocate(T* p, size_t) { sylow_hip_host_free(p); }
+  template <class U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <class U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
 
 // "are ALL of them valid?" as ONE boolean: the glued product of examples/verify_multiple_messages_same_signer.rs:41-60 (weights == nullptr)
 // or the sound small-exponent test with the caller's random weights (sylow_hip_bls_batch_verify_weighted).  One key per message, or one key.

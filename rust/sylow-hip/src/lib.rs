@@ -216,10 +216,35 @@ pub(crate) fn messages(dev: &Device, msgs: &[&[u8]]) -> Result<(DeviceBuf<u8>, D
 }
 
 /// Batched `sylow::pairing` (pairing.rs:870-893): out[i] = pairing(p[i], q[i]); an identity on either side gives Gt::identity().
-pub fn pairing_batch(dev: &Device, p: &[G1Affine], q: &[G2Affine]) -> Result<Vec<GtOut>, HipError> {
+/// Host slices in, host vector out: the points go up in sylow's wire format and the whole call runs through the library's chunked,
+/// double-buffered pipeline (`sylow_hip_pairing_host_bytes`: decode + validation + Miller loop + final exponentiation of chunk k
+/// while the copy engines move chunk k - 1 out and chunk k + 1 in).  The first rejected element is reported as sylow's GroupError.
+pub fn pairing_batch(_dev: &Device, p: &[G1Affine], q: &[G2Affine]) -> Result<Vec<GtOut>, HipError> {
     assert_eq!(p.len(), q.len());
     let n = p.len();
-    let (dp, dq) = (upload_g1(dev, p)?, upload_g2(dev, q)?);
+    let (mut pb, mut qb) = (Vec::with_capacity(64 * n), Vec::with_capacity(128 * n));
+    for x in p {
+        pb.extend_from_slice(&x.to_be_bytes());
+    }
+    for x in q {
+        qb.extend_from_slice(&x.to_be_bytes());
+    }
+    let mut gt = vec![[0u64; 48]; n];
+    let (mut st_p, mut st_q) = (vec![0u8; n], vec![0u8; n]);
+    // SAFETY: pb holds n * 64 bytes, qb n * 128 bytes, gt n * 48 words, the status vectors n bytes each -- all HOST memory that
+    // outlives the (synchronous) call.
+    device::check(unsafe {
+        ffi::sylow_hip_pairing_host_bytes(pb.as_ptr(), qb.as_ptr(), gt.as_mut_ptr() as *mut u64, st_p.as_mut_ptr(), st_q.as_mut_ptr(), n, 0)
+    })?;
+    first_failure(&st_p)?;
+    first_failure(&st_q)?;
+    Ok(gt.iter().map(gt_from_words).collect())
+}
+
+/// `pairing_batch` on points that are already resident (upload_g1 / upload_g2): one stream, no host traffic besides the result.
+pub fn pairing_batch_resident(dev: &Device, dp: &DeviceG1, dq: &DeviceG2) -> Result<Vec<GtOut>, HipError> {
+    assert_eq!(dp.n, dq.n);
+    let n = dp.n;
     let gt = dev.alloc::<u64>(48 * n)?;
     // SAFETY: point arrays and flags hold n elements, gt 48 * n words.
     device::check(unsafe {
@@ -289,6 +314,40 @@ pub fn verify_batch(dev: &Device, pk: &[G2Affine], msgs: &[&[u8]], sig: &[G1Affi
     })?;
     let flags = dev.download(&ok)?;
     Ok((flags.iter().map(|&f| f != 0).collect(), ok))
+}
+
+/// Batched `sylow::verify` (lib.rs:223-236) on host slices through the library's chunked pipeline (`sylow_hip_bls_verify_host_bytes`):
+/// keys and signatures travel in wire format, decoding / validation / hashing / the pairing check of chunk k overlap the copies of
+/// its neighbours.  Same booleans as `verify_batch(.., VerifyMode::Fused)`; nothing stays on the device.
+pub fn verify_batch_host(pk: &[G2Affine], msgs: &[&[u8]], sig: &[G1Affine]) -> Result<Vec<bool>, HipError> {
+    assert!(pk.len() == msgs.len() && sig.len() == msgs.len());
+    let n = msgs.len();
+    let (mut kb, mut sb) = (Vec::with_capacity(128 * n), Vec::with_capacity(64 * n));
+    for x in pk {
+        kb.extend_from_slice(&x.to_be_bytes());
+    }
+    for x in sig {
+        sb.extend_from_slice(&x.to_be_bytes());
+    }
+    let mut offsets = Vec::with_capacity(n + 1);
+    let mut blob = Vec::new();
+    offsets.push(0u64);
+    for m in msgs {
+        blob.extend_from_slice(m);
+        offsets.push(blob.len() as u64);
+    }
+    if blob.is_empty() {
+        blob.push(0);
+    }
+    let (mut ok, mut st_k, mut st_s) = (vec![0u8; n], vec![0u8; n], vec![0u8; n]);
+    // SAFETY: kb n * 128 bytes, sb n * 64 bytes, offsets n + 1 entries into blob, ok / status n bytes each; host memory, synchronous call.
+    device::check(unsafe {
+        ffi::sylow_hip_bls_verify_host_bytes(kb.as_ptr(), blob.as_ptr(), offsets.as_ptr(), sb.as_ptr(), ok.as_mut_ptr(), st_k.as_mut_ptr(),
+                                             st_s.as_mut_ptr(), n, 0)
+    })?;
+    first_failure(&st_k)?;
+    first_failure(&st_s)?;
+    Ok(ok.iter().map(|&f| f != 0).collect())
 }
 
 /// One signer, many messages (examples/verify_multiple_messages_same_signer.rs:41-60) with the key's `G2PreComputed` line table

@@ -707,3 +707,58 @@ pub fn xoshiro_fp(seed: u64, n: usize) -> Result<Vec<Fp>, device::Error> {
     device::check(unsafe { ffi::sylow_hip_host_xoshiro_fp(seed, soa.as_mut_ptr(), n, n) })?;
     Ok((0..n).map(|i| fp_from_words(&[soa[i], soa[n + i], soa[2 * n + i], soa[3 * n + i]])).collect())
 }
+
+// ------------------------------------------------------------------ host-array pipelines on canonical words
+/// Page-locked host memory (`sylow_hip_host_malloc`): staging arrays for the `*_host` calls, whose copies then run asynchronously
+/// beside the kernels.  Freed on drop.
+pub struct PinnedBuf<T: Copy> {
+    ptr: *mut T,
+    len: usize,
+}
+impl<T: Copy> PinnedBuf<T> {
+    pub fn new(len: usize) -> Result<Self, device::Error> {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        // SAFETY: `p` is a valid out-pointer.
+        device::check(unsafe { ffi::sylow_hip_host_malloc(&mut p, len * std::mem::size_of::<T>()) })?;
+        Ok(PinnedBuf { ptr: p as *mut T, len })
+    }
+    pub fn as_slice(&self) -> &[T] {
+        // SAFETY: `len` elements were allocated; T: Copy has no drop glue and every bit pattern written by the library is a valid integer.
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+    pub fn as_mut_slice(&mut self) -> &mut [T] {
+        // SAFETY: as above; unique borrow.
+        unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+impl<T: Copy> Drop for PinnedBuf<T> {
+    fn drop(&mut self) {
+        // SAFETY: the pointer came from sylow_hip_host_malloc.
+        unsafe { ffi::sylow_hip_host_free(self.ptr as *mut c_void) };
+    }
+}
+
+/// `pairing` on canonical words held by the host (x, y per G1 point: `[u64; 8]`; x.c0, x.c1, y.c0, y.c1 per G2 point: `[u64; 16]`):
+/// the chunked two-stream pipeline of `sylow_hip_pairing_host`, writing into `gt` (which may live in a `PinnedBuf`).
+pub fn pairing_words_host(p: &[[u64; 8]], p_inf: Option<&[u8]>, q: &[[u64; 16]], q_inf: Option<&[u8]>, gt: &mut [[u64; 48]]) -> Result<(), device::Error> {
+    let n = p.len();
+    assert!(q.len() == n && gt.len() == n && p_inf.map_or(true, |f| f.len() == n) && q_inf.map_or(true, |f| f.len() == n));
+    // SAFETY: n elements in every array; host memory; the call returns after the last copy has landed.
+    device::check(unsafe {
+        ffi::sylow_hip_pairing_host(p.as_ptr() as *const u64, p_inf.map_or(std::ptr::null(), |f| f.as_ptr()), q.as_ptr() as *const u64,
+                                    q_inf.map_or(std::ptr::null(), |f| f.as_ptr()), gt.as_mut_ptr() as *mut u64, n, 0)
+    })
+}
+
+/// `verify` on canonical words held by the host (`sylow_hip_bls_verify_host`): ok[i] = verify(pk[i], msgs[offsets[i]..offsets[i + 1]], sig[i]).
+pub fn verify_words_host(pk: &[[u64; 16]], pk_inf: Option<&[u8]>, msgs: &[u8], offsets: &[u64], sig: &[[u64; 8]], sig_inf: Option<&[u8]>,
+                         ok: &mut [u8]) -> Result<(), device::Error> {
+    let n = pk.len();
+    assert!(sig.len() == n && ok.len() == n && offsets.len() == n + 1 && *offsets.last().unwrap() as usize <= msgs.len());
+    assert!(pk_inf.map_or(true, |f| f.len() == n) && sig_inf.map_or(true, |f| f.len() == n));
+    // SAFETY: n keys / signatures / flags, n + 1 offsets into msgs; host memory; synchronous call.
+    device::check(unsafe {
+        ffi::sylow_hip_bls_verify_host(pk.as_ptr() as *const u64, pk_inf.map_or(std::ptr::null(), |f| f.as_ptr()), msgs.as_ptr(), offsets.as_ptr(),
+                                       sig.as_ptr() as *const u64, sig_inf.map_or(std::ptr::null(), |f| f.as_ptr()), ok.as_mut_ptr(), n, 0)
+    })
+}

@@ -135,6 +135,12 @@ SIGNATURES = {
     "sylow_hip_pairing_product_all": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_i32, c_vp, c_u64p, c_u8p, c_vp],
     "sylow_hip_fp12_cyclotomic_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_pairing_host": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz],
+    "sylow_hip_bls_verify_host": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],
+    "sylow_hip_pairing_host_bytes": [c_u8p, c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],
+    "sylow_hip_bls_verify_host_bytes": [c_u8p, c_u8p, c_u64p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_sz],
+    "sylow_hip_host_malloc": [ctypes.POINTER(ctypes.c_void_p), c_sz],
+    "sylow_hip_host_free": [c_vp],
 }
 _RESTYPE = {"sylow_hip_last_error": ctypes.c_char_p}
 

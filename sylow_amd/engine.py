@@ -85,6 +85,25 @@ class Engine:
     def sync(self):
         _lib.check(self.lib.sylow_hip_stream_sync(self.stream), "sync")
 
+    def pinned_empty(self, shape, dtype=np.uint64) -> np.ndarray:
+        """A numpy array over page-locked host memory (sylow_hip_host_malloc): every copy of the host pipeline is then asynchronous.
+        The memory is released when the array (and every view of it) is garbage-collected."""
+        dtype = np.dtype(dtype)
+        nbytes = max(1, int(np.prod(shape, dtype=np.int64)) * dtype.itemsize)
+        p = ctypes.c_void_p()
+        _lib.check(self.lib.sylow_hip_host_malloc(ctypes.byref(p), nbytes), "host_malloc")
+        lib, addr = self.lib, p.value
+
+        class _Owner:
+            def __del__(self_inner):
+                try:
+                    lib.sylow_hip_host_free(addr)
+                except Exception:
+                    pass
+        buf = (ctypes.c_uint8 * nbytes).from_address(addr)
+        buf._owner = _Owner()
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
     def xoshiro_fp_soa(self, seed: int, n: int) -> np.ndarray:
         """n values < p from the SplitMix64-seeded xoshiro256** stream, host array in SoA layout [4, n]."""
         out = np.empty((4, n), dtype=np.uint64)
@@ -388,9 +407,23 @@ class Engine:
     def final_exp(self, f):
         return self._unop("sylow_hip_final_exp_batch", 48, f)
 
-    def pairing(self, p_xy, q_xy, p_inf=None, q_inf=None):
+    def pairing(self, p_xy, q_xy, p_inf=None, q_inf=None, pipelined=True, chunk=0, out=None):
+        """pairing() (pairing.rs:870-893) on host arrays: [n, 8] / [n, 16] words in, [n, 48] Gt words out.  Default: the chunked,
+        double-buffered host pipeline (sylow_hip_pairing_host: the copies of chunk k - 1 / k + 1 run beside the kernels of chunk k);
+        `pipelined=False` is upload -> sylow_hip_pairing_batch -> download on the engine's stream (bit-identical).  `out`: a [n, 48]
+        uint64 array to fill (e.g. from `pinned_empty`)."""
         p_xy, q_xy = _aos(p_xy, 8), _aos(q_xy, 16)
         n = p_xy.shape[0]
+        if pipelined:
+            assert q_xy.shape[0] == n
+            gt = out if out is not None else np.empty((n, 48), dtype=np.uint64)
+            assert gt.shape == (n, 48) and gt.dtype == np.uint64 and gt.flags.c_contiguous
+            pi = None if p_inf is None else np.ascontiguousarray(p_inf, dtype=np.uint8).reshape(n)
+            qi = None if q_inf is None else np.ascontiguousarray(q_inf, dtype=np.uint8).reshape(n)
+            _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
+            _lib.check(self.lib.sylow_hip_pairing_host(p_xy.ctypes.data, None if pi is None else pi.ctypes.data, q_xy.ctypes.data,
+                                                       None if qi is None else qi.ctypes.data, gt.ctypes.data, n, chunk), "sylow_hip_pairing_host")
+            return gt
         dp, dq = self.to_device_soa(p_xy, 8), self.to_device_soa(q_xy, 16)
         dpi, dqi = self._flags(p_inf, n), self._flags(q_inf, n)
         do = self.empty((48, n))
@@ -600,10 +633,32 @@ class Engine:
         self._call("sylow_hip_bls_sign_batch", dsk.ptr, dm.ptr, doff.ptr, do.ptr, doi.ptr, n)
         return self.from_device_soa(do), doi.download()
 
-    def bls_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None, fused=False, two_pairings=False):
-        """verify (lib.rs:223-236).  Default and `fused`: one final exponentiation per element; `two_pairings`: the literal form."""
+    def bls_verify(self, pk_xy, msgs, sig_xy, pk_inf=None, sig_inf=None, fused=False, two_pairings=False, pipelined=True, chunk=0):
+        """verify (lib.rs:223-236).  Default and `fused`: one final exponentiation per element; `two_pairings`: the literal form.
+        The default form runs through the chunked host pipeline (sylow_hip_bls_verify_host) unless `pipelined=False`.
+        `msgs`: a list of bytes, or a (blob uint8 array, offsets uint64 [n + 1]) pair."""
         pk_xy, sig_xy = _aos(pk_xy, 16), _aos(sig_xy, 8)
-        n = len(msgs)
+        if isinstance(msgs, tuple):
+            blob, off = np.ascontiguousarray(msgs[0], dtype=np.uint8), np.ascontiguousarray(msgs[1], dtype=np.uint64)
+            n = off.shape[0] - 1
+        else:
+            n = len(msgs)
+            blob, off = None, None
+        if pipelined and not two_pairings and not fused:
+            if blob is None:
+                blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+                off = np.zeros(n + 1, dtype=np.uint64)
+                if n:
+                    off[1:] = np.cumsum([len(m) for m in msgs])
+            ok = np.empty((n,), dtype=np.uint8)
+            ki = None if pk_inf is None else np.ascontiguousarray(pk_inf, dtype=np.uint8).reshape(n)
+            si = None if sig_inf is None else np.ascontiguousarray(sig_inf, dtype=np.uint8).reshape(n)
+            _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
+            _lib.check(self.lib.sylow_hip_bls_verify_host(pk_xy.ctypes.data, None if ki is None else ki.ctypes.data, blob.ctypes.data, off.ctypes.data,
+                                                          sig_xy.ctypes.data, None if si is None else si.ctypes.data, ok.ctypes.data, n, chunk), "sylow_hip_bls_verify_host")
+            return ok
+        if blob is not None:
+            msgs = [bytes(blob[int(off[i]):int(off[i + 1])]) for i in range(n)]
         dm, doff = self._msgs(msgs)
         dpk, dsig = self.to_device_soa(pk_xy, 16), self.to_device_soa(sig_xy, 8)
         dpi, dsi = self._flags(pk_inf, n), self._flags(sig_inf, n)

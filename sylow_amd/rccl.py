@@ -30,9 +30,11 @@ def warm_file(path: str) -> None:
 
 
 def quiet_init_env() -> None:
-    """Defaults (never overriding the caller's environment) that keep communicator construction short on ONE node: the path's collectives are a
-    4-byte all-reduce and a 384-byte all-gather, so the MSCCL / MSCCL++ algorithm stores RCCL would otherwise parse at init are of no use, and
-    the bootstrap socket needs no interface scan (all ranks are local: loopback)."""
+    """ONE-NODE launchers only (bench.py and the tests call it explicitly; the library never does): defaults, never overriding the caller's
+    environment, that keep communicator construction short when every rank is local -- the path's collectives are a 4-byte all-reduce and a
+    384-byte all-gather, so the MSCCL / MSCCL++ algorithm stores RCCL would otherwise parse at init are of no use, and the bootstrap socket
+    needs no interface scan (loopback).  On a multi-node process group NCCL_SOCKET_IFNAME=lo would make rank 0's bootstrap listen where remote
+    ranks cannot reach it, which is why `_load_rccl` / `NativeComm` leave the environment alone."""
     os.environ.setdefault("RCCL_MSCCL_ENABLE", "0")
     os.environ.setdefault("RCCL_MSCCLPP_ENABLE", "0")
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -40,8 +42,7 @@ def quiet_init_env() -> None:
 
 def _load_rccl():
     """The RCCL shared object of this process: torch's bundled copy when torch is importable (its soname is what collective.hip
-    dlopens too), else the system one."""
-    quiet_init_env()
+    dlopens too), else the system one.  Does not touch the environment (see quiet_init_env)."""
     names = []
     try:
         import torch

@@ -83,6 +83,34 @@ int main() {
     std::vector<uint8_t> dinf;
     auto diff = sub({g1_generator()}, {g1_generator()}, &dinf);
     std::printf("VERIFYALL %d%d%d SUB %d\n", all_plain ? 1 : 0, all_weighted ? 1 : 0, bad_weighted ? 1 : 0, dinf[0]);
+    // host vectors in / out through the chunked two-stream pipeline (several chunks: 70000 > 2^16) == upload -> batch call -> download
+    {
+      const size_t n = 70000;
+      std::vector<Fp> ks(n);
+      for (size_t i = 0; i < n; ++i) ks[i] = Fp{{0x9e3779b97f4a7c15ull * (i + 1), i, 7, 0}};
+      auto ps = mul(std::vector<G1Affine>(n, g1_generator()), ks);
+      auto qs = mul(std::vector<G2Affine>(n, g2_generator()), ks, nullptr, nullptr, true);
+      std::vector<uint8_t> pi(n, 0), qi(n, 0);
+      pi[3] = 1; qi[n - 1] = 1; pi[65536] = 1;
+      const bool same = pairing(ps, qs, &pi, &qi) == pairing_unpipelined(ps, qs, &pi, &qi);
+      std::vector<std::vector<uint8_t>> ms(n);
+      for (size_t i = 0; i < n; ++i) ms[i].assign(i % 37, (uint8_t)i);
+      auto sg = sign(ks, ms);
+      std::swap(sg[10], sg[11]);
+      auto v1 = verify(qs, ms, sg), v2 = verify_unpipelined(qs, ms, sg);
+      size_t good = 0;
+      for (auto f : v1) good += f;
+      // page-locked staging through the allocator
+      std::vector<G1Affine, PinnedAllocator<G1Affine>> pp(ps.begin(), ps.end());
+      std::vector<G2Affine, PinnedAllocator<G2Affine>> qp(qs.begin(), qs.end());
+      std::vector<Gt, PinnedAllocator<Gt>> gp(n);
+      check(sylow_hip_pairing_host(reinterpret_cast<const uint64_t*>(pp.data()), nullptr, reinterpret_cast<const uint64_t*>(qp.data()), nullptr,
+                                   reinterpret_cast<uint64_t*>(gp.data()), n, 0), "pairing_host(pinned)");
+      auto plain = pairing(ps, qs);
+      bool pinned_same = true;
+      for (size_t i = 0; i < n; ++i) pinned_same = pinned_same && (gp[i] == plain[i]);
+      std::printf("PIPELINE %d%d%d %zu\n", same ? 1 : 0, v1 == v2 ? 1 : 0, pinned_same ? 1 : 0, n - good);
+    }
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());

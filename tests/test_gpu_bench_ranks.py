@@ -33,6 +33,7 @@ def test_two_rank_bench_all_valid():
     aux = out["aux"]
     assert aux["bls_all_valid"] == 1 and aux["bls_all_valid_two_pairings"] == 1 and aux["aggregate_all_valid"] == 1
     assert aux["bls_verify_batch_per_gpu"] == 4096 and aux["bad_flags_this_rank"] == 0
+    assert out["config"]["bls_all_valid"] == 1 and out["config"]["bls_verifies_per_s"] > 0 and out["config"]["bls_bad_flags_this_rank"] == 0
     # strong scaling: ONE batch of 4096 cut into two contiguous blocks (BASELINE.json configs[3] as written)
     st = aux["strong"]
     assert st["batch_total"] == 4096 and st["shard_this_rank"] == 2048 and st["bls_all_valid"] == 1 and st["bls_verifies_per_s"] > 0 and st["pairings_per_s"] > 0
@@ -45,6 +46,7 @@ def test_two_rank_bench_planted_bad_signature_on_rank_1():
     assert aux["bls_all_valid"] == 0 and aux["bls_all_valid_two_pairings"] == 0      # rank 0 sees rank 1's failure through the reduce
     assert aux["aggregate_all_valid"] == 0 and aux["aggregate_same_signer_all_valid"] == 1   # the aggregate check sees it too
     assert aux["bad_flags_this_rank"] == 0                                       # ... although all of rank 0's own flags are set
+    assert out["config"]["bls_all_valid"] == 0 and out["config"]["bls_bad_flags_this_rank"] == 0     # the headline verify loop sees it too
 
 
 def run_bench_nccl_one_rank(extra):
@@ -77,7 +79,17 @@ def test_single_rank_bench_self_check():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     cb = out["cpu_baseline"]
     assert cb["checked"] == 16 and cb["mismatches"] == 0 and cb["kind"] == "port" and cb["cores"] >= 1
-    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    rf = out["roofline"]
+    assert rf["bound"] == "valu-issue" and 0 < rf["hbm_frac"] < 1 and rf["kernel_ms"] > 0 and rf["verify_kernel_ms"] > 0
+    assert rf["frac"] is None or 0 < rf["frac"] <= 1              # None while profiles/pmc_current.json belongs to another build of the kernels
+    c = out["config"]                                              # the metric's second half sits where the driver's record keeps it
+    assert c["bls_verifies_per_s"] > 0 and c["bls_verify_steps"] == 2 and c["bls_all_valid"] == 1 and c["bls_verify_batch_per_gpu"] == 1 << 13
+    assert all(not isinstance(v, (dict, list)) for v in list(c.values()) + list(rf.values()))      # scalars only: nested objects are dropped
+    sw = out["aux"]["size_sweep"]
+    assert [r["n"] for r in sw["rows"]] == [1, 64, 1 << 10, 1 << 11, 1 << 12] and all(r["verify_all_ok"] == 1 for r in sw["rows"])
+    e2e = out["aux"]["e2e"]
+    assert e2e["pairing_pageable"]["bit_equal_to_device_resident"] == 1 and e2e["pairing_pinned"]["bit_equal_to_device_resident"] == 1
+    assert e2e["verify_pageable"]["all_ok"] == 1 and e2e["verify_pinned"]["all_ok"] == 1
     cfg = out["aux"]["configs"]
     assert {"C2a_fp_mul_2^20", "C2a_fp_add_2^24", "C2b_g1_scalar_mul_2^13", "C3_pairing_2^13"} <= set(cfg)
     assert all(v["pattern_ok"] == 1 for k, v in cfg.items() if k.startswith("C5_"))

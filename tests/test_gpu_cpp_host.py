@@ -29,7 +29,7 @@ def test_cpp_host_layer_compiles():
 @pytest.mark.gpu
 def test_cpp_host_layer_runs(kats, coracle):
     build_exe()
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
     assert [int(x, 16) for x in lines["GT"].split()] == [int(x, 16) for x in kats["gt_generator"]["value"]]
@@ -43,6 +43,9 @@ def test_cpp_host_layer_runs(kats, coracle):
     assert lines["GLUEDSKIP"] == "1"
     # one boolean per batch: the unweighted product passes, the weighted test passes and catches two swapped signatures; P - P = identity
     assert lines["VERIFYALL"] == "110 SUB 1"
+    # 70000 host elements through the two-stream pipeline == the unpipelined calls (pairing with identity flags, verify with two swapped
+    # signatures = exactly 2 failures, pinned staging vectors)
+    assert lines["PIPELINE"] == "111 2"
     sk0 = np.array([[5, 0, 0, 0]], dtype=np.uint64)
     sig_ref, _ = coracle.g1_to_affine(coracle.sign(sk0, [bytes([0, 0, 0, 20])]))
     want = [sum(int(sig_ref[0, 4 * i + k]) << (64 * k) for k in range(4)) for i in range(2)]
