@@ -1,5 +1,5 @@
-// bn254_pair.hpp -- the pairing on LANE PAIRS: two adjacent lanes of a wavefront carry one element of every
-// Fp2-based type, the even lane its c0 coordinate and the odd lane its c1 coordinate.
+// bn254_pair.hpp -- the pairing on LANE PAIRS: two lanes of a wavefront carry one element of every Fp2-based type, one its c0
+// coordinate and its partner the c1 coordinate ("even" / "odd" lane below; the geometry is defined under "lane-pair geometry").
 //
 // Why: with one pairing per lane an Fp12 is 96 VGPRs, so Fp12 products cannot keep their operands, result and
 // temporaries inside the 256-register budget of a 2-waves-per-SIMD kernel; the single-lane path therefore moves
@@ -24,9 +24,19 @@ struct S2 { Fp c; };              // this lane's coordinate of an Fp2 element
 struct S6 { S2 c0, c1, c2; };
 struct S12 { S6 c0, c1; };
 
-BN_DEV bool lane_odd() { return (__lane_id() & 1u) != 0; }
-// value held by the partner lane (quad_perm [1,0,3,2])
-BN_DEV u32 swap_u32(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+// ---- lane-pair geometry --------------------------------------------------------------------------------------------------
+// Within every group of 8 lanes, lanes 0..3 carry the c0 coordinates of four elements and lanes 7..4 the c1 coordinates of the same
+// four (lane l and lane 7 - l are partners: DPP row_half_mirror).  The role of a lane is therefore a property of its DPP BANK (four
+// contiguous lanes): banks 0 and 2 of a row hold c0, banks 1 and 3 hold c1 -- which is what lets a single DPP instruction act on one
+// role only (bank_mask 0x5 = the c0 lanes, 0xA = the c1 lanes; with adjacent-lane pairs a role is a lane PARITY, which no DPP mask
+// can select: the operand exchange of the product leaf then needs 36 instructions instead of 27, bn254_pair29.hpp).
+// Thread t of a launch handles coordinate pair_role(t) of element pair_index(t); a wavefront carries 32 elements; element order in
+// memory is unchanged (each limb plane is still read as 32-byte runs per 4 lanes, 256 contiguous bytes per wavefront).
+template <class T> BN_DEV int pair_role(T t) { return (int)((t >> 2) & 1); }
+template <class T> BN_DEV T pair_index(T t) { return (T)(((t >> 3) << 2) | ((t & 3) ^ (((t >> 2) & 1) ? 3 : 0))); }
+BN_DEV bool lane_odd() { return pair_role(__lane_id()) != 0; }          // "odd" = this lane holds the c1 coordinate
+// value held by the partner lane (row_half_mirror: lane l <-> lane 7 - l of its group of 8)
+BN_DEV u32 swap_u32(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true); }
 BN_DEV Fp xchg(const Fp& a) {
   Fp r;
 #pragma unroll

@@ -47,73 +47,67 @@ BN_DEV F29 f29_reduce(const F29& a) {
 }
 
 // ---- leaves: 18 scalar ABI arguments (two 9-limb structs would travel through the stack) -----------------------------
-// even lane: a0 b0 - a1 b1;  odd lane: a1 b0 + a0 b1.  Operands R / N / D.  Output N, |V| < (VaVb + Va'Vb')/169 + 1.
-// The operand shuffle is written with DPP-fused selects (v_cndmask_b32_dpp reads the partner lane's register as src0):
-//   B0 = b0 on both lanes = even ? own b : partner's b      (vcc = even lanes)
-//   B1 = b1 on both lanes = odd  ? own b : partner's b      (vcc = odd lanes)
-//   X2 = partner's a, negated on even lanes                 ((x ^ m) - m with m = even ? -1 : 0)
-// 36 instructions instead of the 54 of exchange-then-select.  s_nop 1 (two wait states) covers the VALU-write -> DPP-read hazard at block entry
-// (the assembler does not see into inline asm).
-#define BN_DPP_SWAP "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-BN_DEV F29 dpp_pick9(const F29& b, bool own_on_odd) {
-  F29 r;
-  if (own_on_odd) {
-    asm("s_nop 1\n\ts_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
-        "v_cndmask_b32_dpp %0, %9, %9, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %1, %10, %10, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %2, %11, %11, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %3, %12, %12, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %4, %13, %13, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %5, %14, %14, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %6, %15, %15, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %7, %16, %16, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %8, %17, %17, vcc " BN_DPP_SWAP
-        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
-        : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8])
-        : "vcc");
-  } else {
-    asm("s_nop 1\n\ts_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"
-        "v_cndmask_b32_dpp %0, %9, %9, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %1, %10, %10, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %2, %11, %11, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %3, %12, %12, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %4, %13, %13, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %5, %14, %14, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %6, %15, %15, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %7, %16, %16, vcc " BN_DPP_SWAP "\n\t"
-        "v_cndmask_b32_dpp %8, %17, %17, vcc " BN_DPP_SWAP
-        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
-        : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8])
-        : "vcc");
-  }
-  return r;
-}
-// (partner's a) ^ m, one instruction per limb
-BN_DEV F29 dpp_xor9(const F29& a, i32 m) {
-  F29 r;
+// c0 lane: a0 b0 - a1 b1;  c1 lane: a1 b0 + a0 b1.  Operands R / N / D.  Output N, |V| < (VaVb + Va'Vb')/169 + 1.
+// With X / Y this lane's coordinates of a / b and X' / Y' the partner's, both lanes evaluate  X U + W V  with
+//   U = Y  on c0 lanes, Y' on c1 lanes      v_cndmask_b32_dpp: the partner's register is read as src0 of the select itself
+//   W = X' on both                          v_mov_b32_dpp
+//   V = -Y' on c0 lanes, Y on c1 lanes      IN PLACE on the b registers (the callee owns them), two bank-masked instructions per limb that
+//                                            write the c0 lanes only -- possible because a lane's role is its DPP bank (bn254_pair.hpp)
+// 36 instructions + one for the zero and no lane-parity mask to build (adjacent-lane pairs: 45 + 4).
+// s_nop 1 (two wait states) covers the VALU-write -> DPP-read hazard at block entry (the assembler does not see into inline asm).
+#define BN_DPP_SWAP "row_half_mirror row_mask:0xf bank_mask:0xf"
+#define BN_DPP_SWAP_C0 "row_half_mirror row_mask:0xf bank_mask:0x5"
+#define BN_DPP_SELF_C0 "quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x5"      // no permutation: the DPP form only for its bank mask
+BN_DEV void w2_exchange(const F29& a, F29& b, F29& U, F29& W) {
+  asm("s_nop 1\n\ts_mov_b32 vcc_lo, 0x0f0f0f0f\n\ts_mov_b32 vcc_hi, 0x0f0f0f0f\n\t"
+      "v_cndmask_b32_dpp %0, %9, %9, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %1, %10, %10, vcc " BN_DPP_SWAP "\n\t"
+      "v_cndmask_b32_dpp %2, %11, %11, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %3, %12, %12, vcc " BN_DPP_SWAP "\n\t"
+      "v_cndmask_b32_dpp %4, %13, %13, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %5, %14, %14, vcc " BN_DPP_SWAP "\n\t"
+      "v_cndmask_b32_dpp %6, %15, %15, vcc " BN_DPP_SWAP "\n\tv_cndmask_b32_dpp %7, %16, %16, vcc " BN_DPP_SWAP "\n\t"
+      "v_cndmask_b32_dpp %8, %17, %17, vcc " BN_DPP_SWAP
+      : "=&v"(U.v[0]), "=&v"(U.v[1]), "=&v"(U.v[2]), "=&v"(U.v[3]), "=&v"(U.v[4]), "=&v"(U.v[5]), "=&v"(U.v[6]), "=&v"(U.v[7]), "=&v"(U.v[8])
+      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]), "v"(b.v[8])
+      : "vcc");
   asm("s_nop 1\n\t"
-      "v_xor_b32_dpp %0, %9, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %1, %10, %18 " BN_DPP_SWAP "\n\t"
-      "v_xor_b32_dpp %2, %11, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %3, %12, %18 " BN_DPP_SWAP "\n\t"
-      "v_xor_b32_dpp %4, %13, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %5, %14, %18 " BN_DPP_SWAP "\n\t"
-      "v_xor_b32_dpp %6, %15, %18 " BN_DPP_SWAP "\n\tv_xor_b32_dpp %7, %16, %18 " BN_DPP_SWAP "\n\t"
-      "v_xor_b32_dpp %8, %17, %18 " BN_DPP_SWAP
-      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8])
-      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]), "v"(m));
-  return r;
+      "v_mov_b32_dpp %0, %9 " BN_DPP_SWAP "\n\tv_mov_b32_dpp %1, %10 " BN_DPP_SWAP "\n\t"
+      "v_mov_b32_dpp %2, %11 " BN_DPP_SWAP "\n\tv_mov_b32_dpp %3, %12 " BN_DPP_SWAP "\n\t"
+      "v_mov_b32_dpp %4, %13 " BN_DPP_SWAP "\n\tv_mov_b32_dpp %5, %14 " BN_DPP_SWAP "\n\t"
+      "v_mov_b32_dpp %6, %15 " BN_DPP_SWAP "\n\tv_mov_b32_dpp %7, %16 " BN_DPP_SWAP "\n\t"
+      "v_mov_b32_dpp %8, %17 " BN_DPP_SWAP
+      : "=&v"(W.v[0]), "=&v"(W.v[1]), "=&v"(W.v[2]), "=&v"(W.v[3]), "=&v"(W.v[4]), "=&v"(W.v[5]), "=&v"(W.v[6]), "=&v"(W.v[7]), "=&v"(W.v[8])
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]), "v"(a.v[8]));
+  // V in place on the b registers, c0 lanes only (bank_mask 0x5): first the partner's coordinate, then its negative.  (One instruction
+  // cannot do both: in v_sub / v_subrev with DPP the permuted operand is always the minuend -- tools/ubench/dpp_probe2.hip.)
+  const i32 zero = 0;
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %0 " BN_DPP_SWAP_C0 "\n\tv_mov_b32_dpp %1, %1 " BN_DPP_SWAP_C0 "\n\t"
+      "v_mov_b32_dpp %2, %2 " BN_DPP_SWAP_C0 "\n\tv_mov_b32_dpp %3, %3 " BN_DPP_SWAP_C0 "\n\t"
+      "v_mov_b32_dpp %4, %4 " BN_DPP_SWAP_C0 "\n\tv_mov_b32_dpp %5, %5 " BN_DPP_SWAP_C0 "\n\t"
+      "v_mov_b32_dpp %6, %6 " BN_DPP_SWAP_C0 "\n\tv_mov_b32_dpp %7, %7 " BN_DPP_SWAP_C0 "\n\t"
+      "v_mov_b32_dpp %8, %8 " BN_DPP_SWAP_C0 "\n\t"
+      "v_sub_u32_dpp %0, %9, %0 " BN_DPP_SELF_C0 "\n\tv_sub_u32_dpp %1, %9, %1 " BN_DPP_SELF_C0 "\n\t"
+      "v_sub_u32_dpp %2, %9, %2 " BN_DPP_SELF_C0 "\n\tv_sub_u32_dpp %3, %9, %3 " BN_DPP_SELF_C0 "\n\t"
+      "v_sub_u32_dpp %4, %9, %4 " BN_DPP_SELF_C0 "\n\tv_sub_u32_dpp %5, %9, %5 " BN_DPP_SELF_C0 "\n\t"
+      "v_sub_u32_dpp %6, %9, %6 " BN_DPP_SELF_C0 "\n\tv_sub_u32_dpp %7, %9, %7 " BN_DPP_SELF_C0 "\n\t"
+      "v_sub_u32_dpp %8, %9, %8 " BN_DPP_SELF_C0
+      : "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]), "+v"(b.v[4]), "+v"(b.v[5]), "+v"(b.v[6]), "+v"(b.v[7]), "+v"(b.v[8])
+      : "v"(zero));
 }
 BN_NOINLINE F29 w2_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
                             i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
-  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
-  const i32 m = lane_odd() ? 0 : -1;
-  const F29 B0 = dpp_pick9(b, false), B1 = dpp_pick9(b, true);
-  F29 x2 = dpp_xor9(a, m);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) x2.v[i] -= m;                 // even lanes: -(partner's a1); odd lanes: partner's a0
-  // even: a0 b0 + (-a1) b1;  odd: a1 b0 + a0 b1
-  return f29_dot2(a, B0, x2, B1);
+  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+  F29 b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}}, U, W;
+  w2_exchange(a, b, U, W);
+  // c0: a0 b0 + a1 (-b1);  c1: a1 b0 + a0 b1
+  return f29_dot2(a, U, W, b);
 }
 // the same product on the two-accumulator column form (f29_dot2_ilp): used by the G2 group law
 BN_NOINLINE F29 w2_mul_ilp_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
                                 i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8) {
-  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
-  const i32 m = lane_odd() ? 0 : -1;
-  const F29 B0 = dpp_pick9(b, false), B1 = dpp_pick9(b, true);
-  F29 x2 = dpp_xor9(a, m);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) x2.v[i] -= m;
-  return f29_dot2_ilp(a, B0, x2, B1);
+  const F29 a{{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+  F29 b{{b0, b1, b2, b3, b4, b5, b6, b7, b8}}, U, W;
+  w2_exchange(a, b, U, W);
+  return f29_dot2_ilp(a, U, W, b);
 }
 // even lane: (a0 + a1)(a0 - a1);  odd lane: a0 * 2 a1.  Operand limbs non-negative (R / N).  Output N.
 BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8) {
@@ -705,7 +699,7 @@ BN_DEV W2 wide_get(WideLdsPtr x, int slot, int odd) {
 BN_DEV W2 w2_pick(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }                // c ? b : a
 BN_DEV W2 w2_sel3(int k, const W2& a, const W2& b, const W2& c) { return w2_pick(w2_pick(a, b, k == 1), c, k == 2); }
 BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   const int p = j < 6 ? j : 0, k = p >> 1;
   const bool s = (p & 1) != 0;
   const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
@@ -745,7 +739,7 @@ BN_DEV W2 w12_coef(const W12& a, int c) {      // c = 3 * half + i
   return w2_pick(lo, hi, c >= 3);
 }
 BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   {   // stage 0: coefficients and the sums a.c0 + a.c1, b.c0 + b.c1 into LDS
     const int c = j < 6 ? j : 0;
     const W2 ac = w12_coef(a, c), bc = w12_coef(b, c);
@@ -862,7 +856,7 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
 // product replicated (one product: nothing to spread), four on four lane pairs (b h, a (b - f), g^2, e^2).  Inputs and outputs replicated;
 // the squares are taken with the product leaf (same values).  Products of level 1 meet in the P slots, those of level 3 in the T slots.
 BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   {
     const W2 yz = w2_norm(w2_add(r.y, r.z));
     const int p = j < 5 ? j : 0;
@@ -897,7 +891,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
 // g2_addition_step29 with its thirteen products in four levels (2 + 4 + 3 + 4 lane pairs); inputs and outputs replicated.  Levels 1 and 3
 // meet in the P slots, levels 2 and 4 in the T slots (a barrier separates every reuse).
 BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = lane & 1, j = lane >> 1;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   {   // level 1: z bx, z by
     const W2 pr = w2_mul(r.z, w2_pick(bx, by, j == 1));
     if (j < 2) wide_put(x, WL_P + j, odd, pr);

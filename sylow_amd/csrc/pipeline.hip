@@ -4,8 +4,8 @@
 // verify(&G2Projective, &[u8], &G1Projective) -> bool, lib.rs:223-236), i.e. a host that switches to this library holds
 // arrays of structs in host memory (a Rust Vec<G1Affine> is [n][8] words, element-major).  Upload -> compute -> download run
 // serially would leave the GPU idle for the transfers (2^20 pairings: 201 MB up + 403 MB down, ~8 % of the 119 ms of compute on
-// PCIe Gen5).  Here a batch is cut into chunks of whole GPU rounds (2^16 elements: one resident set of lane pairs) that alternate
-// between TWO streams, each with its own device block:
+// PCIe Gen5).  Here a batch is cut into chunks (a base chunk of 2^16 elements -- one resident set of lane pairs -- first and last,
+// up to four times that in between: `schedule`) that alternate between TWO streams, each with its own device block:
 //
 //     stream k & 1:   H2D(chunk k) -> AoS->SoA -> kernels -> SoA->AoS -> D2H(chunk k)
 //
@@ -18,6 +18,7 @@
 #include "host.hpp"
 
 #include <algorithm>
+#include <vector>
 
 namespace {
 constexpr size_t DEFAULT_CHUNK = size_t(1) << 16;
@@ -42,6 +43,29 @@ struct Pipe {
   ~Pipe() { (void)close(); }
 };
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+// Chunk schedule.  A launch costs ~1 ms beyond its share of the work however large it is (its wavefronts start in step and drain
+// unevenly; measured on k_pairing: 2^16 elements 8.6 ms, 2^18 30.7 ms, 2^20 119.5 ms), the first chunk's upload and the last chunk's
+// download are the only copies nothing hides: so the batch opens and closes with one `base` chunk (short exposed copies) and the middle
+// goes in chunks of up to 4 x base (few launches).  Returns the chunk boundaries (k + 1 offsets); the largest chunk is *cmax.
+inline std::vector<size_t> schedule(size_t n, size_t base, size_t* cmax) {
+  std::vector<size_t> cut(1, 0);
+  const size_t cap = 4 * base;
+  size_t pos = 0;
+  auto push = [&](size_t m) { pos += m; cut.push_back(pos); };
+  if (n <= 2 * base) {
+    if (n > base) { push(n / 2); push(n - n / 2); } else push(n);
+  } else {
+    push(base);
+    size_t mid = n - 2 * base;
+    const size_t k = (mid + cap - 1) / cap;                 // number of middle chunks, sizes as equal as possible
+    for (size_t i = 0; i < k; ++i) { const size_t m = mid / (k - i); push(m); mid -= m; }
+    push(base);
+  }
+  size_t mx = 0;
+  for (size_t i = 1; i < cut.size(); ++i) mx = std::max(mx, cut[i] - cut[i - 1]);
+  *cmax = mx;
+  return cut;
+}
 #define RCCHK(x) do { const int32_t rc_ = (x); if (rc_ != SYLOW_HIP_OK) return rc_; } while (0)
 }  // namespace
 
@@ -52,15 +76,16 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 template <bool WIRE>
 static int32_t pairing_pipeline(const void* p_in, const uint8_t* p_inf, const void* q_in, const uint8_t* q_inf, uint64_t* gt_aos,
                                 uint8_t* st_p, uint8_t* st_q, size_t n, size_t chunk) {
-  const size_t c = std::min(n, chunk ? chunk : DEFAULT_CHUNK);
-  // block layout (bytes): p_in 64 c | q_in 128 c | p_soa 64 c | q_soa 128 c | gt_soa 384 c | gt_aos 384 c | p_inf c | q_inf c | st_p c | st_q c
+  size_t c = 0;
+  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, &c);
+  // block layout (bytes), c = the largest chunk: p_in 64 c | q_in 128 c | p_soa 64 c | q_soa 128 c | gt_soa 384 c | gt_aos 384 c | p_inf c | q_inf c | st_p c | st_q c
   const size_t o_pa = 0, o_qa = o_pa + 64 * c, o_ps = o_qa + 128 * c, o_qs = o_ps + 64 * c, o_gs = o_qs + 128 * c, o_ga = o_gs + 384 * c,
                o_pi = o_ga + 384 * c, o_qi = align256(o_pi + c), o_sp = align256(o_qi + c), o_sq = align256(o_sp + c), total = align256(o_sq + c);
   Pipe pp;
   RCCHK(pp.open(total));
-  const size_t nchunks = (n + c - 1) / c;
+  const size_t nchunks = cut.size() - 1;
   auto enqueue = [&](size_t k) -> int32_t {
-    const size_t lo = k * c, m = std::min(c, n - lo);
+    const size_t lo = cut[k], m = cut[k + 1] - lo;
     hipStream_t s = pp.st[k & 1];
     char* b = (char*)pp.blk[k & 1].p;
     HIPCHK(hipMemcpyAsync(b + o_pa, (const char*)p_in + 64 * lo, 64 * m, hipMemcpyHostToDevice, s));
@@ -83,7 +108,7 @@ static int32_t pairing_pipeline(const void* p_in, const uint8_t* p_inf, const vo
   RCCHK(enqueue(0));
   for (size_t k = 0; k < nchunks; ++k) {
     if (k + 1 < nchunks) RCCHK(enqueue(k + 1));
-    const size_t lo = k * c, m = std::min(c, n - lo);
+    const size_t lo = cut[k], m = cut[k + 1] - lo;
     char* b = (char*)pp.blk[k & 1].p;
     if (WIRE) {
       HIPCHK(hipMemcpyAsync(st_p + lo, b + o_sp, m, hipMemcpyDeviceToHost, pp.st[k & 1]));
@@ -97,11 +122,12 @@ static int32_t pairing_pipeline(const void* p_in, const uint8_t* p_inf, const vo
 template <bool WIRE>
 static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets, const void* sig_in,
                                const uint8_t* sig_inf, uint8_t* ok, uint8_t* st_pk, uint8_t* st_sig, size_t n, size_t chunk) {
-  const size_t c = std::min(n, chunk ? chunk : DEFAULT_CHUNK);
-  const size_t nchunks = (n + c - 1) / c;
+  size_t c = 0;
+  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, &c);
+  const size_t nchunks = cut.size() - 1;
   size_t max_msg = 0;
   for (size_t k = 0; k < nchunks; ++k) {
-    const size_t lo = k * c, hi = std::min(n, lo + c);
+    const size_t lo = cut[k], hi = cut[k + 1];
     ARGCHK(msg_offsets[hi] >= msg_offsets[lo]);
     max_msg = std::max(max_msg, (size_t)(msg_offsets[hi] - msg_offsets[lo]));
   }
@@ -112,7 +138,7 @@ static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const u
   Pipe pp;
   RCCHK(pp.open(total));
   auto enqueue = [&](size_t k) -> int32_t {
-    const size_t lo = k * c, m = std::min(c, n - lo);
+    const size_t lo = cut[k], m = cut[k + 1] - lo;
     hipStream_t s = pp.st[k & 1];
     char* b = (char*)pp.blk[k & 1].p;
     const size_t m0 = msg_offsets[lo], mb = msg_offsets[lo + m] - m0;
@@ -140,7 +166,7 @@ static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const u
   RCCHK(enqueue(0));
   for (size_t k = 0; k < nchunks; ++k) {
     if (k + 1 < nchunks) RCCHK(enqueue(k + 1));
-    const size_t lo = k * c, m = std::min(c, n - lo);
+    const size_t lo = cut[k], m = cut[k + 1] - lo;
     char* b = (char*)pp.blk[k & 1].p;
     if (WIRE) {
       HIPCHK(hipMemcpyAsync(st_pk + lo, b + o_tk, m, hipMemcpyDeviceToHost, pp.st[k & 1]));

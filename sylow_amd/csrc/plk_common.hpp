@@ -1,5 +1,5 @@
 // plk_common.hpp -- helpers shared by the LANE-PAIR kernel units (bn254_pair.hpp, bn254_pair29.hpp).
-// Thread t handles coordinate (t & 1) of element t >> 1, so a launch covers 2 n threads and a wavefront carries 32 elements.
+// Thread t handles coordinate pair_role(t) of element pair_index(t) (bn254_pair.hpp), so a launch covers 2 n threads and a wavefront carries 32 elements.
 // Both lanes of a pair always take the same branches.
 #pragma once
 #include "host.hpp"

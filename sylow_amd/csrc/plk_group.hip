@@ -171,8 +171,8 @@ BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int od
 constexpr int COMB_WIN = 32, COMB_ENT = 128;
 constexpr size_t COMB_WORDS = (size_t)COMB_WIN * COMB_ENT * 36;
 __global__ void HEAVY_BOUNDS k_g2_comb_table(i32* table) {
-  const size_t t = TID, e = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, e = pair_index(t);
+  const int odd = pair_role(t);
   if (e >= (size_t)COMB_WIN * COMB_ENT) return;
   const int w = (int)(e / COMB_ENT), j = (int)(e % COMB_ENT) + 1;
   u32 k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -189,8 +189,8 @@ __global__ void HEAVY_BOUNDS k_g2_comb_table(i32* table) {
   for (int q = 0; q < 9; ++q) { dst[odd * 9 + q] = wx.c.v[q]; dst[18 + odd * 9 + q] = wy.c.v[q]; }
 }
 __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __restrict__ table, u64* oxy, uint8_t* oinf, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   u32 k[8];
   load_scalar(k, ks, n, i);
@@ -222,8 +222,8 @@ __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __rest
 
 // tables: NULL, or 2 n * G1_TABLE_BYTES_PER_LANE bytes (thread t's window table contiguous)
 __global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   u32 k[8];
   load_scalar(k, ks, n, i);
@@ -233,8 +233,8 @@ __global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf
 }
 // the same for inputs in the r-torsion (G2Projective values of the reference are: G2Projective::new checks, g2.rs:460-525)
 __global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   u32 k[8];
   load_scalar(k, ks, n, i);
@@ -243,8 +243,8 @@ __global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* 
   store_g2q_affine(oxy, oinf, n, i, odd, r);
 }
 __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   G2Q r;
   g2q_add(r, load_g2q(axy, ainf, n, i, odd), load_g2q(bxy, binf, n, i, odd));
@@ -252,8 +252,8 @@ __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const
 }
 // Sub for projective points (group.rs:614-624): self + (-other)
 __global__ void HEAVY_BOUNDS k_g2_sub(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   G2Q r;
   g2q_add(r, load_g2q(axy, ainf, n, i, odd), proj_neg<OpsW2>(load_g2q(bxy, binf, n, i, odd)));
@@ -265,8 +265,8 @@ BN_DEV G2Q load_g2q_proj(const u64* pxyz, size_t n, size_t i, int odd) {
 // G2Projective::new([x, y, z]) (g2.rs:460-525): Y^2 Z == X^3 + b' Z^3 or Z == 0, then the subgroup relation on the projective
 // point itself.  Off the curve the reference's endomorphism() panics inside the subgroup test (g2.rs:151): NOT_ON_CURVE here.
 __global__ void HEAVY_BOUNDS k_g2_projective_new(const u64* pxyz, uint8_t* status, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const S2 x = load_s2(pxyz, n, i, 0, odd), y = load_s2(pxyz, n, i, 8, odd), z = load_s2(pxyz, n, i, 16, odd);
   const S2 lhs = s2_mul(s2_sqr(y), z);
@@ -286,8 +286,8 @@ __global__ void HEAVY_BOUNDS k_g2_projective_new(const u64* pxyz, uint8_t* statu
 }
 // ConstantTimeEq for projective points (group.rs:426-447)
 __global__ void HEAVY_BOUNDS k_g2_ct_eq(const u64* a, const u64* b, uint8_t* eq, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const S2 ax = load_s2(a, n, i, 0, odd), ay = load_s2(a, n, i, 8, odd), az = load_s2(a, n, i, 16, odd);
   const S2 bx = load_s2(b, n, i, 0, odd), by = load_s2(b, n, i, 8, odd), bz = load_s2(b, n, i, 16, odd);
@@ -296,16 +296,16 @@ __global__ void HEAVY_BOUNDS k_g2_ct_eq(const u64* a, const u64* b, uint8_t* eq,
   if (!odd) eq[i] = ((iz && yz) || (!iz && !yz && same)) ? 1 : 0;
 }
 __global__ void HEAVY_BOUNDS k_g2_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   G2Q r;
   g2q_double(r, load_g2q(axy, ainf, n, i, odd));
   store_g2q_affine(oxy, oinf, n, i, odd, r);
 }
 __global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* oinf, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const G2Q p{w2_from_s2(load_s2(pxyz, n, i, 0, odd)), w2_from_s2(load_s2(pxyz, n, i, 8, odd)), w2_from_s2(load_s2(pxyz, n, i, 16, odd))};
   store_g2q_affine(oxy, oinf, n, i, odd, p);
@@ -313,8 +313,8 @@ __global__ void HEAVY_BOUNDS k_g2_normalize(const u64* pxyz, u64* oxy, uint8_t* 
 // G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (eps0 conj x, eps1 conj y), psi(identity) = identity; status reports the
 // on-curve re-check the reference performs on the result (it panics there; here NOT_ON_CURVE)
 __global__ void __launch_bounds__(BLOCK) k_g2_psi(const u64* qxy, const uint8_t* qinf, u64* oxy, uint8_t* oinf, uint8_t* status, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const bool inf = qinf && qinf[i];
   S2 x = load_s2(qxy, n, i, 0, odd), y = load_s2(qxy, n, i, 8, odd), px, py;
@@ -326,8 +326,8 @@ __global__ void __launch_bounds__(BLOCK) k_g2_psi(const u64* qxy, const uint8_t*
 }
 // g2.rs:460-525 on an affine input
 __global__ void HEAVY_BOUNDS k_g2_subgroup_check(const u64* qxy, const uint8_t* qinf, uint8_t* status, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   uint8_t st = SYLOW_HIP_ST_OK;
   if (!(qinf && qinf[i])) {                       // Z == 0 passes both tests (g2.rs:469,510)
@@ -359,8 +359,8 @@ BN_DEV int gt_window_slot(u32 wp, u32 wm, bool& conj) {
   return slot;
 }
 __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
   W12 tab[11];
@@ -447,8 +447,8 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
 // one LANE PAIR per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes.  Both lanes decode
 // the six field elements; the G2 checks (twist equation, subgroup) run on the lane-pair Fp2 (g2q_* above).
 __global__ void HEAVY_BOUNDS k_evm_decode_pairs(const uint8_t* in, size_t n_pairs, u64* pxy, uint8_t* pinf, u64* qxy, uint8_t* qinf, uint8_t* pst) {
-  const size_t t = TID, i = t >> 1;
-  const bool odd = (t & 1) != 0;
+  const size_t t = TID, i = bn254::pl::pair_index(t);
+  const bool odd = bn254::pl::pair_role(t) != 0;
   if (i >= n_pairs) return;
   const uint8_t* b = in + 192 * i;
   Fp f[6];
@@ -498,8 +498,8 @@ __global__ void __launch_bounds__(BLOCK) k_g2_to_bytes(const u64* xy, const uint
 }
 // one LANE PAIR per 128-byte encoding (both lanes decode, the curve / subgroup checks run on the lane-pair Fp2)
 __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const bool odd = (t & 1) != 0;
+  const size_t t = TID, i = bn254::pl::pair_index(t);
+  const bool odd = bn254::pl::pair_role(t) != 0;
   if (i >= n) return;
   uint8_t b[128];
   for (int k = 0; k < 128; ++k) b[k] = in[128 * i + k];

@@ -230,8 +230,8 @@ template <int KMAX>
 __global__ void HEAVY_BOUNDS k_multi_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                              const u64* offsets, size_t n_jobs, size_t n_pairs, int skip_infinity,
                                              u64* gout, uint8_t* is_one, int raw_miller) {
-  const size_t t = TID, job = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, job = pair_index(t);
+  const int odd = pair_role(t);
   const bool active = job < n_jobs;           // no early return: every lane takes part in the wave reductions
   const size_t lo = active ? offsets[job] : 0, hi = active ? offsets[job + 1] : 0;
   W12 acc;
@@ -292,8 +292,8 @@ BN_DEV LineW line_get(PTR at, size_t stride) {
 // identity walks through the formulas with Z = 0 exactly as in glued_miller_chunks.
 __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, const u64* offsets,
                                           size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity, u32x4* table) {
-  const size_t t = TID, u = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, u = pair_index(t);
+  const int odd = pair_role(t);
   if (u >= (size_t)kt * jb) return;
   const size_t slot = u / jb, jl = u - slot * jb, job = job0 + jl;
   const size_t lo = offsets[job], hi = offsets[job + 1], idx = lo + slot;
@@ -344,8 +344,8 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
 // [87*24][n], triple t of point i at words 24t .. 24t+23 = (ell.0, ell.1, ell.2) as Fp2 each -- the reference's [Ell; 87] in its own
 // order and with its own (unscaled) values: the same walk as k_pair_lines without a G1 point
 __global__ void HEAVY_BOUNDS k_g2_precompute_pairs(const u64* qxy, u64* coeffs, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const S2 qxs = load_s2(qxy, n, i, 0, odd), qys = load_s2(qxy, n, i, 8, odd);
   const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
@@ -421,8 +421,8 @@ BN_NOINLINE void glued_miller_tables(W12& fout, const u32x4* at_generic, size_t 
 __global__ void HEAVY_BOUNDS k_glued_from_tables(const u32x4* table, const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf,
                                                  const u64* offsets, size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity,
                                                  u64* fout, size_t n_out, size_t out0) {
-  const size_t t = TID, jl = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, jl = pair_index(t);
+  const int odd = pair_role(t);
   const bool active = jl < jb;                 // no early return: every lane takes part in the wave reductions
   const size_t job = job0 + (active ? jl : 0);
   const size_t lo = offsets[job], hi = offsets[job + 1];
@@ -445,8 +445,8 @@ __global__ void HEAVY_BOUNDS k_glued_from_tables(const u32x4* table, const u64* 
 // PHASE C: final exponentiation of the batch's raw values (a kernel of its own: fused behind phase B it ran a third slower -- every
 // wavefront of the one-round launch reaches the exponentiation, and its stack frame traffic, at the same moment)
 __global__ void HEAVY_BOUNDS k_final_exp_jobs(const u64* fin, size_t n_in, size_t job0, size_t jb, size_t n_jobs, u64* gout, uint8_t* is_one) {
-  const size_t t = TID, jl = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, jl = pair_index(t);
+  const int odd = pair_role(t);
   if (jl >= jb) return;
   S12 f, g;
   load_s12(f, fin, n_in, jl, odd);
@@ -472,8 +472,8 @@ __global__ void k_chunk_offsets(u64* off, size_t n_jobs, size_t n_pairs, size_t 
 }
 // out[i] = in[2 i] * in[2 i + 1] (the odd tail is copied), SoA strides n_in / n_out
 __global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* out, size_t n_out) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n_out) return;
   S12 a;
   load_s12(a, in, n_in, 2 * i, odd);
@@ -491,8 +491,8 @@ __global__ void HEAVY_BOUNDS k_fp12_tree_level(const u64* in, size_t n_in, u64* 
 // the last levels of a product tree (m <= BLOCK values, SoA stride `stride`, multiplied IN PLACE: value i absorbs value i + h, a level per
 // barrier instead of a launch per level); the product leaves in `out` with stride 1
 __global__ void HEAVY_BOUNDS k_fp12_tree_tail(u64* vals, size_t stride, size_t m, u64* out) {
-  const size_t i = threadIdx.x >> 1;
-  const int odd = (int)(threadIdx.x & 1);
+  const size_t i = pair_index(threadIdx.x);
+  const int odd = pair_role(threadIdx.x);
   while (m > 1) {
     const size_t h = (m + 1) / 2;
     if (i + h < m) {
@@ -518,14 +518,14 @@ __global__ void HEAVY_BOUNDS k_fp12_tree_tail(u64* vals, size_t stride, size_t m
 }
 // f = 1 (the empty Miller product), SoA stride 1
 __global__ void k_fp12_set_one(u64* out) {
-  if (TID >= 2) return;
-  store_s12(out, 1, 0, (int)(TID & 1), s12_one());
+  if (pair_index(TID) != 0) return;
+  store_s12(out, 1, 0, pair_role(TID), s12_one());
 }
 // out = a * b, all SoA stride 1 (two raw Miller products)
 __global__ void HEAVY_BOUNDS k_fp12_mul_pair(const u64* a, const u64* b, u64* out) {
   const size_t t = TID;
-  const int odd = (int)(t & 1);
-  if (t >= 2) return;
+  const int odd = pair_role(t);
+  if (pair_index(t) != 0) return;
   S12 sa, sb;
   load_s12(sa, a, 1, 0, odd);
   load_s12(sb, b, 1, 0, odd);
@@ -539,8 +539,8 @@ __global__ void HEAVY_BOUNDS k_fp12_mul_pair(const u64* a, const u64* b, u64* ou
 // column `col` of a G2 pair array (stride `stride`) <- the generator (src NULL) or element 0 of a one-key array
 __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t col, const u64* src_xy, const uint8_t* src_inf) {
   const size_t t = TID;
-  const int odd = (int)(t & 1);
-  if (t >= 2) return;
+  const int odd = pair_role(t);
+  if (pair_index(t) != 0) return;
   store_s2(qxy, stride, col, 0, odd, src_xy ? load_s2(src_xy, 1, 0, 0, odd) : s2_g2gen_x());
   store_s2(qxy, stride, col, 8, odd, src_xy ? load_s2(src_xy, 1, 0, 8, odd) : s2_g2gen_y());
   if (!odd) qinf[col] = (src_xy && src_inf && src_inf[0]) ? 1 : 0;
@@ -550,7 +550,7 @@ __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t c
 __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, size_t stride, const u64* range, u64* fout) {
   __shared__ WideLds lds;
   const size_t t = TID;
-  const int odd = (int)(t & 1);
+  const int odd = pair_role(t);
   const size_t i = range ? (size_t)range[0] : 0;
   const bool empty = range && range[1] <= range[0];
   S12 f;
@@ -561,7 +561,7 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
     const S2 qx = load_s2(qxy, stride, i, 0, odd), qy = load_s2(qxy, stride, i, 8, odd);
     miller_loop29_wide(f, px, py, qx, qy, &lds);
   }
-  if (t < 2) store_s12(fout, 1, 0, odd, f);
+  if (pair_index(t) == 0) store_s12(fout, 1, 0, odd, f);
 }
 // Small batches, one WAVEFRONT per element (grid = n blocks of 64): block b takes pair b of set A, block n + b pair b of set B (B optional).
 // qxy NULL = the G2 generator for every pair of that set.  An identity on either side gives 1.  Raw Miller values, SoA stride n.
@@ -573,7 +573,7 @@ __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* p
   const u64 *pxy = second ? pb : pa, *qxy = second ? qb : qa;
   const uint8_t *pinf = second ? pb_inf : pa_inf, *qinf = second ? qb_inf : qa_inf;
   u64* fout = second ? fb : fa;
-  const int odd = (int)(threadIdx.x & 1);
+  const int odd = pair_role(threadIdx.x);
   S12 f;
   if ((pinf && pinf[i]) || (qinf && qinf[i])) {
     f = s12_one();
@@ -582,13 +582,13 @@ __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* p
     const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
     miller_loop29_wide(f, px, py, qx, qy, &lds);
   }
-  if (threadIdx.x < 2) store_s12(fout, n, i, odd, f);
+  if (pair_index(threadIdx.x) == 0) store_s12(fout, n, i, odd, f);
 }
 // final_exponentiation(fa_b * fb_b) (fb optional), one wavefront per element: Gt values (SoA stride n) and / or "== identity" flags
 __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb, size_t n, u64* gout, uint8_t* is_one) {
   __shared__ WideLds lds;
   const size_t i = blockIdx.x;
-  const int odd = (int)(threadIdx.x & 1);
+  const int odd = pair_role(threadIdx.x);
   S12 f, g;
   load_s12(f, fa, n, i, odd);
   if (fb) {
@@ -601,7 +601,7 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb
     w12_to_s12(f, r);
   }
   final_exponentiation29_wide(g, f, &lds);
-  if (threadIdx.x >= 2) return;
+  if (pair_index(threadIdx.x) != 0) return;
   if (gout) store_s12(gout, n, i, odd, g);
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[i] = one ? 1 : 0;
@@ -611,7 +611,7 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb
 __global__ void HEAVY_BOUNDS k_final_exp_wide_jobs(const u64* raw, size_t n_pairs, const u64* offsets, size_t n_jobs, u64* gout, uint8_t* is_one) {
   __shared__ WideLds lds;
   const size_t j = blockIdx.x;
-  const int odd = (int)(threadIdx.x & 1);
+  const int odd = pair_role(threadIdx.x);
   const size_t lo = offsets[j], hi = offsets[j + 1];
   S12 f, g;
   if (hi <= lo) {
@@ -632,7 +632,7 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_jobs(const u64* raw, size_t n_pair
     }
   }
   final_exponentiation29_wide(g, f, &lds);
-  if (threadIdx.x >= 2) return;
+  if (pair_index(threadIdx.x) != 0) return;
   if (gout) store_s12(gout, n_jobs, j, odd, g);
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[j] = one ? 1 : 0;
@@ -642,12 +642,12 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_jobs(const u64* raw, size_t n_pair
 __global__ void HEAVY_BOUNDS k_final_exp_flag(const u64* fin, size_t n_in, u64* gout, uint8_t* is_one, int wide) {
   __shared__ WideLds lds;
   const size_t t = TID;
-  const int odd = (int)(t & 1);
-  if (!wide && t >= 2) return;
+  const int odd = pair_role(t);
+  if (!wide && pair_index(t) != 0) return;
   S12 f, g;
   if (n_in) load_s12(f, fin, n_in, 0, odd); else f = s12_one();      // empty product = identity (pairing.rs:1218-1219)
   if (wide) final_exponentiation29_wide(g, f, &lds); else final_exponentiation29(g, f);
-  if (t >= 2) return;
+  if (pair_index(t) != 0) return;
   if (gout) store_s12(gout, 1, 0, odd, g);
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[0] = one ? 1 : 0;
@@ -677,8 +677,8 @@ BN_DEV F29 f29_from_plain(const Fp& x) {
 // fewer pairs than the wavefront maximum multiplies by the unit line
 __global__ void HEAVY_BOUNDS k_miller_precomputed(const u64* coeffs, size_t m, const u64* tab_idx, const u64* pxy, size_t n_pairs,
                                                   const u64* offsets, size_t n_jobs, u64* fout) {
-  const size_t t = TID, job = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, job = pair_index(t);
+  const int odd = pair_role(t);
   const bool active = job < n_jobs;
   const size_t lo = !active ? 0 : offsets ? offsets[job] : job, hi = !active ? 0 : offsets ? offsets[job + 1] : job + 1;
   const int kw = wave_max((int)(hi - lo));

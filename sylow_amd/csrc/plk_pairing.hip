@@ -5,8 +5,8 @@
 namespace plk {
 // ------------------------------------------------------------------ pairing(), Miller loop, final exponentiation ------
 __global__ void HEAVY_BOUNDS k_miller_loop(const u64* pxy, const u64* qxy, u64* fout, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
   const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
@@ -15,8 +15,8 @@ __global__ void HEAVY_BOUNDS k_miller_loop(const u64* pxy, const u64* qxy, u64* 
   store_s12(fout, n, i, odd, f);
 }
 __global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   S12 f, g;
   load_s12(f, fin, n, i, odd);
@@ -25,8 +25,8 @@ __global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
 }
 // pairing.rs:870-893
 __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   const bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
   S12 g;
@@ -48,8 +48,8 @@ enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 =
        OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28,
        OPW_SPARSE_UNIT = 29, OPW_LAST = 29 };   // 29: first line coefficient = (element index & 1), the other two from `b` as for 18
 __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   S12 sx, sy, sr;
   load_s12(sx, a, n, i, odd);

@@ -30,8 +30,8 @@ BN_DEV bool hash_to_g1_pair(Fp& hx, Fp& hy, bool& hinf, const uint8_t* msg, size
 constexpr int LINES_BLOCK = 192;
 __global__ void __launch_bounds__(LINES_BLOCK) k_g2_lines29(const u64* qxy, size_t n, size_t idx, i32* table) {
   __shared__ i32 raw[LINE_TABLE_LINES][3][2][9];
-  const int odd = (int)(threadIdx.x & 1);
-  if (threadIdx.x < 2) {
+  const int odd = pair_role(threadIdx.x);
+  if (pair_index(threadIdx.x) == 0) {
     S2 qxs = s2_g2gen_x(), qys = s2_g2gen_y();
     if (qxy) { qxs = load_s2(qxy, n, idx, 0, odd); qys = load_s2(qxy, n, idx, 8, odd); }
     const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys), nqy = w2_from_s2(s2_neg(qys));
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(LINES_BLOCK) k_g2_lines29(const u64* qxy, size
     g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2); put();
   }
   __syncthreads();
-  const int line = (int)(threadIdx.x >> 1);
+  const int line = (int)(pair_index(threadIdx.x));
   if (line >= LINE_TABLE_LINES) return;
   auto get = [&](int k) {
     const i32* t = raw[line][k][odd];
@@ -90,8 +90,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
   __shared__ i32 tabA[LINE_TABLE_WORDS];
   stage_table(tabA, gen_table);
   __syncthreads();
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   if (i >= n) return;
   Fp hx, hy; bool hinf;
   hash_to_g1_pair(hx, hy, hinf, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
@@ -151,8 +151,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   stage_table(tabA, gen_table);
   if (PK_TABLE) stage_table(tabB, pk_table);
   __syncthreads();
-  const size_t t = TID, i = t >> 1;
-  const int odd = (int)(t & 1);
+  const size_t t = TID, i = pair_index(t);
+  const int odd = pair_role(t);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
   Fp hxs, hys; bool hinf;                                                    // pair B is (-H, pk)
