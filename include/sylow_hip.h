@@ -68,6 +68,9 @@ int32_t sylow_hip_set_device(int32_t device);
  * stays usable: state is rebuilt on demand.  EXCLUSIVE: while another host thread is inside an entry point that holds a scratch
  * block the call frees nothing and returns SYLOW_HIP_E_ARG. */
 int32_t sylow_hip_shutdown(void);
+/* Frees the current device's idle scratch blocks larger than keep_bytes whose last user has completed (blocks grow with the largest
+ * batch seen and are otherwise kept for reuse until sylow_hip_shutdown).  Never blocks, never touches a block that is in use. */
+int32_t sylow_hip_trim(size_t keep_bytes);
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
 int32_t sylow_hip_malloc(void** dptr, size_t bytes);
@@ -206,6 +209,10 @@ int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* 
 /* GroupAffine::from(&GroupProjective) (group.rs:475-495) */
 int32_t sylow_hip_g1_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
+/* sum_i P_i of a batch of G1 points as ONE point (the `+` fold over signatures / hashes of
+ * examples/verify_multiple_messages_same_signer.rs:41-60, Add for G1Projective, group.rs:528-599): p_xy [8][n] affine + flags in,
+ * out_xy [8][1] + out_inf [1] out; n = 0 gives the identity.  Serial per-lane accumulation in stages (g1.hip), complete formulas. */
+int32_t sylow_hip_g1_sum_batch(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* out_xy, uint8_t* out_inf, void* stream);
 /* G1Affine::new (g1.rs:111-132): status[i] = OK when y^2 == x^3 + 3 (or the identity flag is set), NOT_ON_CURVE otherwise */
 int32_t sylow_hip_g1_on_curve_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* status, size_t n, void* stream);
 /* G2Affine::endomorphism (g2.rs:140-152): psi(x, y) = (xi^((p-1)/3) conj x, xi^((p-1)/2) conj y), identity -> identity.
@@ -402,8 +409,8 @@ int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t*
  * verify(&G2Projective, &[u8], &G1Projective) -> bool, lib.rs:223-236): a host that switches holds arrays of structs in HOST memory.
  * These two calls are the batched forms on such arrays -- EVERY pointer is a HOST pointer, element-major ("array of structs", what a
  * Rust Vec<[u64; W]> is): p_aos [n][8] (x, y), q_aos / pk_aos [n][16], sig_aos [n][8], gt_aos [n][48], flags [n] (NULL = none), msgs +
- * msg_offsets [n + 1] as in sylow_hip_bls_verify_batch, ok [n].  The batch is cut into chunks of `chunk` elements (0 = 2^16: one resident
- * set of lane pairs) that alternate between two internal streams, each chunk H2D -> AoS->SoA -> the same kernels as the device-pointer
+ * msg_offsets [n + 1] as in sylow_hip_bls_verify_batch, ok [n].  The batch is cut into chunks -- `chunk` elements (0 = 2^16: one resident
+ * set of lane pairs) first and last, up to four times that in between -- that alternate between two internal streams, each chunk H2D -> AoS->SoA -> the same kernels as the device-pointer
  * entry points -> D2H, issued so that the copy engines move chunk k - 1 out and chunk k + 1 in while chunk k computes.  Synchronous:
  * the results are in host memory when the call returns.  Bit-identical to upload + sylow_hip_pairing_batch /
  * sylow_hip_bls_verify_batch + download.  Pageable memory works; pinned memory (sylow_hip_host_malloc) makes every copy asynchronous. */

@@ -292,6 +292,18 @@ inline bool verify_all(const std::vector<G2Affine>& pubkey, const std::vector<st
   if (product) *product = from_device_soa<Gt>(dgt, 1)[0];
   return one != 0;
 }
+// sum_i p[i] as ONE point (the `+` fold of examples/verify_multiple_messages_same_signer.rs:41-60); *is_identity receives the flag of the result
+inline G1Affine sum(const std::vector<G1Affine>& p, bool* is_identity = nullptr, const std::vector<uint8_t>* p_inf = nullptr) {
+  const size_t n = p.size();
+  auto dp = to_device_soa(p);
+  Flags dpi(p_inf, n);
+  DeviceBuffer dout(sizeof(G1Affine) + 8), dinf(8);
+  check(sylow_hip_g1_sum_batch(dp.as<uint64_t>(), dpi.ptr, n, dout.as<uint64_t>(), dinf.as<uint8_t>(), nullptr), "sylow_hip_g1_sum_batch");
+  std::vector<uint8_t> f;
+  fetch_flags(&f, dinf, 1);
+  if (is_identity) *is_identity = f[0] != 0;
+  return from_device_soa<G1Affine>(dout, 1)[0];
+}
 // Sub for &G1Projective (group.rs:614-624), elementwise on affine inputs
 inline std::vector<G1Affine> sub(const std::vector<G1Affine>& a, const std::vector<G1Affine>& b, std::vector<uint8_t>* inf_out = nullptr) {
   if (a.size() != b.size()) throw Error("G1 - G1: length mismatch");

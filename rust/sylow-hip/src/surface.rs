@@ -762,3 +762,18 @@ pub fn verify_words_host(pk: &[[u64; 16]], pk_inf: Option<&[u8]>, msgs: &[u8], o
                                        sig.as_ptr() as *const u64, sig_inf.map_or(std::ptr::null(), |f| f.as_ptr()), ok.as_mut_ptr(), n, 0)
     })
 }
+
+/// sum_i p[i] as one point (`sylow_hip_g1_sum_batch`): the `+` fold of examples/verify_multiple_messages_same_signer.rs:41-60 over a resident batch.
+pub fn g1_sum(dev: &Device, p: &DeviceG1) -> Result<G1Projective, HipError> {
+    let out = DeviceG1 { xy: dev.alloc::<u64>(8)?, inf: dev.alloc::<u8>(1)?, n: 1 };
+    // SAFETY: p holds p.n points and flags; out one point and one flag.
+    device::check(unsafe { ffi::sylow_hip_g1_sum_batch(p.xy.as_ptr(), p.inf.as_ptr(), p.n, out.xy.as_mut_ptr(), out.inf.as_mut_ptr(), dev.stream) })?;
+    Ok(download_g1(dev, &out)?.remove(0))
+}
+
+/// Hand the current device's idle scratch blocks above `keep_bytes` back to the driver (`sylow_hip_trim`): the library keeps the largest
+/// block a call has needed for reuse, which after a 2^20-pair product is several GB.
+pub fn trim(keep_bytes: usize) -> Result<(), device::Error> {
+    // SAFETY: plain value argument.
+    device::check(unsafe { ffi::sylow_hip_trim(keep_bytes) })
+}

@@ -135,6 +135,8 @@ SIGNATURES = {
     "sylow_hip_pairing_product_all": [c_u64p, c_u8p, c_u64p, c_u8p, c_sz, c_i32, c_vp, c_u64p, c_u8p, c_vp],
     "sylow_hip_fp12_cyclotomic_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
+    "sylow_hip_trim": [c_sz],
+    "sylow_hip_g1_sum_batch": [c_u64p, c_u8p, c_sz, c_u64p, c_u8p, c_vp],
     "sylow_hip_pairing_host": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz],
     "sylow_hip_bls_verify_host": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],
     "sylow_hip_pairing_host_bytes": [c_u8p, c_u8p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],

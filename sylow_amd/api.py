@@ -438,14 +438,28 @@ class KeyTable:
 
 def batch_verify(pubkey: G2Affine, msgs, sig: G1Affine, weight_bits: int = 128, seed=None) -> bool:
     """Sound one-boolean batch verification (the small-exponent test): prod_i [e(sig_i, G2gen) e(-H(m_i), pk_i)]^(w_i) == identity
-    with fresh `weight_bits`-bit weights from the operating system's generator (an int `seed` draws reproducible weights: tests
-    only).  True when every signature is valid; a batch with an invalid one passes with probability <= 2^-weight_bits."""
+    with fresh non-zero `weight_bits`-bit weights from the operating system's generator (an int `seed` draws reproducible weights:
+    tests only).  True when every signature is valid; a batch with an invalid one passes with probability <= 2^-weight_bits PROVIDED
+    the keys lie in G2 proper: keys whose r-torsion membership is not established (a G2Affine built from raw coordinates) go through
+    the subgroup check first and a failing one raises, exactly where G2Projective::new (g2.rs:460-525) would have refused the key."""
+    if not 1 <= int(weight_bits) <= 128:
+        raise ValueError("weight_bits must be in 1..128")
+    if not pubkey.in_subgroup:
+        st = engine().g2_subgroup_check(pubkey.xy, pubkey.infinity)
+        if np.any(st != 0):
+            raise ValueError(f"batch_verify: public key {int(np.flatnonzero(st != 0)[0])} is not a point of G2 (status {int(st[st != 0][0])})")
     n = len(sig)
+    mask = (1 << weight_bits) - 1
     if seed is None:
         import secrets
-        w = fp([secrets.randbits(weight_bits) | 1 for _ in range(n)])
+        w = []
+        while len(w) < n:                                  # uniform over [1, 2^weight_bits): zero is redrawn, no bit is forced
+            v = secrets.randbits(weight_bits)
+            if v:
+                w.append(v)
+        w = fp(w)
     else:
-        w = fp([((int(v) & ((1 << weight_bits) - 1)) | 1) for v in _ints(engine().xoshiro_fp_soa(seed, n).T)])
+        w = fp([(int(v) & mask) or 1 for v in _ints(engine().xoshiro_fp_soa(seed, n).T)])
     _, ok = engine().bls_batch_verify_weighted(pubkey.xy, list(msgs), sig.xy, w, pubkey.infinity, sig.infinity)
     return ok
 

@@ -319,18 +319,6 @@ BN_DEV Fp fp_add_lazy(const Fp& a, const Fp& b) {
       : "vcc");
   return s;
 }
-// a / 2 mod p: (a + (a odd ? p : 0)) >> 1.  Halving commutes with the Montgomery factor, so this is exactly
-// a * TWO_INV (fp2.rs:18-23) at ~26 instructions instead of a full product.
-BN_DEV Fp fp_halve(const Fp& a) {
-  const u32 mask = 0u - (a.v[0] & 1u);
-  const u32 q[8] = {BN_P0 & mask, BN_P1 & mask, BN_P2 & mask, BN_P3 & mask, BN_P4 & mask, BN_P5 & mask, BN_P6 & mask, BN_P7 & mask};
-  Fp t = fp_add_lazy(a, fp_from_limbs(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]));   // < 2p < 2^255: no carry out
-  Fp r;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) r.v[i] = (t.v[i] >> 1) | (t.v[i + 1] << 31);
-  r.v[7] = t.v[7] >> 1;
-  return r;
-}
 
 // (9a + s*b) mod p for s = +-1: the two coordinates of x*(9+u) (fp2.rs:99-107) as ONE multiply-by-9 pass instead of
 // five modular add/subs.  t = 9a + (s > 0 ? b : p - b) is a 9-word value < 10p; its quotient by p is estimated
@@ -458,14 +446,6 @@ BN_DEV Fp fp_inv(const Fp& a) { return fp_inv_safegcd(a); }
 // the Fermat twin, kept for the tests
 BN_DEV Fp fp_inv_fermat(const Fp& a) {
   return fp_pow_words(a, BN_P0 - 2, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7);
-}
-// a^((p-1)/2)  (Legendre; fp.rs:625-631)
-BN_DEV Fp fp_pow_pm1_half(const Fp& a) {
-  return fp_pow_words(a, 0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u);
-}
-// a^((p+1)/4)  (sqrt candidate; fp.rs:611-616)
-BN_DEV Fp fp_pow_pp1_quarter(const Fp& a) {
-  return fp_pow_words(a, 0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu);
 }
 
 // a^((p-3)/4): one chain serves both the Legendre symbol (a * t^2 = a^((p-1)/2)) and the square-root candidate

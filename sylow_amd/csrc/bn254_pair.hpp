@@ -103,11 +103,9 @@ BN_DEV S2 s2_add(const S2& a, const S2& b) { return S2{fp_add(a.c, b.c)}; }
 BN_DEV S2 s2_sub(const S2& a, const S2& b) { return S2{fp_sub(a.c, b.c)}; }
 BN_DEV S2 s2_neg(const S2& a) { return S2{fp_neg(a.c)}; }
 BN_DEV S2 s2_dbl(const S2& a) { return S2{fp_dbl(a.c)}; }
-BN_DEV S2 s2_halve(const S2& a) { return S2{fp_halve(a.c)}; }
 BN_DEV S2 s2_conj(const S2& a) { return S2{sel(lane_odd(), a.c, fp_neg(a.c))}; }
 BN_DEV S2 s2_mul(const S2& a, const S2& b) { return S2{s2_mul_leaf(a.c, b.c)}; }
 BN_DEV S2 s2_sqr(const S2& a) { return S2{s2_sqr_leaf(a.c)}; }
-BN_DEV S2 s2_scale(const S2& a, const Fp& k) { return S2{fp_mul(a.c, k)}; }
 // x (9 + u): even 9 a0 - a1, odd 9 a1 + a0
 BN_DEV S2 s2_mul_xi(const S2& a) {
   const Fp o = xchg(a.c);
@@ -165,7 +163,6 @@ BN_DEV S6 s6_sqr(const S6& a) {
   r.c2 = s2_sub(s2_sub(s2_add(s2_add(s1, s2), s3), s0), s4);
   return r;
 }
-BN_DEV S6 s6_scale(const S6& a, const S2& k) { return S6{s2_mul(a.c0, k), s2_mul(a.c1, k), s2_mul(a.c2, k)}; }
 // fp6.rs:415-423
 BN_DEV S6 s6_inv(const S6& a) {
   S2 t0 = s2_sub(s2_sqr(a.c0), s2_mul(a.c1, s2_mul_xi(a.c2)));
@@ -174,18 +171,6 @@ BN_DEV S6 s6_inv(const S6& a) {
   S2 d = s2_add(s2_mul_xi(s2_add(s2_mul(a.c2, t1), s2_mul(a.c1, t2))), s2_mul(a.c0, t0));
   S2 di = s2_inv(d);
   return S6{s2_mul(di, t0), s2_mul(di, t1), s2_mul(di, t2)};
-}
-// fp6.rs:203-209
-template <int E>
-BN_DEV S6 s6_frobenius(const S6& a) {
-  constexpr bool oddE = (E & 1) != 0;
-  const uint32_t (&k1)[2][8] = (E == 1) ? C_FROB6_C1_1 : (E == 2) ? C_FROB6_C1_2 : C_FROB6_C1_3;
-  const uint32_t (&k2)[2][8] = (E == 1) ? C_FROB6_C2_1 : (E == 2) ? C_FROB6_C2_2 : C_FROB6_C2_3;
-  S6 r;
-  r.c0 = oddE ? s2_conj(a.c0) : a.c0;
-  r.c1 = s2_mul(oddE ? s2_conj(a.c1) : a.c1, s2_const(k1));
-  r.c2 = s2_mul(oddE ? s2_conj(a.c2) : a.c2, s2_const(k2));
-  return r;
 }
 
 // ------------------------------------------------------------------ S12 -----------------------------------------
@@ -218,57 +203,6 @@ BN_DEV S12 s12_inv(const S12& a) {
   S6 t = s6_inv(d);
   return S12{s6_mul(a.c0, t), s6_neg(s6_mul(a.c1, t))};
 }
-// fp12.rs:515-522
-template <int E>
-BN_DEV S12 s12_frobenius(const S12& a) {
-  const uint32_t (&k)[2][8] = (E == 1) ? C_FROB12_C1_1 : (E == 2) ? C_FROB12_C1_2 : C_FROB12_C1_3;
-  return S12{s6_frobenius<E>(a.c0), s6_scale(s6_frobenius<E>(a.c1), s2_const(k))};
-}
-// fp12.rs:426-503 (mul_by_024): f * (x0 + x2 v^2... ) with x0 = ell_0, x2 = ell_vv, x4 = ell_vw; 13 products
-BN_DEV S12 s12_sparse_mul(const S12& f, const S2& ell_0, const S2& ell_vw, const S2& ell_vv) {
-  const S2 x0 = ell_0, x2 = ell_vv, x4 = ell_vw;
-  const S2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
-  const S2 d0 = s2_mul(z0, x0);
-  const S2 d2 = s2_mul(z2, x2);
-  const S2 d4 = s2_mul(z4, x4);
-  S12 o;
-  S2 s1 = s2_mul(z1, x2);
-  o.c0.c0 = s2_add(s2_mul_xi(s2_add(s1, d4)), d0);
-  {
-    S2 t3 = s2_mul(z5, x4);
-    s1 = s2_add(s1, t3);
-    S2 t4 = s2_mul_xi(s2_add(t3, d2));
-    t3 = s2_mul(z1, x0);
-    s1 = s2_add(s1, t3);
-    o.c0.c1 = s2_add(t4, t3);
-  }
-  {
-    S2 t3 = s2_sub(s2_sub(s2_mul(s2_add(z0, z2), s2_add(x0, x2)), d0), d2);
-    S2 t4 = s2_mul(z3, x4);
-    s1 = s2_add(s1, t4);
-    o.c0.c2 = s2_add(t3, t4);
-  }
-  {
-    S2 t3 = s2_sub(s2_sub(s2_mul(s2_add(z2, z4), s2_add(x2, x4)), d2), d4);
-    S2 t4 = s2_mul_xi(t3);
-    t3 = s2_mul(z3, x0);
-    s1 = s2_add(s1, t3);
-    o.c1.c0 = s2_add(t4, t3);
-  }
-  {
-    S2 t3 = s2_mul(z5, x2);
-    s1 = s2_add(s1, t3);
-    S2 t4 = s2_mul_xi(t3);
-    t3 = s2_sub(s2_sub(s2_mul(s2_add(z0, z4), s2_add(x0, x4)), d0), d4);
-    o.c1.c1 = s2_add(t4, t3);
-  }
-  {
-    S2 s0 = s2_add(s2_add(z1, z3), z5);
-    S2 t0 = s2_add(s2_add(x0, x2), x4);
-    o.c1.c2 = s2_sub(s2_mul(s0, t0), s1);
-  }
-  return o;
-}
 BN_DEV bool s12_is_one(const S12& a) {
   bool z = s2_eq(a.c0.c0, s2_one());
   z = z && s2_is_zero(a.c0.c1) && s2_is_zero(a.c0.c2) && s2_is_zero(a.c1.c0) && s2_is_zero(a.c1.c1) && s2_is_zero(a.c1.c2);
@@ -277,77 +211,10 @@ BN_DEV bool s12_is_one(const S12& a) {
 
 // ------------------------------------------------------------------ Miller loop ---------------------------------
 struct G2S { S2 x, y, z; };
-// pairing.rs:798-818
-BN_DEV void g2_doubling_step(G2S& r, S2& l0, S2& l1, S2& l2) {
-  S2 a = s2_halve(s2_mul(r.x, r.y));
-  {
-    S2 j = s2_sqr(r.x);
-    l2 = s2_add(s2_dbl(j), j);
-  }
-  S2 b = s2_sqr(r.y);
-  S2 c = s2_sqr(r.z);
-  S2 h = s2_sub(s2_sqr(s2_add(r.y, r.z)), s2_add(b, c));
-  S2 e = s2_mul(s2_const(C_TWIST_B), s2_add(s2_dbl(c), c));
-  l1 = s2_neg(h);
-  r.z = s2_mul(b, h);
-  l0 = s2_mul_xi(s2_sub(e, b));
-  S2 f = s2_add(s2_dbl(e), e);
-  r.x = s2_mul(a, s2_sub(b, f));
-  S2 g = s2_halve(s2_add(b, f));
-  S2 esq = s2_sqr(e);
-  r.y = s2_sub(s2_sqr(g), s2_add(s2_dbl(esq), esq));
-}
-// pairing.rs:756-772
-BN_DEV void g2_addition_step(G2S& r, const S2& bx, const S2& by, S2& l0, S2& l1, S2& l2) {
-  S2 d = s2_sub(r.x, s2_mul(r.z, bx));
-  S2 e = s2_sub(r.y, s2_mul(r.z, by));
-  l0 = s2_mul_xi(s2_sub(s2_mul(e, bx), s2_mul(d, by)));
-  l1 = d;
-  l2 = s2_neg(e);
-  S2 f = s2_sqr(d);
-  S2 h = s2_mul(d, f);
-  S2 i = s2_mul(r.x, f);
-  S2 j = s2_sub(s2_add(s2_mul(r.z, s2_sqr(e)), h), s2_dbl(i));
-  r.z = s2_mul(r.z, h);
-  r.x = s2_mul(d, j);
-  r.y = s2_sub(s2_mul(e, s2_sub(i, j)), s2_mul(h, r.y));
-}
 // g2.rs:140-152
 BN_DEV void g2_psi_affine(S2& xo, S2& yo, const S2& x, const S2& y) {
   xo = s2_mul(s2_const(C_EPS_EXP0), s2_conj(x));
   yo = s2_mul(s2_const(C_EPS_EXP1), s2_conj(y));
-}
-// f <- f * line(P): sparse_mul(c0, c1 * P.y, c2 * P.x)  (pairing.rs:598)
-BN_DEV S12 s12_line(const S12& f, const S2& l0, const S2& l1, const S2& l2, const Fp& px, const Fp& py) {
-  return s12_sparse_mul(f, l0, s2_scale(l1, py), s2_scale(l2, px));
-}
-// pairing.rs:590-619 fused with :676-708; P, Q affine and finite
-BN_NOINLINE void miller_loop(S12& fout, const Fp& px, const Fp& py, const S2& qx, const S2& qy) {
-  S12 f = s12_one();
-  G2S r{qx, qy, s2_one()};
-  const S2 nqy = s2_neg(qy);
-  S2 l0, l1, l2;
-  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
-#pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    g2_doubling_step(r, l0, l1, l2);
-    f = s12_sqr(f);
-    f = s12_line(f, l0, l1, l2, px, py);
-    if ((nz >> (63 - i)) & 1) {
-      const bool neg = (ng >> (63 - i)) & 1;
-      g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
-      f = s12_line(f, l0, l1, l2, px, py);
-    }
-  }
-  S2 q1x, q1y, q2x, q2y;
-  g2_psi_affine(q1x, q1y, qx, qy);
-  g2_psi_affine(q2x, q2y, q1x, q1y);
-  q2y = s2_neg(q2y);
-  g2_addition_step(r, q1x, q1y, l0, l1, l2);
-  f = s12_line(f, l0, l1, l2, px, py);
-  g2_addition_step(r, q2x, q2y, l0, l1, l2);
-  f = s12_line(f, l0, l1, l2, px, py);
-  fout = f;
 }
 
 // ------------------------------------------------------------------ final exponentiation ------------------------
@@ -377,11 +244,6 @@ BN_DEV S12 cyclotomic_sqr(const S12& f) {
   r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
   return r;
 }
-// out-of-line twins for the straight-line part of the hard part (called ~20 times per pairing: the operands'
-// trip through the stack frame is noise there, and the code stays small)
-BN_NOINLINE void s12_mul_nl(S12& r, const S12& a, const S12& b) { r = s12_mul(a, b); }
-BN_NOINLINE void cyclotomic_sqr_nl(S12& r, const S12& a) { r = cyclotomic_sqr(a); }
-template <int E> BN_NOINLINE void s12_frobenius_nl(S12& r, const S12& a) { r = s12_frobenius<E>(a); }
 // pairing.rs:366-392 with the width-3 signed-digit form of x (see exp_by_neg_z_sat in bn254_pairing.hpp)
 BN_NOINLINE void exp_by_neg_z(S12& r, const S12& f) {
   const S12 f3 = s12_mul(cyclotomic_sqr(f), f);
@@ -397,37 +259,6 @@ BN_NOINLINE void exp_by_neg_z(S12& r, const S12& f) {
     }
   }
   r = s12_conj(res);
-}
-// pairing.rs:245-492
-BN_NOINLINE void final_exponentiation(S12& out, const S12& fin) {
-  S12 in, t, a, b, d, e, g;
-  a = s12_conj(fin);
-  b = s12_inv(fin);
-  s12_mul_nl(t, a, b);
-  s12_frobenius_nl<2>(a, t);
-  s12_mul_nl(in, a, t);
-  exp_by_neg_z(a, in);
-  cyclotomic_sqr_nl(b, a);
-  cyclotomic_sqr_nl(t, b);
-  s12_mul_nl(d, t, b);
-  exp_by_neg_z(e, d);
-  cyclotomic_sqr_nl(t, e);
-  exp_by_neg_z(g, t);
-  d = s12_conj(d);
-  g = s12_conj(g);
-  s12_mul_nl(t, g, e);
-  s12_mul_nl(a, t, d);
-  s12_mul_nl(d, a, b);
-  s12_mul_nl(t, a, e);
-  s12_mul_nl(e, in, t);
-  s12_frobenius_nl<1>(t, d);
-  s12_mul_nl(b, t, e);
-  s12_frobenius_nl<2>(t, a);
-  s12_mul_nl(e, t, b);
-  t = s12_conj(in);
-  s12_mul_nl(a, t, d);
-  s12_frobenius_nl<3>(t, a);
-  s12_mul_nl(out, t, e);
 }
 
 }  // namespace pl

@@ -411,9 +411,6 @@ BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l
   r.x = w2_mul(dn, j);
   r.y = w2_norm(w2_sub(w2_mul(en, w2_sub(i, j)), w2_mul(h, r.y)));       // e (i - j) - h y, N
 }
-BN_DEV W12 w12_line29(const W12& f, const W2& l0, const W2& l1, const W2& l2, const F29& px, const F29& py) {
-  return w12_sparse_mul(f, l0, w2_scale(l1, py), w2_scale(l2, px));
-}
 // Product of two lines (a0 + a2 v^2 + a4 v w)(b0 + b2 v^2 + b4 v w) with v^3 = xi, w^2 = v:
 //   1: a0 b0 + xi a4 b4   v: xi a2 b2   v^2: a0 b2 + a2 b0   w: xi (a2 b4 + a4 b2)   v w: a0 b4 + a4 b0   v^2 w: 0
 // six Fp2 products (Karatsuba on the three cross terms).  f * l1 * l2 = f * (l1 l2) exactly (field arithmetic).  Used for the
@@ -512,47 +509,6 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   w12_to_s12(fout, f);
 }
 
-// ---- Miller loop: G2 point arithmetic on the saturated lane-pair core, accumulator on the carry-free core ----------
-BN_DEV W12 w12_line(const W12& f, const S2& l0, const S2& l1, const S2& l2, const F29& px, const F29& py) {
-  // sparse_mul(c0, c1 * P.y, c2 * P.x) (pairing.rs:598); f29_from_fp yields N-class digits with V <= 32, the products
-  // with the reduced px / py are N with |V| < 1.1
-  const W2 x0 = w2_from_s2(l0);
-  const W2 x4 = w2_scale(W2{f29_from_fp(l1.c)}, py);
-  const W2 x2 = w2_scale(W2{f29_from_fp(l2.c)}, px);
-  return w12_sparse_mul(f, x0, x4, x2);
-}
-BN_NOINLINE void miller_loop29(S12& fout, const Fp& pxs, const Fp& pys, const S2& qx, const S2& qy) {
-  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
-  W12 f;
-  {
-    S12 one = s12_one();
-    w12_from_s12(f, one);
-  }
-  G2S r{qx, qy, s2_one()};
-  const S2 nqy = s2_neg(qy);
-  S2 l0, l1, l2;
-  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
-#pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    g2_doubling_step(r, l0, l1, l2);
-    f = w12_sqr(f);
-    f = w12_line(f, l0, l1, l2, px, py);
-    if ((nz >> (63 - i)) & 1) {
-      const bool neg = (ng >> (63 - i)) & 1;
-      g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
-      f = w12_line(f, l0, l1, l2, px, py);
-    }
-  }
-  S2 q1x, q1y, q2x, q2y;
-  g2_psi_affine(q1x, q1y, qx, qy);
-  g2_psi_affine(q2x, q2y, q1x, q1y);
-  q2y = s2_neg(q2y);
-  g2_addition_step(r, q1x, q1y, l0, l1, l2);
-  f = w12_line(f, l0, l1, l2, px, py);
-  g2_addition_step(r, q2x, q2y, l0, l1, l2);
-  f = w12_line(f, l0, l1, l2, px, py);
-  w12_to_s12(fout, f);
-}
 
 // ---- final exponentiation, all of it on the carry-free core (one Fp inversion inside the easy part) -----------------------
 // Out-of-line Fp12 routines of the straight-line part.  Operands arrive by reference (an Fp12 is 54 registers per lane, the C ABI

@@ -118,8 +118,6 @@ template <class O> BN_DEV Proj<typename O::F> proj_neg(const Proj<typename O::F>
 
 BN_NOINLINE G1P g1_double(G1P p) { return proj_double<OpsFp>(p); }
 BN_NOINLINE G1P g1_add(G1P p, G1P q) { return proj_add<OpsFp>(p, q); }
-BN_NOINLINE void g2_double(G2P& r, const G2P& p) { r = proj_double<OpsFp2>(p); }
-BN_NOINLINE void g2_add(G2P& r, const G2P& p, const G2P& q) { r = proj_add<OpsFp2>(p, q); }
 
 // ---- where a window table of 0P..8P lives (see G1TableGlobal below for why) ----
 typedef unsigned int g1tab_u32x4 __attribute__((ext_vector_type(4)));
@@ -469,11 +467,6 @@ BN_NOINLINE G1P g1_scalar_mul_ws(G1P p, const u32 (&k)[8], void* region) {
   G1TableGlobal tab{(G1TableGlobal::gptr)region};
   return g1_scalar_mul_t(p, k, tab);
 }
-BN_NOINLINE void g2_scalar_mul(G2P& out, const G2P& p, const u32 (&k)[8]) {
-  out = scalar_mul_window<OpsFp2>(p, k, [](const G2P& a) { G2P r; g2_double(r, a); return r; },
-                                  [](const G2P& a, const G2P& b) { G2P r; g2_add(r, a, b); return r; });
-}
-
 // group.rs:475-495: affine = (X/Z, Y/Z); infinity iff Z^-1 == 0 -> (0, 1, inf)
 BN_DEV void g1_to_affine(Fp& x, Fp& y, bool& inf, const G1P& p) {
   Fp zi = fp_inv(p.z);
@@ -481,18 +474,9 @@ BN_DEV void g1_to_affine(Fp& x, Fp& y, bool& inf, const G1P& p) {
   x = fp_select(fp_mul(p.x, zi), fp_zero(), inf);
   y = fp_select(fp_mul(p.y, zi), fp_one(), inf);
 }
-BN_DEV void g2_to_affine(Fp2& x, Fp2& y, bool& inf, const G2P& p) {
-  Fp2 zi = fp2_inv(p.z);
-  inf = fp2_is_zero(zi);
-  x = fp2_select(fp2_mul(p.x, zi), fp2_zero(), inf);
-  y = fp2_select(fp2_mul(p.y, zi), fp2_one(), inf);
-}
-// g1.rs:111-132 / g2.rs:279-297
+// g1.rs:111-132
 BN_DEV bool g1_on_curve_affine(const Fp& x, const Fp& y) {
   return fp_eq(fp_sub(fp_sqr(y), fp_mul(fp_sqr(x), x)), fp_small(3));
-}
-BN_DEV bool g2_on_curve_affine(const Fp2& x, const Fp2& y) {
-  return fp2_eq(fp2_sub(fp2_sqr(y), fp2_mul(fp2_sqr(x), x)), fp2_const(C_TWIST_B));
 }
 // g2.rs:140-152: psi(x, y) = (eps0 * conj(x), eps1 * conj(y))
 BN_DEV void g2_psi_affine(Fp2& xo, Fp2& yo, const Fp2& x, const Fp2& y) {
@@ -500,93 +484,7 @@ BN_DEV void g2_psi_affine(Fp2& xo, Fp2& yo, const Fp2& x, const Fp2& y) {
   yo = fp2_mul(fp2_const(C_EPS_EXP1), fp2_conj(y));
 }
 
-// ---------------------------------------------------------------- Miller loop -----------------
-// pairing.rs:798-818: doubling step on the twist; returns the three non-zero line coefficients.
-// Same values as the reference's a..j sequence, evaluated in an order that keeps at most five Fp2
-// temporaries live (everything below Fp6 is inlined, so live ranges decide the scratch traffic).
-BN_NOINLINE void g2_doubling_step(G2P& r, Fp2& l0, Fp2& l1, Fp2& l2) {
-  Fp2 a = fp2_halve(fp2_mul(r.x, r.y));          // a = (X*Y) * TWO_INV
-  {
-    Fp2 j = fp2_sqr(r.x);                        // j = X^2
-    l2 = fp2_add(fp2_dbl(j), j);                 // ell.2 = 3j
-  }
-  Fp2 b = fp2_sqr(r.y);                          // b = Y^2
-  Fp2 c = fp2_sqr(r.z);                          // c = Z^2
-  Fp2 h = fp2_sub(fp2_sqr(fp2_add(r.y, r.z)), fp2_add(b, c));   // h = (Y+Z)^2 - (b+c)
-  Fp2 e = fp2_mul(fp2_const(C_TWIST_B), fp2_add(fp2_dbl(c), c)); // e = b' * 3c
-  l1 = fp2_neg(h);                               // ell.1 = -h
-  r.z = fp2_mul(b, h);                           // Z3 = b*h
-  l0 = fp2_mul_xi(fp2_sub(e, b));                // ell.0 = xi * (e - b)
-  Fp2 f = fp2_add(fp2_dbl(e), e);                // f = 3e
-  r.x = fp2_mul(a, fp2_sub(b, f));               // X3 = a*(b - f)
-  Fp2 g = fp2_halve(fp2_add(b, f));              // g = (b+f) * TWO_INV
-  Fp2 esq = fp2_sqr(e);
-  r.y = fp2_sub(fp2_sqr(g), fp2_add(fp2_dbl(esq), esq));        // Y3 = g^2 - 3e^2
-}
-// pairing.rs:756-772: mixed addition step R += (bx, by), same values, short live ranges
-BN_NOINLINE void g2_addition_step(G2P& r, const Fp2& bx, const Fp2& by, Fp2& l0, Fp2& l1, Fp2& l2) {
-  Fp2 d = fp2_sub(r.x, fp2_mul(r.z, bx));
-  Fp2 e = fp2_sub(r.y, fp2_mul(r.z, by));
-  l0 = fp2_mul_xi(fp2_sub(fp2_mul(e, bx), fp2_mul(d, by)));
-  l1 = d;
-  l2 = fp2_neg(e);
-  Fp2 h, i;
-  {
-    Fp2 f = fp2_sqr(d);
-    h = fp2_mul(d, f);
-    i = fp2_mul(r.x, f);
-  }
-  Fp2 j = fp2_sub(fp2_add(fp2_mul(r.z, fp2_sqr(e)), h), fp2_dbl(i));
-  r.z = fp2_mul(r.z, h);
-  r.x = fp2_mul(d, j);
-  r.y = fp2_sub(fp2_mul(e, fp2_sub(i, j)), fp2_mul(h, r.y));
-}
-// Two Fp12 accumulators used alternately: squaring and the sparse line product are both out-of-place,
-// so every step reads one buffer and writes the other (no copies, operands re-loadable).
-struct Acc12 {
-  Fp12 buf[2];
-  int cur;
-  BN_DEV Fp12& get() { return buf[cur]; }
-  BN_DEV void set_one() { cur = 0; fp12_set_one(buf[0]); }
-  BN_DEV void square() { fp12_sqr(buf[cur ^ 1], buf[cur]); cur ^= 1; }
-  // f <- f * (l0 + l_vw w^3... ) (fp12.rs:426-503)
-  BN_DEV void sparse(const Fp2& l0, const Fp2& lvw, const Fp2& lvv) { fp12_sparse_mul(buf[cur ^ 1], buf[cur], l0, lvw, lvv); cur ^= 1; }
-  // f <- f * line(P): sparse_mul(c0, c1 * P.y, c2 * P.x)  (pairing.rs:598)
-  BN_DEV void line(const Fp2& l0, const Fp2& l1, const Fp2& l2, const Fp& px, const Fp& py) { sparse(l0, fp2_scale(l1, py), fp2_scale(l2, px)); }
-};
-// pairing.rs:590-619 fused with :676-708 (coefficients produced and consumed on the fly).
-// P = (px, py), Q = (qx, qy) affine, neither at infinity (callers substitute, pairing.rs:876-878).
-BN_NOINLINE void miller_loop(Fp12& fout, const Fp& px, const Fp& py, const Fp2& qx, const Fp2& qy) {
-  Acc12 f;
-  f.set_one();
-  G2P r{qx, qy, fp2_one()};
-  const Fp2 nqy = fp2_neg(qy);
-  Fp2 l0, l1, l2;
-  const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
-#pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    g2_doubling_step(r, l0, l1, l2);
-    f.square();
-    f.line(l0, l1, l2, px, py);
-    if ((nz >> (63 - i)) & 1) {
-      bool neg = (ng >> (63 - i)) & 1;
-      g2_addition_step(r, qx, neg ? nqy : qy, l0, l1, l2);
-      f.line(l0, l1, l2, px, py);
-    }
-  }
-  // Q1 = psi(Q), Q2 = -psi(psi(Q))  (pairing.rs:701-706)
-  Fp2 q1x, q1y, q2x, q2y;
-  g2_psi_affine(q1x, q1y, qx, qy);
-  g2_psi_affine(q2x, q2y, q1x, q1y);
-  q2y = fp2_neg(q2y);
-  g2_addition_step(r, q1x, q1y, l0, l1, l2);
-  f.line(l0, l1, l2, px, py);
-  g2_addition_step(r, q2x, q2y, l0, l1, l2);
-  f.line(l0, l1, l2, px, py);
-  fout = f.get();
-}
-
-// ---------------------------------------------------------------- final exponentiation --------
+// ---------------------------------------------------------------- final exponentiation pieces (the Fp12 selector of tower.hip) --------
 // pairing.rs:274-284
 BN_DEV void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {
   Fp2 t0 = fp2_sqr(a);
@@ -659,38 +557,4 @@ BN_NOINLINE void exp_by_neg_z(Fp12& r, const Fp12& f) {
   u12_conj(t, res);
   u12_to_fp12(r, t);
 }
-// pairing.rs:245-492: easy part (:410), hard part (:437, Fuentes-Castaneda chain)
-BN_NOINLINE void final_exponentiation(Fp12& out, const Fp12& fin) {
-  Fp12 in, t, a, b, d, e, g;
-  // easy part: f^(p^6-1) then ^(p^2+1)
-  fp12_conj(a, fin);
-  fp12_inv(b, fin);
-  fp12_mul(t, a, b);
-  fp12_frobenius<2>(a, t);
-  fp12_mul(in, a, t);
-  // hard part
-  exp_by_neg_z(a, in);           // a
-  cyclotomic_sqr(b, a);          // b
-  cyclotomic_sqr(t, b);          // c
-  fp12_mul(d, t, b);             // d = c*b
-  exp_by_neg_z(e, d);            // e
-  cyclotomic_sqr(t, e);          // f
-  exp_by_neg_z(g, t);            // g
-  fp12_conj(d, d);               // h = conj(d)
-  fp12_conj(g, g);               // i = conj(g)
-  fp12_mul(t, g, e);             // j = i*e
-  fp12_mul(a, t, d);             // k = j*h
-  fp12_mul(d, a, b);             // l = k*b
-  fp12_mul(t, a, e);             // m = k*e
-  fp12_mul(e, in, t);            // n = in*m
-  fp12_frobenius<1>(t, d);       // o = frob(l)
-  fp12_mul(b, t, e);             // p = o*n
-  fp12_frobenius<2>(t, a);       // q = frob2(k)
-  fp12_mul(e, t, b);             // r = q*p
-  fp12_conj(t, in);              // s
-  fp12_mul(a, t, d);             // t = s*l
-  fp12_frobenius<3>(t, a);       // u
-  fp12_mul(out, t, e);           // u*r
-}
-
 }  // namespace bn254

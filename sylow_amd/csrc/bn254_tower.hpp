@@ -32,7 +32,6 @@ BN_DEV Fp2 fp2_neg(const Fp2& a) { return Fp2{fp_neg(a.c0), fp_neg(a.c1)}; }
 BN_DEV Fp2 fp2_dbl(const Fp2& a) { return Fp2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
 BN_DEV Fp2 fp2_conj(const Fp2& a) { return Fp2{a.c0, fp_neg(a.c1)}; }  // frobenius(odd), fp2.rs:119-133
 BN_DEV bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
-BN_DEV bool fp2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BN_DEV Fp2 fp2_select(const Fp2& a, const Fp2& b, bool c) { return Fp2{fp_select(a.c0, b.c0, c), fp_select(a.c1, b.c1, c)}; }
 
 // fp2.rs:285-306 (value): (a0 b0 - a1 b1, a0 b1 + a1 b0) with lazy reduction -- each coordinate is one fused
@@ -51,9 +50,7 @@ BN_DEV Fp2 fp2_sqr(const Fp2& a) {
   Fp t = fp_mul(a.c0, a.c1);
   return Fp2{fp_mul(s, d), fp_dbl(t)};
 }
-// extensions.rs:86-94 with F = Fp
-BN_DEV Fp2 fp2_scale(const Fp2& a, const Fp& k) { return Fp2{fp_mul(a.c0, k), fp_mul(a.c1, k)}; }
-BN_DEV Fp2 fp2_halve(const Fp2& a) { return Fp2{fp_halve(a.c0), fp_halve(a.c1)}; }   // == scale(TWO_INV)
+   // == scale(TWO_INV)
 // x (9+u): (9a - b, a + 9b)  (fp2.rs:99-107), one multiply-by-9 pass per coordinate
 BN_DEV Fp2 fp2_mul_xi(const Fp2& a) {
   return Fp2{fp_mul9_addsub<false>(a.c0, a.c1), fp_mul9_addsub<true>(a.c1, a.c0)};
@@ -64,9 +61,6 @@ BN_DEV Fp2 fp2_inv(const Fp2& a) {
   return Fp2{fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
 }
 
-// ------------------------------------------------------------------ Fp6 (fp6.rs) -------------
-BN_DEV Fp6 fp6_zero() { return Fp6{fp2_zero(), fp2_zero(), fp2_zero()}; }
-BN_DEV Fp6 fp6_one() { return Fp6{fp2_one(), fp2_zero(), fp2_zero()}; }
 BN_DEV Fp6 fp6_add(const Fp6& a, const Fp6& b) { return Fp6{fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)}; }
 BN_DEV Fp6 fp6_sub(const Fp6& a, const Fp6& b) { return Fp6{fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)}; }
 BN_DEV Fp6 fp6_neg(const Fp6& a) { return Fp6{fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)}; }
@@ -128,8 +122,6 @@ BN_DEV void fp6_frobenius(Fp6& r, const Fp6& a) {
   r.c2 = fp2_mul(x2, fp2_const(k2));
 }
 
-// ------------------------------------------------------------------ Fp12 (fp12.rs) -----------
-BN_DEV void fp12_set_one(Fp12& r) { r.c0 = fp6_one(); r.c1 = fp6_zero(); }
 // fp12.rs:229-238
 BN_NOINLINE void fp12_mul(Fp12& r, const Fp12& a, const Fp12& b) {
   Fp6 t0, t1, t2;
@@ -235,7 +227,5 @@ BN_NOINLINE void fp12_sparse_mul(Fp12& __restrict__ o, const Fp12& __restrict__ 
     o.c1.c2 = fp2_sub(fp2_mul(s0, t0), s1);
   }
 }
-BN_DEV bool fp6_eq(const Fp6& a, const Fp6& b) { return fp2_eq(a.c0, b.c0) && fp2_eq(a.c1, b.c1) && fp2_eq(a.c2, b.c2); }
-BN_DEV bool fp12_eq(const Fp12& a, const Fp12& b) { return fp6_eq(a.c0, b.c0) && fp6_eq(a.c1, b.c1); }
 
 }  // namespace bn254

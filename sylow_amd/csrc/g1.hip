@@ -154,25 +154,45 @@ __global__ void HEAVY_BOUNDS k_g1_generator_mul(const u64* ks, const i32* __rest
 }
 
 // ------------------------------------------------------------------ sum of a batch of G1 points ----------
-// sum_i P_i as a log-depth tree of complete additions on a projective scratch array acc [12][n] (canonical words): the G1 side of
-// aggregate verification (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen)).  init: affine + flags -> projective; level: element t
-// absorbs element t + h, in place (nobody else touches either); tail: the last levels in one block, then element 0 -> affine, written to
-// column `col` of an SoA array of stride `stride`, optionally negated.
-__global__ void __launch_bounds__(BLOCK) k_g1_sum_init(const u64* pxy, const uint8_t* pinf, u64* acc, size_t n) {
-  size_t i = TID;
-  if (i >= n) return;
-  const bool inf = pinf && pinf[i];
-  store_fp(acc, n, i, 0, inf ? fp_zero() : load_fp(pxy, n, i, 0));
-  store_fp(acc, n, i, 4, inf ? fp_one() : load_fp(pxy, n, i, 4));
-  store_fp(acc, n, i, 8, inf ? fp_zero() : fp_one());
+// sum_i P_i: the G1 side of aggregate verification (prod_i e(sig_i, G2gen) = e(sum_i sig_i, G2gen); the fold of
+// examples/verify_multiple_messages_same_signer.rs:41-60).  Stages of SERIAL accumulation: with L lanes, lane t adds up elements
+// t, t + L, t + 2 L, ... (a wavefront reads consecutive elements at every step) with the complete addition on the carry-free core,
+// accumulator in registers -- no intermediate leaves the lane -- and writes ONE projective partial to element t of acc [12][stride]
+// (in place when the input is acc itself: lane t is the only reader of element t and has read it before it writes).  Every stage
+// divides the count by SUM_FOLD; the last <= 2 * BLOCK partials go through the one-block tail (a level per barrier), which also
+// converts to affine.  (The round-3 form -- a binary tree with one launch per level and every intermediate through HBM on the
+// saturated core -- took 4-6 ms per 2^20 points, neither issue- nor bandwidth-bound; this one is a few hundred microseconds.)
+constexpr size_t SUM_FOLD = 16;
+BN_DEV G1W g1w_load_proj(const u64* a, size_t stride, size_t i) {
+  return G1W{f29_from_fp_reduced(load_fp(a, stride, i, 0)), f29_from_fp_reduced(load_fp(a, stride, i, 4)), f29_from_fp_reduced(load_fp(a, stride, i, 8))};
 }
-__global__ void __launch_bounds__(BLOCK) k_g1_sum_level(u64* acc, size_t n, size_t m, size_t h) {
-  size_t t = TID;
-  if (t + h >= m) return;
-  const G1P a{load_fp(acc, n, t, 0), load_fp(acc, n, t, 4), load_fp(acc, n, t, 8)};
-  const G1P b{load_fp(acc, n, t + h, 0), load_fp(acc, n, t + h, 4), load_fp(acc, n, t + h, 8)};
-  const G1P r = g1_add(a, b);
-  store_fp(acc, n, t, 0, r.x); store_fp(acc, n, t, 4, r.y); store_fp(acc, n, t, 8, r.z);
+BN_DEV void g1w_store_proj(u64* a, size_t stride, size_t i, const G1W& r) {
+  store_fp(a, stride, i, 0, f29_to_fp(r.x)); store_fp(a, stride, i, 4, f29_to_fp(r.y)); store_fp(a, stride, i, 8, f29_to_fp(r.z));
+}
+// affine points + identity flags (stride n) -> L partial sums in acc (stride acc_stride)
+__global__ void HEAVY_BOUNDS k_g1_sum_fold_affine(const u64* pxy, const uint8_t* pinf, size_t n, size_t L, u64* acc, size_t acc_stride) {
+  const size_t t = TID;
+  if (t >= L) return;
+  G1W res = proj_zero<OpsF29>();
+#pragma unroll 1
+  for (size_t i = t; i < n; i += L) {
+    const bool inf = pinf && pinf[i];
+    G1W q;                                              // the identity joins as (0 : 1 : 0): the formulas are complete
+    q.x = OpsF29::select(f29_from_fp_reduced(load_fp(pxy, n, i, 0)), OpsF29::zero(), inf);
+    q.y = OpsF29::select(f29_from_fp_reduced(load_fp(pxy, n, i, 4)), OpsF29::one(), inf);
+    q.z = OpsF29::select(OpsF29::one(), OpsF29::zero(), inf);
+    res = proj_add<OpsF29>(res, q);
+  }
+  g1w_store_proj(acc, acc_stride, t, res);
+}
+// m projective points of acc (stride `stride`) -> L partial sums, in place
+__global__ void HEAVY_BOUNDS k_g1_sum_fold_proj(u64* acc, size_t stride, size_t m, size_t L) {
+  const size_t t = TID;
+  if (t >= L) return;
+  G1W res = g1w_load_proj(acc, stride, t);
+#pragma unroll 1
+  for (size_t i = t + L; i < m; i += L) res = proj_add<OpsF29>(res, g1w_load_proj(acc, stride, i));
+  g1w_store_proj(acc, stride, t, res);
 }
 // the last levels (m <= 2 * BLOCK live elements) and the finish in ONE block: a level per barrier instead of a launch per level
 __global__ void __launch_bounds__(BLOCK) k_g1_sum_tail(u64* acc, size_t n, size_t m, u64* oxy, uint8_t* oinf, size_t stride, size_t col, int negate) {
@@ -369,35 +389,49 @@ size_t g1_comb_bytes() { return COMB1_WORDS * sizeof(bn254::i32); }
 int32_t build_g1_comb(bn254::i32* table, void* stream) {
   k_g1_comb_table<<<GRID((size_t)COMB_WIN * COMB_ENT)>>>(table); LAUNCHED();
 }
+static size_t fold_lanes(size_t m) { return (m + SUM_FOLD - 1) / SUM_FOLD; }
 int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
-  if (n) k_g1_sum_init<<<GRID(n)>>>(p_xy, p_inf, acc, n);
-  return sum_tree(acc, n, out_xy, out_inf, stride, col, negate, stream);
+  if (!n) return sum_tree(acc, 0, out_xy, out_inf, stride, col, negate, stream);
+  const size_t L = fold_lanes(n);
+  k_g1_sum_fold_affine<<<GRID(L)>>>(p_xy, p_inf, n, L, acc, n);
+  return sum_tree_strided(acc, n, L, out_xy, out_inf, stride, col, negate, stream);
 }
 int32_t sum_tree(uint64_t* acc, size_t n, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
-  size_t m = n;
+  return sum_tree_strided(acc, n, n, out_xy, out_inf, stride, col, negate, stream);
+}
+// the first m of the projective points in acc [12][acc_stride] -> their sum (affine, column `col` of an SoA array of stride `stride`)
+int32_t sum_tree_strided(uint64_t* acc, size_t acc_stride, size_t m, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream) {
   while (m > 2 * BLOCK) {
-    const size_t h = (m + 1) / 2;
-    k_g1_sum_level<<<GRID(m - h)>>>(acc, n, m, h);
-    m = h;
+    const size_t L = fold_lanes(m);
+    k_g1_sum_fold_proj<<<GRID(L)>>>(acc, acc_stride, m, L);
+    m = L;
   }
-  k_g1_sum_tail<<<1, BLOCK, 0, (hipStream_t)stream>>>(acc, n, m, out_xy, out_inf, stride, col, negate); LAUNCHED();
+  k_g1_sum_tail<<<1, BLOCK, 0, (hipStream_t)stream>>>(acc, acc_stride, m, out_xy, out_inf, stride, col, negate); LAUNCHED();
 }
 }  // namespace g1h
 
 // window tables of n lanes in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: ProjTableGlobal);
-// SYLOW_HIP_G1_TABLES=0 or a failed lease keeps them in the stack frame (NULL)
+// a failed lease keeps them in the stack frame (NULL)
 static uint8_t* g1_window_tables(host::Lease& ws, size_t n, void* stream) {
-  static const bool global_tables = [] { const char* e = getenv("SYLOW_HIP_G1_TABLES"); return !(e && e[0] == '0'); }();
-  if (global_tables && ws.acquire(n * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
+  if (ws.acquire(n * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
   (void)hipGetLastError();
   return nullptr;
 }
 
 extern "C" {
+int32_t sylow_hip_g1_sum_batch(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* out_xy, uint8_t* out_inf, void* stream) {
+  ARGCHK(out_xy && out_inf && (p_xy || !n));
+  host::Lease ws;
+  int32_t rc = ws.acquire(12 * (n ? n : 1) * sizeof(u64), (hipStream_t)stream);
+  if (rc != SYLOW_HIP_OK) return rc;
+  rc = g1h::sum(p_xy, p_inf, n, (uint64_t*)ws.p, out_xy, out_inf, 1, 0, 0, stream);
+  const int32_t r2 = ws.release();
+  return rc != SYLOW_HIP_OK ? rc : r2;
+}
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  // window tables in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: G1TableGlobal); SYLOW_HIP_G1_TABLES=0 or a
-  // failed lease keeps them in the stack frame
+  // window tables in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: G1TableGlobal); a failed
+  // lease keeps them in the stack frame
   host::Lease ws;
   uint8_t* tables = g1_window_tables(ws, n, stream);
   k_g1_scalar_mul<<<GRID(n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);

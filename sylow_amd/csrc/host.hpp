@@ -12,9 +12,6 @@
 extern thread_local char sylow_g_err[256];
 namespace host {
 int32_t fail(hipError_t e, const char* what);
-// SYLOW_HIP_SINGLE_LANE=1 selects the one-element-per-lane kernels (single.hip): the slower twin kept for A/B measurements and
-// as a second implementation for the parity tests.
-bool single_lane();
 
 // Scratch workspace (runtime.hip).  A Lease hands out one device block for the duration of ONE entry-point call: blocks are
 // keyed per device, a block whose previous user ran on the same stream is reused in stream order, a block last used on another
@@ -30,7 +27,6 @@ struct Lease {
 };
 // per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
 int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair line table (plk_common.hpp: LINE_TABLE_WORDS)
-int32_t gen_lines_sat(const u32** out, hipStream_t st);
 int32_t g1_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G1 generator (g1.hip), built on first use
 int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use         // single-lane Montgomery layout [87][48] uint32
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
@@ -43,28 +39,9 @@ void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow
 #define LAUNCHED() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return host::fail(e_, "kernel launch"); return SYLOW_HIP_OK; } while (0)
 
 // ---- launchers exported between units (argument lists as the C entry points of include/sylow_hip.h) ----------------------
-namespace single {      // single.hip: one element per lane
-int32_t g2_scalar_mul(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
-int32_t g2_normalize(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
-int32_t g2_precompute(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream);
-int32_t g2_subgroup_check(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream);
-int32_t g2_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
-int32_t g2_double(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
-int32_t miller_loop(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
-int32_t final_exp(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
-int32_t pairing(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream);
-int32_t multi_pairing(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
-                      size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, void* stream);
-int32_t gt_pow(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream);
-int32_t bls_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                   const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
-int32_t bls_verify_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                         const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
-int32_t bls_verify_same_signer(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
-                               const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream);
-int32_t build_gen_lines(u32* table, void* stream);              // k_g2_lines on the generator
-int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);   // k_fp12_op selectors 0..11
-}  // namespace single
+namespace towerh {      // tower.hip: the one-element-per-lane Fp12 selector behind sylow_hip_fp12_hook_batch (ops 0..11)
+int32_t fp12_hook(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
+}  // namespace towerh
 namespace g1h {         // g1.hip
 size_t g1_comb_bytes();
 int32_t build_g1_comb(bn254::i32* table, void* stream);
@@ -76,9 +53,15 @@ int32_t hash_to_g1_dst(const uint8_t* msgs, const uint64_t* msg_offsets, const D
 int32_t sum(const uint64_t* p_xy, const uint8_t* p_inf, size_t n, uint64_t* acc, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream);
 // the same from an acc [12][n] that already holds the n projective points
 int32_t sum_tree(uint64_t* acc, size_t n, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream);
+// the same for the first m elements of an acc whose SoA stride is acc_stride
+int32_t sum_tree_strided(uint64_t* acc, size_t acc_stride, size_t m, uint64_t* out_xy, uint8_t* out_inf, size_t stride, size_t col, int negate, void* stream);
 }  // namespace g1h
 namespace plkh {        // lane-pair units
-// plk_pairing.hip: one Fp12 operation on the lane-pair layer; op = 16 mul, 17 sqr, 18 sparse (b = 24 words), 19 cyclotomic sqr, 20..22 frobenius 1..3, 26 inv
+// selectors of plk_pairing.hip's Fp12 kernel (sylow_hip_fp12_hook_batch, and the Fp12 entry points of tower.hip)
+enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 = 20, OPW_FROB2 = 21, OPW_FROB3 = 22, OPW_EXPZ = 23,
+       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28,
+       OPW_SPARSE_UNIT = 29, OPW_LAST = 29 };   // 29: first line coefficient = (element index & 1), the other two from `b` as for 18
+// plk_pairing.hip: one Fp12 operation on the lane-pair layer (op = an OPW_* selector; OPW_SPARSE: b = 24 words)
 int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* table, void* stream);   // plk_verify.hip; q_xy NULL = generator
 size_t line_table_bytes();                                                                             // plk_verify.hip

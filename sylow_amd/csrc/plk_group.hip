@@ -540,10 +540,9 @@ int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8
 }  // namespace plkh
 
 // window tables of `threads` lanes in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: ProjTableGlobal);
-// SYLOW_HIP_G1_TABLES=0 or a failed lease keeps them in the stack frame (NULL)
+// a failed lease keeps them in the stack frame (NULL)
 static uint8_t* plkh_window_tables(host::Lease& ws, size_t threads, void* stream) {
-  static const bool global_tables = [] { const char* e = getenv("SYLOW_HIP_G1_TABLES"); return !(e && e[0] == '0'); }();
-  if (global_tables && ws.acquire(threads * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
+  if (ws.acquire(threads * G1_TABLE_BYTES_PER_LANE, (hipStream_t)stream) == SYLOW_HIP_OK) return (uint8_t*)ws.p;
   (void)hipGetLastError();
   return nullptr;
 }
@@ -551,7 +550,6 @@ static uint8_t* plkh_window_tables(host::Lease& ws, size_t threads, void* stream
 extern "C" {
 int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
   host::Lease ws;
   uint8_t* tables = plkh_window_tables(ws, 2 * n, stream);
   plk::k_g2_scalar_mul<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);
@@ -561,7 +559,6 @@ int32_t sylow_hip_g2_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf
 }
 int32_t sylow_hip_g2_scalar_mul_subgroup_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_scalar_mul(p_xy, p_inf, k, out_xy, out_inf, n, stream);
   host::Lease ws;
   uint8_t* tables = plkh_window_tables(ws, 2 * n, stream);
   plk::k_g2_scalar_mul_gls<<<GRID(2 * n)>>>(p_xy, p_inf, k, out_xy, out_inf, n, tables);
@@ -578,7 +575,6 @@ int32_t sylow_hip_g2_generator_mul_batch(const uint64_t* k, uint64_t* out_xy, ui
 }
 int32_t sylow_hip_g2_normalize_batch(const uint64_t* p_xyz, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xyz && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_normalize(p_xyz, out_xy, out_inf, n, stream);
   plk::k_g2_normalize<<<GRID(2 * n)>>>(p_xyz, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* out_xy, uint8_t* out_inf, uint8_t* status, size_t n, void* stream) {
@@ -587,7 +583,6 @@ int32_t sylow_hip_g2_psi_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint6
 }
 int32_t sylow_hip_g2_subgroup_check_batch(const uint64_t* q_xy, const uint8_t* q_inf, uint8_t* status, size_t n, void* stream) {
   ARGCHK(q_xy && status); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_subgroup_check(q_xy, q_inf, status, n, stream);
   plk::k_g2_subgroup_check<<<GRID(2 * n)>>>(q_xy, q_inf, status, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {
@@ -598,12 +593,10 @@ int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, ui
 }
 int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream) {
   ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::gt_pow(gt, k, out, n, stream);
   plk::k_gt_pow<<<GRID(2 * n)>>>(gt, k, out, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && b_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_add(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n, stream);
   plk::k_g2_add<<<GRID(2 * n)>>>(a_xy, a_inf, b_xy, b_inf, out_xy, out_inf, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_sub_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
@@ -618,7 +611,6 @@ int32_t sylow_hip_g2_ct_eq_batch(const uint64_t* a_xyz, const uint64_t* b_xyz, u
 }
 int32_t sylow_hip_g2_double_batch(const uint64_t* a_xy, const uint8_t* a_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(a_xy && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_double(a_xy, a_inf, out_xy, out_inf, n, stream);
   plk::k_g2_double<<<GRID(2 * n)>>>(a_xy, a_inf, out_xy, out_inf, n); LAUNCHED();
 }
 }  // extern "C"

@@ -755,7 +755,7 @@ static int wide_tail() {
 namespace plkh {
 // Small batches on one wavefront per element (k_miller_wide_batch / k_final_exp_wide_batch): up to this many elements the latency route
 // beats the one-lane-pair kernels (2 n + n blocks against 2048 resident wavefronts; measured crossover ~ 3 k verifications)
-size_t wide_batch_max() { return wide_tail() && !host::single_lane() ? 2048 : 0; }
+size_t wide_batch_max() { return wide_tail() ? 2048 : 0; }
 // pairing(P_i, Q_i), i < n: raw values through `scratch` (48 n words), Gt values to gt_out (SoA stride n)
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -822,7 +822,6 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, int32_t skip_infinity,
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::multi_pairing(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, stream);
   if (single_job_route(n_jobs, n_pairs, skip_infinity)) return single_job_product(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, gt_out, is_one, stream);
   if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, stream);
   // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
@@ -832,7 +831,6 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
 }
 int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, size_t n, void* stream) {
   ARGCHK(q_xy && coeffs); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::g2_precompute(q_xy, coeffs, n, stream);
   plk::k_g2_precompute_pairs<<<GRID(2 * n)>>>(q_xy, coeffs, n); LAUNCHED();
 }
 int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
@@ -870,7 +868,7 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   if (rc != SYLOW_HIP_OK) return rc;
   u64 *off = (u64*)ws.p, *bufa = off + n_off, *bufb = bufa + n_a;
   // ONE pair (the collapsed halves of the aggregate verifiers): pure latency on one lane pair -- the whole wavefront takes it
-  if (n_pairs == 1 && skip_infinity && wide_tail() && !host::single_lane()) {
+  if (n_pairs == 1 && skip_infinity && wide_tail()) {
     plk::k_miller_single_wide<<<1, 64, 0, st>>>(p_xy, p_inf, q_xy, q_inf, 1, range, bufa);
     *result = bufa;
     return SYLOW_HIP_OK;
@@ -1124,8 +1122,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   uint8_t* isone = pst + np;
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
-    if (host::single_lane()) rc = single::multi_pairing(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, stream);
-    else if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, nullptr, isone, stream);
+    if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, nullptr, isone, stream);
     else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, stream);
     else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);

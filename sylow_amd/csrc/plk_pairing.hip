@@ -44,9 +44,7 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
 
 // test hook: the lane-pair Fp12 layer one operation at a time (ops 16.. of sylow_hip_fp12_hook_batch); `b` carries the second
 // operand, or the three line coefficients (ell_0, ell_vw, ell_vv) in its first 24 words for the sparse product
-enum { OPW_MUL = 16, OPW_SQR = 17, OPW_SPARSE = 18, OPW_CYCSQR = 19, OPW_FROB1 = 20, OPW_FROB2 = 21, OPW_FROB3 = 22, OPW_EXPZ = 23,
-       OPW_S_MUL = 24, OPW_S_SQR = 25, OPW_S_INV = 26, OPW_S_CYCSQR = 27, OPW_CONJ = 28,
-       OPW_SPARSE_UNIT = 29, OPW_LAST = 29 };   // 29: first line coefficient = (element index & 1), the other two from `b` as for 18
+using namespace plkh;      // the OPW_* selectors (host.hpp)
 __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* out, size_t n) {
   const size_t t = TID, i = pair_index(t);
   const int odd = pair_role(t);
@@ -98,17 +96,14 @@ int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out,
 extern "C" {
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::miller_loop(p_xy, q_xy, f_out, n, stream);
   plk::k_miller_loop<<<GRID(2 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
 }
 int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::final_exp(f, gt_out, n, stream);
   plk::k_final_exp<<<GRID(2 * n)>>>(f, gt_out, n); LAUNCHED();
 }
 int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && gt_out); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::pairing(p_xy, p_inf, q_xy, q_inf, gt_out, n, stream);
   // a few pairings are pure latency on one lane pair each: a wavefront per pairing instead; same Gt, an identity on either side gives the
   // identity of Gt either way (pairing.rs:876-886)
   if (n <= plkh::wide_batch_max()) {      // small batches: one wavefront per pairing (2.3 ms against 5.4 ms on one lane pair each)
@@ -121,11 +116,11 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
   }
   plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
 }
-// test hook: raw Fp12 selector.  0..11: the single-lane layer (single.hip: 8 product on the carry-free core, 9 cyclotomic square on
+// test hook: raw Fp12 selector.  0..11: the one-element-per-lane layer (tower.hip: 8 product on the carry-free core, 9 cyclotomic square on
 // it, 10 / 11 exp_by_neg_z on the carry-free / saturated core); 16..29: the lane-pair Fp12 layer (plk::k_w12_op)
 int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   ARGCHK(a && out && op >= 0 && (op <= 11 || (op >= 16 && op <= plk::OPW_LAST))); if (!n) return SYLOW_HIP_OK;
-  if (op < 16) return single::fp12_hook(op, a, b, out, n, stream);
+  if (op < 16) return towerh::fp12_hook(op, a, b, out, n, stream);
   plk::k_w12_op<<<GRID(2 * n)>>>(op, a, b, out, n); LAUNCHED();
 }
 }  // extern "C"

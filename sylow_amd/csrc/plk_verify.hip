@@ -138,12 +138,12 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
   if (!odd) okout[i] = eq ? 1 : 0;
 }
 
-// e(sig, G2gen) * e(-H(msg), pk) == 1 with one shared-squaring Miller loop and one final exponentiation (see the single-lane
-// k_bls_verify_fused in single.hip for the contract).  PK_TABLE: one public key for the whole batch, its lines precomputed.
-// HASHED: -H(m_i) was computed by k_hash_to_g1 beforehand (affine SoA hneg / hneg_inf; msgs / off / dp unused): one Keccak expansion per
-// element instead of one per lane of the pair, and the hashing code's registers and stack frame stay out of this kernel.
-template <bool PK_TABLE, bool HASHED>
-__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table, const uint8_t* msgs, const u64* off, DstPrime dp,
+// e(sig, G2gen) * e(-H(msg), pk) == 1 with one shared-squaring Miller loop and one final exponentiation: the boolean of lib.rs:223-236
+// (FE(a) == FE(b) <=> FE(a conj(b)) == 1, conj(miller(H, pk)) = miller(-H, pk)).  PK_TABLE: one public key for the whole batch, its lines
+// precomputed.  -H(m_i) comes from k_hash_to_g1 (affine SoA hneg / hneg_inf): one Keccak expansion per element, and the hashing code's
+// registers and stack frame stay out of this kernel (hashing inside it -- each lane of a pair mapping one field element -- measured 1 % slower).
+template <bool PK_TABLE>
+__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
                                                 const u64* hneg, const uint8_t* hneg_inf,
                                                 const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
   __shared__ i32 tabA[LINE_TABLE_WORDS];
@@ -155,13 +155,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const int odd = pair_role(t);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
-  Fp hxs, hys; bool hinf;                                                    // pair B is (-H, pk)
-  if (HASHED) {
-    hxs = load_fp(hneg, n, ii, 0); hys = load_fp(hneg, n, ii, 4); hinf = hneg_inf[ii] != 0;
-  } else {
-    hash_to_g1_pair(hxs, hys, hinf, msgs + off[ii], (size_t)(off[ii + 1] - off[ii]), dp);
-    hys = fp_neg(hys);
-  }
+  const Fp hxs = load_fp(hneg, n, ii, 0), hys = load_fp(hneg, n, ii, 4);     // pair B is (-H, pk)
+  const bool hinf = hneg_inf[ii] != 0;
   // Loop invariants that are read once or twice per step live in LDS, [limb][thread] (see miller_loop29g): the signature's and
   // -H(m)'s coordinates for the line scalings and, without a key table, the key's for the addition steps.
   __shared__ i32 lds[PK_TABLE ? 36 : 54][256];
@@ -254,20 +249,11 @@ int32_t build_lines29(const uint64_t* q_xy, size_t n, size_t idx, bn254::i32* ta
 }
 }  // namespace plkh
 
-// The fused check as two launches: -H(m_i) for the batch (hash.hip: k_hash_to_g1, one element per lane, four wavefronts per SIMD, 64 bytes per element through a leased
-// block), then the pairing kernel reading it.  SYLOW_HIP_VERIFY_HASH_INSIDE=1 keeps the hashing inside the pairing kernel (each lane of a
-// pair maps one of the two field elements, both expand the message): 1 % slower at 2^20, one launch.
-static bool verify_hash_inside() {
-  static const bool v = [] { const char* e = getenv("SYLOW_HIP_VERIFY_HASH_INSIDE"); return e && e[0] == '1'; }();
-  return v;
-}
+// The fused check as two launches: -H(m_i) for the batch (hash.hip: k_hash_to_g1, one element per lane, four wavefronts per SIMD, 64 bytes
+// per element through a leased block), then the pairing kernel reading it.
 template <bool PK_TABLE>
 static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint8_t* msgs, const uint64_t* msg_offsets,
                             const DstPrime& dp, const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, void* stream) {
-  if (verify_hash_inside()) {
-    plk::k_bls_verify_fused<PK_TABLE, false><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, msgs, msg_offsets, dp, nullptr, nullptr, sig_xy, sig_inf, gen, ok, n);
-    LAUNCHED();
-  }
   host::Lease ws;
   int32_t rc = ws.acquire(8 * n * sizeof(u64) + n, (hipStream_t)stream);
   if (rc != SYLOW_HIP_OK) return rc;
@@ -275,7 +261,7 @@ static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const 
   uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
   rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
   if (rc == SYLOW_HIP_OK)
-    plk::k_bls_verify_fused<PK_TABLE, true><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, nullptr, nullptr, dp, hneg, hinf, sig_xy, sig_inf, gen, ok, n);
+    plk::k_bls_verify_fused<PK_TABLE><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n);
   const hipError_t e = hipGetLastError();
   const int32_t r2 = ws.release();
   if (rc != SYLOW_HIP_OK) return rc;
@@ -290,7 +276,6 @@ extern "C" {
 static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                     const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::bls_verify_fused(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
   // a few verifications are pure latency on one lane pair each (6.8 ms): the same product e(sig, G2gen) e(-H, pk) with the same reading of
   // identities on one wavefront per Miller loop and per final exponentiation (3 ms)
   if (n <= plkh::wide_batch_max() / 2) {  // small batches: -H(m_i), then a wavefront per Miller loop and per final exponentiation
@@ -322,7 +307,6 @@ int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* p
 int32_t sylow_hip_bls_verify_two_pairings_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                 const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::bls_verify(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
@@ -332,7 +316,6 @@ int32_t sylow_hip_bls_verify_two_pairings_batch(const uint64_t* pk_xy, const uin
 int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
-  if (host::single_lane()) return single::bls_verify_same_signer(pk_xy, pk_inf, msgs, msg_offsets, sig_xy, sig_inf, ok, n, stream);
   hipStream_t st = (hipStream_t)stream;
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;

@@ -186,10 +186,6 @@ int32_t fail(hipError_t e, const char* what) {
   (void)hipGetLastError();          // the failure is reported through the return code: do not leave it sticky for the next launch check
   return SYLOW_HIP_E_HIP;
 }
-bool single_lane() {
-  static const bool v = [] { const char* e = getenv("SYLOW_HIP_SINGLE_LANE"); return e && e[0] == '1'; }();
-  return v;
-}
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
   if (!dst) { dst = SYLOW_DST; len = 30; }
@@ -199,7 +195,7 @@ void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
 namespace {
 constexpr int MAX_DEV = 64;
 struct Block { void* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool recorded = false, leased = false; };
-struct DevState { std::vector<Block> blocks; bn254::i32* gen29 = nullptr; u32* gensat = nullptr; bn254::i32* g2comb = nullptr; bn254::i32* g1comb = nullptr; };
+struct DevState { std::vector<Block> blocks; bn254::i32* gen29 = nullptr; bn254::i32* g2comb = nullptr; bn254::i32* g1comb = nullptr; };
 std::mutex g_mu;               // guards g_dev (bookkeeping + one-time table construction); never held across a user kernel
 DevState g_dev[MAX_DEV];
 int32_t current_device(int& d) {
@@ -213,25 +209,7 @@ int32_t current_device(int& d) {
 // block (the new stream then waits for its event on the device, the host does not block), (4) a new block.  Reuse is always
 // ordered with hipStreamWaitEvent on the block's own event -- also on the "same" stream, since a destroyed stream's handle
 // value can come back for a different stream -- so no stale stream handle is ever passed to HIP.
-// SYLOW_HIP_WS_ASYNC=1 (debugging only, tools/dbg_prod.py): take the block from HIP's stream-ordered allocator instead, the design
-// round 1 abandoned after intermittent wrong products -- kept switchable so that the incident stays reproducible / re-testable.
-static bool ws_async() {
-  static const bool v = [] { const char* e = getenv("SYLOW_HIP_WS_ASYNC"); return e && e[0] == '1'; }();
-  return v;
-}
-// SYLOW_HIP_WS_POISON=1 (debugging only): fill every leased block with 0xA5 before use, so that a kernel reading scratch it has
-// not written yet cannot be masked by a previous call's identical contents
-static bool ws_poison() {
-  static const bool v = [] { const char* e = getenv("SYLOW_HIP_WS_POISON"); return e && e[0] == '1'; }();
-  return v;
-}
 int32_t Lease::acquire(size_t bytes, hipStream_t stream) {
-  if (ws_async()) {
-    HIPCHK(hipMallocAsync(&p, bytes ? bytes : 1, stream));
-    dev = -2; slot = 0; st = stream;
-    if (ws_poison()) HIPCHK(hipMemsetAsync(p, 0xA5, bytes, stream));
-    return SYLOW_HIP_OK;
-  }
   std::lock_guard<std::mutex> lock(g_mu);
   int d = 0;
   int32_t rc = current_device(d);
@@ -261,16 +239,10 @@ int32_t Lease::acquire(size_t bytes, hipStream_t stream) {
   }
   b.leased = true;
   p = b.p; dev = d; slot = pick; st = stream;
-  if (ws_poison()) HIPCHK(hipMemsetAsync(p, 0xA5, bytes, stream));
   return SYLOW_HIP_OK;
 }
 int32_t Lease::release() {
   if (slot < 0) return SYLOW_HIP_OK;
-  if (dev == -2) {
-    slot = -1;
-    HIPCHK(hipFreeAsync(p, st));
-    return SYLOW_HIP_OK;
-  }
   std::lock_guard<std::mutex> lock(g_mu);
   if ((size_t)slot >= g_dev[dev].blocks.size()) { slot = -1; return SYLOW_HIP_OK; }    // defensive: shutdown refuses while a block is leased
   Block& b = g_dev[dev].blocks[slot];
@@ -340,23 +312,6 @@ int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st) {
   *out = D.g2comb;
   return SYLOW_HIP_OK;
 }
-int32_t gen_lines_sat(const u32** out, hipStream_t st) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  int d = 0;
-  int32_t rc = current_device(d);
-  if (rc != SYLOW_HIP_OK) return rc;
-  DevState& D = g_dev[d];
-  if (!D.gensat) {
-    u32* t = nullptr;
-    HIPCHK(hipMalloc((void**)&t, 87 * 48 * sizeof(u32)));
-    rc = single::build_gen_lines(t, st);
-    hipError_t e = (rc == SYLOW_HIP_OK) ? hipStreamSynchronize(st) : hipSuccess;
-    if (rc != SYLOW_HIP_OK || e != hipSuccess) { (void)hipFree(t); return rc != SYLOW_HIP_OK ? rc : fail(e, "generator line table"); }
-    D.gensat = t;
-  }
-  *out = D.gensat;
-  return SYLOW_HIP_OK;
-}
 }  // namespace host
 
 // ================================================================== C ABI ======================
@@ -412,7 +367,7 @@ int32_t sylow_hip_shutdown(void) {
   int32_t rc = SYLOW_HIP_OK;
   for (int d = 0; d < host::MAX_DEV; ++d) {
     host::DevState& D = host::g_dev[d];
-    if (D.blocks.empty() && !D.gen29 && !D.gensat && !D.g2comb && !D.g1comb) continue;
+    if (D.blocks.empty() && !D.gen29 && !D.g2comb && !D.g1comb) continue;
     if (hipSetDevice(d) != hipSuccess) { rc = SYLOW_HIP_E_HIP; continue; }
     hipError_t e = hipDeviceSynchronize();          // nothing may still be reading a block or a table
     if (e != hipSuccess) rc = host::fail(e, "hipDeviceSynchronize(shutdown)");
@@ -422,12 +377,28 @@ int32_t sylow_hip_shutdown(void) {
     }
     D.blocks.clear();
     if (D.gen29) { (void)hipFree(D.gen29); D.gen29 = nullptr; }
-    if (D.gensat) { (void)hipFree(D.gensat); D.gensat = nullptr; }
     if (D.g2comb) { (void)hipFree(D.g2comb); D.g2comb = nullptr; }
     if (D.g1comb) { (void)hipFree(D.g1comb); D.g1comb = nullptr; }
   }
   if (have_prev) (void)hipSetDevice(prev);
   return rc;
+}
+// Scratch blocks grow with the largest batch a call has seen (the line tables of a 2^20-pair product take ~10 GB) and are kept for reuse.
+// trim frees every block that is idle AND whose last user has completed (its event has fired) and is larger than keep_bytes; blocks in
+// use, or still referenced by queued work, stay.  Cheap; hosts that share the GPU call it after a large batch.
+int32_t sylow_hip_trim(size_t keep_bytes) {
+  std::lock_guard<std::mutex> lock(host::g_mu);
+  int d = 0;
+  int32_t rc = host::current_device(d);
+  if (rc != SYLOW_HIP_OK) return rc;
+  for (host::Block& b : host::g_dev[d].blocks) {
+    if (b.leased || !b.p || b.cap <= keep_bytes) continue;
+    if (b.recorded && hipEventQuery(b.done) != hipSuccess) continue;
+    (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0; b.recorded = false;
+  }
+  (void)hipGetLastError();          // hipEventQuery reports hipErrorNotReady through the sticky error too
+  return SYLOW_HIP_OK;
 }
 int32_t sylow_hip_malloc(void** dptr, size_t bytes) { ARGCHK(dptr); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return SYLOW_HIP_OK; }
 int32_t sylow_hip_free(void* dptr) { HIPCHK(hipFree(dptr)); return SYLOW_HIP_OK; }

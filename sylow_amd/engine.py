@@ -125,6 +125,11 @@ class Engine:
         _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
         _lib.check(getattr(self.lib, name)(*args, self.stream), name)
 
+    def trim(self, keep_bytes: int = 0):
+        """Free this device's idle scratch blocks above `keep_bytes` whose last user has completed (sylow_hip_trim)."""
+        _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
+        _lib.check(self.lib.sylow_hip_trim(keep_bytes), "sylow_hip_trim")
+
     def shutdown(self):
         """Free the library's scratch blocks and generator tables on every device (it stays usable)."""
         _lib.check(self.lib.sylow_hip_shutdown(), "sylow_hip_shutdown")
@@ -406,6 +411,16 @@ class Engine:
 
     def final_exp(self, f):
         return self._unop("sylow_hip_final_exp_batch", 48, f)
+
+    def g1_sum(self, p_xy, p_inf=None):
+        """sum_i P_i as one G1 point (the `+` fold of examples/verify_multiple_messages_same_signer.rs:41-60): ([1, 8] affine words, [1] flag)."""
+        p_xy = _aos(p_xy, 8)
+        n = p_xy.shape[0]
+        dp = self.to_device_soa(p_xy, 8) if n else None
+        dpi = self._flags(p_inf, n) if n else None
+        do, doi = self.empty((8, 1)), self.empty((1,), np.uint8)
+        self._call("sylow_hip_g1_sum_batch", self._ptr(dp), self._ptr(dpi), n, do.ptr, doi.ptr)
+        return self.from_device_soa(do), doi.download()
 
     def pairing(self, p_xy, q_xy, p_inf=None, q_inf=None, pipelined=True, chunk=0, out=None):
         """pairing() (pairing.rs:870-893) on host arrays: [n, 8] / [n, 16] words in, [n, 48] Gt words out.  Default: the chunked,

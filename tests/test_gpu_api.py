@@ -196,6 +196,26 @@ def test_aggregate_verify_api(api):
     assert api.aggregate_verify(one.public_key, msgs, sig) is False
 
 
+def test_batch_verify_api(api):
+    """The small-exponent batch test of the mirror: accepts a valid batch, rejects one with a swapped signature (seeded and OS-drawn
+    weights), validates weight_bits, and refuses a key that was built from raw coordinates outside G2 proper."""
+    kp = api.KeyPair.generate(9, seed=5)
+    msgs = [bytes([i, 1, 2]) for i in range(9)]
+    sig = api.sign(kp.secret_key, msgs)
+    assert api.batch_verify(kp.public_key, msgs, sig) and api.batch_verify(kp.public_key, msgs, sig, weight_bits=64, seed=11)
+    bad = api.G1Affine(np.roll(sig.xy, 1, axis=0), sig.infinity)
+    assert not api.batch_verify(kp.public_key, msgs, bad) and not api.batch_verify(kp.public_key, msgs, bad, seed=12)
+    for wb in (0, 129):
+        with pytest.raises(ValueError):
+            api.batch_verify(kp.public_key, msgs, sig, weight_bits=wb)
+    raw = api.G2Affine(kp.public_key.xy.copy(), kp.public_key.infinity)           # membership not established: checked, and passes
+    assert not raw.in_subgroup and api.batch_verify(raw, msgs, sig)
+    off = raw.xy.copy()
+    off[0, :4] = np.array([5, 0, 0, 0], dtype=np.uint64)                          # not on the twist
+    with pytest.raises(ValueError):
+        api.batch_verify(api.G2Affine(off, raw.infinity), msgs, sig)
+
+
 def test_mirror_sub_and_tower_classes(api, coracle):
     """Sub for points (group.rs:614-624) and the Fp2 / Fp6 / Fp12 value classes of the mirror: operators and the small items
     (residue_mul, frobenius, square) against the oracle."""

@@ -1,8 +1,6 @@
 """Lane-pair kernels (sylow_amd/csrc/plk_*.hip): ragged batch sizes (partial wavefronts, odd element counts), identity flags mixed
-inside one wavefront, and the single-lane twin (SYLOW_HIP_SINGLE_LANE=1) replaying the pairing test files in a subprocess."""
+inside one wavefront (pair geometry: bn254_pair.hpp -- lanes l and 7 - l of a group of 8)."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -37,12 +35,3 @@ def test_identity_flags_inside_a_wavefront(engine, coracle):
     dead = (p_inf | q_inf).astype(bool)
     exp[dead] = one
     assert np.array_equal(got, exp)
-
-
-def test_single_lane_twin_passes_the_same_pairing_tests():
-    """The one-element-per-lane kernels stay selectable; they must satisfy the same parity tests."""
-    env = dict(os.environ, SYLOW_HIP_SINGLE_LANE="1")
-    files = ["tests/test_gpu_pairing.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_hash_bls.py"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files,
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -252,28 +252,3 @@ def test_single_job_route_equals_the_generic_one(engine, coracle):
     pp[1, 4:] = engine.fp_neg(p[:1, 4:])[0]
     _, o = engine.multi_pairing(pp, np.concatenate([q[:1], q[:1]]), [0, 2], skip_infinity=True)
     assert o[0] == 1
-
-
-@pytest.mark.parametrize("mode", ["0", "1"])
-def test_both_multi_pair_routes_pass_the_same_tests(mode):
-    """SYLOW_HIP_MULTI_TABLES=0 forces the in-register shared-squaring schedule for every job size, =1 the lines-to-HBM + table-driven
-    route; the default picks by the batch's average job size, so neither is covered for all shapes by the plain run.
-    Each route must pass this whole file and the EIP-197 vectors (the in-register route also the aggregate products, there with
-    SYLOW_HIP_AGG_FORK=0 and SYLOW_HIP_WIDE_TAIL=0 as well: the aggregate verifiers without their side stream and with the single-element
-    Miller loop / final exponentiation on one lane pair)."""
-    if os.environ.get("SYLOW_HIP_MULTI_TABLES") is not None or os.environ.get("SYLOW_HIP_SINGLE_LANE"):
-        pytest.skip("already inside a forced-route / single-lane run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SYLOW_HIP_MULTI_TABLES=mode)
-    if mode == "0":
-        env["SYLOW_HIP_AGG_FORK"] = "0"
-        env["SYLOW_HIP_WIDE_TAIL"] = "0"         # and the single-element tails on one lane pair instead of the whole wavefront
-    # mode 0 also re-runs the batch-wide products (their chunks take the table route by default); mode 1 sends one-pair jobs through tables
-    files = ["tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py"]
-    if mode == "0":
-        # without the wide routes every small batch of the pairing / BLS / ragged-wavefront tests runs on the one-lane-pair kernels again
-        # (k_pairing, k_bls_verify_fused: by default only batches above 2048 / 1024 elements reach them)
-        files += ["tests/test_gpu_aggregate.py", "tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_lane_pair.py"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files,
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,32 @@
+"""Every route switch the library still has, forced over the pairing / verification / multi-pairing test files in a child run -- the
+default build picks by batch size, so no single plain run covers every route for every shape:
+  SYLOW_HIP_MULTI_TABLES=0   in-register shared-squaring schedule for every multi-pair job (default: by the batch's average job size)
+  SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
+  SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
+                             shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
+                             above 2048 / 1024 elements reach them)
+  SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
+(sylow_amd/csrc/plk_multi.hip; nothing else in the library reads the environment.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
+         "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py"]
+ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"},
+          {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
+
+
+@pytest.mark.parametrize("route", ROUTES, ids=lambda r: ",".join(f"{k[10:]}={v}" for k, v in r.items()))
+def test_forced_route_passes_the_same_tests(route):
+    if any(k.startswith("SYLOW_HIP_") and k in ("SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_AGG_FORK") for k in os.environ):
+        pytest.skip("already inside a forced-route run")
+    env = dict(os.environ, **route)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--deselect",
+                        "tests/test_gpu_aggregate.py::test_rccl_entry_points_one_rank_communicator"] + FILES,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]

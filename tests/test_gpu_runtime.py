@@ -105,6 +105,13 @@ def test_shutdown_then_reuse(engine, coracle):
     assert engine.bls_verify(pk, msgs, sig, fused=True).tolist() == [1, 1]
     engine.shutdown()
     engine.shutdown()                                                              # idempotent
+    # trim: idle, completed scratch blocks are handed back; the next call leases afresh and computes the same
+    again, _ = engine.pairing_product(p, q)
+    engine.sync()
+    engine.trim(0)
+    engine.trim(1 << 40)                                                           # nothing is above the threshold: a no-op
+    final, _ = engine.pairing_product(p, q)
+    assert np.array_equal(before, again) and np.array_equal(before, final)
 
 
 def test_set_device_is_reasserted_and_checked(engine):

@@ -151,3 +151,32 @@ def test_projective_ct_eq_vs_oracle(engine, coracle):
     b2[4] = limbs([7, 1, 2, 3, 0, 0]).reshape(-1)
     got, exp = engine.g2_ct_eq(a2, b2), coracle.g2_ct_eq(a2, b2)
     assert np.array_equal(got, exp) and list(got[:5]) == [1, 0, 1, 0, 1]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 17, 513, 600, 5000, 70000])
+def test_g1_sum_vs_oracle(engine, coracle, n):
+    """sylow_hip_g1_sum_batch: the fold of Add for G1Projective (group.rs:528-599) over a batch -- staged serial accumulation on the device
+    against a left-to-right fold by the oracle's own addition; identity flags inside, and P + (-P) in the batch."""
+    from helpers import P as PRIME
+    k = engine.xoshiro_fp_soa(SEED + 600 + n, max(n, 1)).T.copy()[:n]
+    pts, _ = engine.g1_scalar_mul(np.tile(pack([1, 2], 8), (n, 1)), k) if n else (np.zeros((0, 8), np.uint64), None)
+    flags = (np.random.default_rng(n).random(n) < 0.1).astype(np.uint8)
+    if n >= 4:                                        # a point and its negative: the complete formulas must pass through the identity
+        neg = pts[2].copy()
+        y = sum(int(neg[4 + j]) << (64 * j) for j in range(4))
+        neg[4:8] = limbs([(PRIME - y) % PRIME])[0]
+        pts[3] = neg
+        flags[2] = flags[3] = 0
+    got_xy, got_inf = engine.g1_sum(pts, flags)
+    one = np.zeros((1, 4), dtype=np.uint64); one[0, 0] = 1
+    acc = np.concatenate([np.zeros((1, 4), np.uint64), one, np.zeros((1, 4), np.uint64)], axis=1)      # (0 : 1 : 0)
+    live = pts[flags == 0]
+    # fold in chunks: pairwise tree on the host side of the ORACLE's addition (associativity is the group law's; the affine result is unique)
+    cur = np.concatenate([live, np.tile(one, (live.shape[0], 1))], axis=1) if live.shape[0] else np.zeros((0, 12), np.uint64)
+    while cur.shape[0] > 1:
+        if cur.shape[0] % 2:
+            cur = np.concatenate([cur, acc], axis=0)
+        cur = coracle.g1_add(cur[0::2], cur[1::2])
+    total = cur if cur.shape[0] else acc
+    exp_xy, exp_inf = coracle.g1_to_affine(total)
+    assert np.array_equal(got_inf, exp_inf) and (exp_inf[0] or np.array_equal(got_xy, exp_xy))

@@ -22,4 +22,4 @@ def timed(fn, reps=3):
 tf = timed(lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv))
 assert ok.download().all()
 ts = timed(lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv))
-print("inside=%s  verify %.2f ms  same-signer shape %.2f ms" % (os.environ.get("SYLOW_HIP_VERIFY_HASH_INSIDE", "0"), tf, ts))
+print("verify %.2f ms  same-signer shape %.2f ms" % (tf, ts))
