@@ -71,7 +71,9 @@ def main():
     config("C2c_g2_scalar_mul_2^20", n, lambda: eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", q.ptr, None, ka.ptr, o2.ptr, o2i.ptr, n), "scalar-mul")
     config("C2c_g2_scalar_mul_any_2^20", n, lambda: eng._call("sylow_hip_g2_scalar_mul_batch", q.ptr, None, ka.ptr, o2.ptr, o2i.ptr, n), "scalar-mul")
     config("C2c_g2_generator_mul_2^20", n, lambda: eng._call("sylow_hip_g2_generator_mul_batch", ka.ptr, o2.ptr, o2i.ptr, n), "scalar-mul")
-    del o1, o1i, o2, o2i
+    s1, s1i = eng.empty((8, 1)), eng.empty((1,), np.uint8)
+    config("g1_sum_2^20", n, lambda: eng._call("sylow_hip_g1_sum_batch", p.ptr, None, n, s1.ptr, s1i.ptr), "point")
+    del o1, o1i, o2, o2i, s1, s1i
     # C5: byte-level ecPairing, 2^16 jobs of k pairs (the construction of bench.single_gpu_configs)
     nj = 1 << 16
     npts = 2 * nj
