@@ -57,12 +57,15 @@ G2 = [0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED,
       0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA,
       0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B]
 M64 = (1 << 64) - 1
+HOST_ONLY_UNITS = ("pipeline.hip",)     # no device code: editing them does not change any kernel
+
+
 def csrc_hash():
     """Hash of every kernel source: the committed PMC summary (profiles/pmc_current.json) is only valid for the build it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sylow_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp")) and name not in HOST_ONLY_UNITS:
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

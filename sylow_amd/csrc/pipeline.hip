@@ -4,8 +4,8 @@
 // verify(&G2Projective, &[u8], &G1Projective) -> bool, lib.rs:223-236), i.e. a host that switches to this library holds
 // arrays of structs in host memory (a Rust Vec<G1Affine> is [n][8] words, element-major).  Upload -> compute -> download run
 // serially would leave the GPU idle for the transfers (2^20 pairings: 201 MB up + 403 MB down, ~8 % of the 119 ms of compute on
-// PCIe Gen5).  Here a batch is cut into chunks (a base chunk of 2^16 elements -- one resident set of lane pairs -- first and last,
-// up to four times that in between: `schedule`) that alternate between TWO streams, each with its own device block:
+// PCIe Gen5).  Here a batch is cut into a few chunks of growing size (2^16 elements -- one resident set of lane pairs -- then 2^18,
+// then the rest; a short last chunk where the results are large: `schedule`) that alternate between TWO streams, each with its own device block:
 //
 //     stream k & 1:   H2D(chunk k) -> AoS->SoA -> kernels -> SoA->AoS -> D2H(chunk k)
 //
@@ -44,23 +44,29 @@ struct Pipe {
 };
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // Chunk schedule.  A launch costs ~1 ms beyond its share of the work however large it is (its wavefronts start in step and drain
-// unevenly; measured on k_pairing: 2^16 elements 8.6 ms, 2^18 30.7 ms, 2^20 119.5 ms), the first chunk's upload and the last chunk's
-// download are the only copies nothing hides: so the batch opens and closes with one `base` chunk (short exposed copies) and the middle
-// goes in chunks of up to 4 x base (few launches).  Returns the chunk boundaries (k + 1 offsets); the largest chunk is *cmax.
-inline std::vector<size_t> schedule(size_t n, size_t base, size_t* cmax) {
+// unevenly; measured on k_pairing: 2^16 elements 8.6 ms, 2^18 30.7 ms, 2^20 119.5 ms), and the first chunk's upload and the last
+// chunk's download are the only copies nothing hides.  So: a geometric ramp -- base, 4 base, 16 base, ... (chunk k + 1's upload, ~8 ns
+// per element even from pageable memory, hides behind chunk k's ~115 ns per element as long as it is at most ~4 times as large), capped at
+// 32 base, the rest in one piece -- and, when the results are large (Gt values: 384 bytes per element), one base chunk at the END so that the
+// exposed download is short.  Returns the chunk boundaries (k + 1 offsets); the largest chunk is *cmax.
+inline std::vector<size_t> schedule(size_t n, size_t base, bool large_results, size_t* cmax) {
+  // sizes of the ramp-down at the end (large results only): ..., 4 base, base -- chunk k's download (~15 ns per element) hides behind chunk
+  // k + 1's kernels as long as that chunk is not much smaller than a quarter of it, and only the last, small download is exposed
+  std::vector<size_t> down;
+  size_t reserved = 0;
+  if (large_results)
+    for (size_t c = base; c <= 4 * base && reserved + c + base <= n / 2; c *= 4) { down.push_back(c); reserved += c; }
   std::vector<size_t> cut(1, 0);
-  const size_t cap = 4 * base;
-  size_t pos = 0;
-  auto push = [&](size_t m) { pos += m; cut.push_back(pos); };
-  if (n <= 2 * base) {
-    if (n > base) { push(n / 2); push(n - n / 2); } else push(n);
-  } else {
-    push(base);
-    size_t mid = n - 2 * base;
-    const size_t k = (mid + cap - 1) / cap;                 // number of middle chunks, sizes as equal as possible
-    for (size_t i = 0; i < k; ++i) { const size_t m = mid / (k - i); push(m); mid -= m; }
-    push(base);
+  size_t pos = 0, c = base;
+  const size_t body = n - reserved;
+  while (pos < body) {
+    size_t m = std::min(c, body - pos);
+    if (body - pos - m < c) m = body - pos;             // what would be left is smaller than this chunk: take it along
+    pos += m;
+    cut.push_back(pos);
+    c = std::min(4 * c, 32 * base);                     // bounded device blocks: at most 2^21 elements (2.4 GB) per chunk at the default base
   }
+  for (size_t i = down.size(); i-- > 0;) { pos += down[i]; cut.push_back(pos); }
   size_t mx = 0;
   for (size_t i = 1; i < cut.size(); ++i) mx = std::max(mx, cut[i] - cut[i - 1]);
   *cmax = mx;
@@ -77,7 +83,7 @@ template <bool WIRE>
 static int32_t pairing_pipeline(const void* p_in, const uint8_t* p_inf, const void* q_in, const uint8_t* q_inf, uint64_t* gt_aos,
                                 uint8_t* st_p, uint8_t* st_q, size_t n, size_t chunk) {
   size_t c = 0;
-  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, &c);
+  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, /*large_results=*/true, &c);
   // block layout (bytes), c = the largest chunk: p_in 64 c | q_in 128 c | p_soa 64 c | q_soa 128 c | gt_soa 384 c | gt_aos 384 c | p_inf c | q_inf c | st_p c | st_q c
   const size_t o_pa = 0, o_qa = o_pa + 64 * c, o_ps = o_qa + 128 * c, o_qs = o_ps + 64 * c, o_gs = o_qs + 128 * c, o_ga = o_gs + 384 * c,
                o_pi = o_ga + 384 * c, o_qi = align256(o_pi + c), o_sp = align256(o_qi + c), o_sq = align256(o_sp + c), total = align256(o_sq + c);
@@ -123,7 +129,7 @@ template <bool WIRE>
 static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets, const void* sig_in,
                                const uint8_t* sig_inf, uint8_t* ok, uint8_t* st_pk, uint8_t* st_sig, size_t n, size_t chunk) {
   size_t c = 0;
-  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, &c);
+  const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, /*large_results=*/false, &c);     // one flag byte per element comes back
   const size_t nchunks = cut.size() - 1;
   size_t max_msg = 0;
   for (size_t k = 0; k < nchunks; ++k) {

@@ -24,11 +24,14 @@ N_SIMD, N_XCD = 1024, 8
 ALGO_BYTES = {"pairing": 576, "Fp op": 96, "scalar-mul": None, "job": None, "hash": 32 + 64, "signature": None, "verify": 225}
 
 
+HOST_ONLY_UNITS = ("pipeline.hip",)     # no device code: editing them does not change any kernel
+
+
 def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sylow_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp")) and name not in HOST_ONLY_UNITS:
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
