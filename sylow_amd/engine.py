@@ -586,6 +586,33 @@ class Engine:
     def g1_from_be_bytes(self, blobs): return self._from_bytes("sylow_hip_g1_from_be_bytes_batch", 8, 64, blobs)
     def g2_from_be_bytes(self, blobs): return self._from_bytes("sylow_hip_g2_from_be_bytes_batch", 16, 128, blobs)
 
+    # ---- the value-typed calls on the reference's wire format (pipeline.hip) ----------------
+    def pairing_from_bytes(self, p_blobs, q_blobs, chunk=0):
+        """pairing() on G1Affine / G2Affine::to_be_bytes blobs (64 / 128 bytes each): decoding + validation on the device inside the host
+        pipeline.  Returns (gt [n, 48], status_p [n], status_q [n]); an element with a non-zero status entered as the identity (Gt = 1)."""
+        n = len(p_blobs)
+        assert len(q_blobs) == n and all(len(b) == 64 for b in p_blobs) and all(len(b) == 128 for b in q_blobs)
+        pb, qb = np.frombuffer(b"".join(p_blobs) or b"\0", dtype=np.uint8), np.frombuffer(b"".join(q_blobs) or b"\0", dtype=np.uint8)
+        gt, sp, sq = np.empty((n, 48), dtype=np.uint64), np.empty((n,), dtype=np.uint8), np.empty((n,), dtype=np.uint8)
+        _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
+        _lib.check(self.lib.sylow_hip_pairing_host_bytes(pb.ctypes.data, qb.ctypes.data, gt.ctypes.data, sp.ctypes.data, sq.ctypes.data, n, chunk), "sylow_hip_pairing_host_bytes")
+        return gt, sp, sq
+
+    def bls_verify_from_bytes(self, pk_blobs, msgs, sig_blobs, chunk=0):
+        """verify() on wire-format keys (128 bytes) and signatures (64 bytes).  Returns (ok [n], status_pk [n], status_sig [n])."""
+        n = len(msgs)
+        assert len(pk_blobs) == n and len(sig_blobs) == n and all(len(b) == 128 for b in pk_blobs) and all(len(b) == 64 for b in sig_blobs)
+        kb, sb = np.frombuffer(b"".join(pk_blobs) or b"\0", dtype=np.uint8), np.frombuffer(b"".join(sig_blobs) or b"\0", dtype=np.uint8)
+        blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            off[1:] = np.cumsum([len(m) for m in msgs])
+        ok, sk, ss = np.empty((n,), dtype=np.uint8), np.empty((n,), dtype=np.uint8), np.empty((n,), dtype=np.uint8)
+        _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
+        _lib.check(self.lib.sylow_hip_bls_verify_host_bytes(kb.ctypes.data, blob.ctypes.data, off.ctypes.data, sb.ctypes.data, ok.ctypes.data,
+                                                            sk.ctypes.data, ss.ctypes.data, n, chunk), "sylow_hip_bls_verify_host_bytes")
+        return ok, sk, ss
+
     # ---- hashing / BLS ---------------------------------------------------------------------
     def _msgs(self, msgs):
         off = np.zeros(len(msgs) + 1, dtype=np.uint64)

@@ -71,3 +71,51 @@ def test_verify_host_equals_device_call(engine, n, chunk):
 def test_host_calls_empty_batch(engine):
     assert engine.pairing(np.zeros((0, 8), np.uint64), np.zeros((0, 16), np.uint64)).shape == (0, 48)
     assert engine.bls_verify(np.zeros((0, 16), np.uint64), [], np.zeros((0, 8), np.uint64)).shape == (0,)
+
+
+def test_wire_format_pipelines(engine, coracle):
+    """sylow_hip_pairing_host_bytes / sylow_hip_bls_verify_host_bytes: G1Affine / G2Affine::to_be_bytes blobs (g1.rs:151-180, g2.rs:319-359) in,
+    decoded + validated on the device inside the pipeline.  Valid input == the word-level calls; an off-curve G1 point, a G2 point outside the
+    r-torsion and a non-canonical coordinate are reported per element with the reference's GroupError codes and enter as the identity."""
+    n = 700
+    sk, p_xy, q_xy = points(engine, SEED + 60, n)
+    pb, qb = engine.g1_to_be_bytes(p_xy), engine.g2_to_be_bytes(q_xy)
+    gt, sp, sq = engine.pairing_from_bytes(pb, qb, chunk=128)
+    assert not sp.any() and not sq.any()
+    assert np.array_equal(gt, engine.pairing(p_xy, q_xy, pipelined=False))
+    # planted failures
+    pb2, qb2 = list(pb), list(qb)
+    pb2[5] = pb[5][:63] + bytes([pb[5][63] ^ 1])                                   # y off by one: not on the curve
+    pb2[6] = b"\x30\x64\x4e\x72\xe1\x31\xa0\x29\xb8\x50\x45\xb6\x81\x81\x58\x5d\x97\x81\x6a\x91\x68\x71\xca\x8d\x3c\x20\x8c\x16\xd8\x7c\xfd\x47" + pb[6][32:]   # x = p: not canonical
+    # a twist point outside G2: x = 1 is on the twist for some y?  take a valid point and add a point of the cofactor part instead: simplest
+    # reliable construction is the test vector the subgroup-check test uses -- reuse the engine's own check to find one by scanning small x
+    from helpers import fp2_sqrt, P as PRIME
+    from oracle import pyref as R
+    off_sub = None
+    for x0 in range(1, 200):
+        rhs = R.fp2_add(R.fp2_mul(R.fp2_square((x0, 0)), (x0, 0)), R.TWIST_B)
+        y = fp2_sqrt(rhs)
+        if y is not None:
+            cand = pack([x0, 0, y[0], y[1]], 16)
+            if engine.g2_subgroup_check(cand)[0] == 2:
+                off_sub = cand
+                break
+    assert off_sub is not None
+    qb2[9] = engine.g2_to_be_bytes(off_sub)[0]
+    gt2, sp2, sq2 = engine.pairing_from_bytes(pb2, qb2, chunk=128)
+    assert sp2[5] == 1 and sp2[6] == 4 and sq2[9] == 2 and sp2.sum() == 5 and sq2.sum() == 2       # NOT_ON_CURVE, DECODE_ERROR, NOT_IN_SUBGROUP
+    one = np.zeros(48, dtype=np.uint64); one[0] = 1
+    for i in (5, 6, 9):
+        assert np.array_equal(gt2[i], one)
+    keep = np.ones(n, dtype=bool); keep[[5, 6, 9]] = False
+    assert np.array_equal(gt2[keep], gt[keep])
+    # verify from bytes
+    msgs = [bytes([i & 255]) * (i % 40) for i in range(n)]
+    sig_xy, sig_inf = engine.bls_sign(sk, msgs)
+    pk_xy, pk_inf = engine.g2_scalar_mul(np.tile(pack(G2, 16), (n, 1)), sk)
+    ok, s1, s2 = engine.bls_verify_from_bytes(engine.g2_to_be_bytes(pk_xy), msgs, engine.g1_to_be_bytes(sig_xy), chunk=300)
+    assert ok.all() and not s1.any() and not s2.any()
+    sb = engine.g1_to_be_bytes(sig_xy)
+    sb[3], sb[4] = sb[4], sb[3]
+    ok2, _, _ = engine.bls_verify_from_bytes(engine.g2_to_be_bytes(pk_xy), msgs, sb)
+    assert not ok2[3] and not ok2[4] and ok2.sum() == n - 2
