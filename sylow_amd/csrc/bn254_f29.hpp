@@ -298,6 +298,26 @@ BN_DEV F29 f29_reduce_terms(const F29* const (&x)[N], const i32 (&k)[N]) {
   return r;
 }
 
+// Carry normalisation of a linear combination sum_j k_j x_j WITHOUT the reduce step (no multiple of p is subtracted): one chain of
+// multiply-adds, mask, shift; limbs 0..7 in [0, 2^29), top limb signed: an N-class value with V = sum |k_j| V(x_j).  For combinations
+// whose VALUE stays small enough to be a product operand (|V| <= 8) but whose limbs do not fit 32-bit lazy arithmetic (the x 9 of xi).
+template <int N>
+BN_DEV F29 f29_norm_terms(const F29* const (&x)[N], const i32 (&k)[N]) {
+  F29 r;
+  i64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { acc += (i64)x[j]->v[i] * k[j]; BN_CHAIN(acc); }
+    r.v[i] = (i32)((u32)acc & BN_M29);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) acc += (i64)x[j]->v[8] * k[j];
+  r.v[8] = (i32)acc;
+  return r;
+}
+
 // ---- out-of-line product leaf: 18 scalar ABI arguments (two 9-limb structs would travel through the stack) -------------
 // operands R / N / D class, L(a) L(b) <= 2.5; output normalized
 BN_NOINLINE F29 f29_mul_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,

@@ -156,17 +156,29 @@ BN_DEV void w12_to_s12(S12& r, const W12& a) {
 }
 
 // ---- Fp6: inputs R / N / D with |V| <= 4, outputs R ---------------------------------------------------------------------
-BN_DEV W6 w6_mul(const W6& a, const W6& b) {
+// The six Karatsuba products and their LAZY recombination (32-bit limb sums, no pass over them yet).  SUBTRACTIVE Karatsuba (round 4):
+//   a_i b_j + a_j b_i = a_i b_i + a_j b_j - (a_i - a_j)(b_i - b_j)
+// the difference of two N-class values is a D-class value (|limbs| < 2^29) and goes into the product leaf as it is, where the additive
+// form had to carry-normalise every pre-addition (25 instructions each, six per Fp6 product).  Operands therefore R / N (limbs in [0, 2^29)).
+//   c0 = v0 + xi x0,  c1 = y1 + xi v2,  c2 = y2     with  v0, v2 in [0, 2^29),  x0, y1 in (-2^29, 2^30),  y2 in (-2^29, 2^30 + 2^29).
+// w6_mul finishes each coefficient with one reduce pass; a caller that only adds further terms to a coefficient (the second Fp6 product of an
+// Fp12 squaring, the third of an Fp12 product) folds them into the SAME pass instead of reducing twice.
+struct W6Raw { W2 v0, x0, y1, v2, y2; };
+BN_DEV W6Raw w6_mul_raw(const W6& a, const W6& b) {
   const W2 v0 = w2_mul(a.c0, b.c0);
   const W2 v1 = w2_mul(a.c1, b.c1);
   const W2 v2 = w2_mul(a.c2, b.c2);
-  const W2 t0 = w2_mul(w2_norm(w2_add(a.c1, a.c2)), w2_norm(w2_add(b.c1, b.c2)));
-  const W2 t1 = w2_mul(w2_norm(w2_add(a.c0, a.c1)), w2_norm(w2_add(b.c0, b.c1)));
-  const W2 t2 = w2_mul(w2_norm(w2_add(a.c0, a.c2)), w2_norm(w2_add(b.c0, b.c2)));
+  const W2 s0 = w2_mul(w2_sub(a.c1, a.c2), w2_sub(b.c1, b.c2));
+  const W2 s1 = w2_mul(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
+  const W2 s2 = w2_mul(w2_sub(a.c0, a.c2), w2_sub(b.c0, b.c2));
+  return W6Raw{v0, w2_sub(w2_add(v1, v2), s0), w2_sub(w2_add(v0, v1), s1), v2, w2_add(w2_sub(w2_add(v0, v2), s2), v1)};
+}
+BN_DEV W6 w6_mul(const W6& a, const W6& b) {
+  const W6Raw m = w6_mul_raw(a, b);
   W6 r;
-  r.c0 = w2_xi_lin(w2_sub(w2_sub(t0, v1), v2), 1, v0, 1);               // v0 + xi (t0 - v1 - v2)
-  r.c1 = w2_xi_lin(v2, 1, w2_sub(w2_sub(t1, v0), v1), 1);               // (t1 - v0 - v1) + xi v2
-  r.c2 = w2_reduce(w2_add(w2_sub(w2_sub(t2, v0), v2), v1));             // t2 - v0 - v2 + v1
+  r.c0 = w2_xi_lin(m.x0, 1, m.v0, 1);                                   // v0 + xi (t0 - v1 - v2)
+  r.c1 = w2_xi_lin(m.v2, 1, m.y1, 1);                                   // (t1 - v0 - v1) + xi v2
+  r.c2 = w2_reduce(m.y2);                                               // t2 - v0 - v2 + v1
   return r;
 }
 BN_DEV W6 w6_add_norm(const W6& a, const W6& b) {
@@ -175,14 +187,19 @@ BN_DEV W6 w6_add_norm(const W6& a, const W6& b) {
 BN_DEV W6 w6_sub(const W6& a, const W6& b) { return W6{w2_sub(a.c0, b.c0), w2_sub(a.c1, b.c1), w2_sub(a.c2, b.c2)}; }
 
 // ---- Fp12: inputs R / N, outputs R / N --------------------------------------------------------------------------------
+// c1 = t2 - t0 - t1 with the third Fp6 product left raw: every coefficient of c1 is ONE pass over (raw piece of t2) - t0.ci - t1.ci
+// (limb ranges: v0 - t0.c0 - t1.c0 in (-2^30, 2^29), y1 - t0.c1 - t1.c1 in (-2^30 - 2^29, 2^30), y2 - t0.c2 in (-2^30, 2^30 + 2^29): all int32)
+BN_DEV void w12_mul_c1(W12& r, const W6Raw& t2, const W6& t0, const W6& t1) {
+  r.c1.c0 = w2_xi_lin(t2.x0, 1, w2_sub(w2_sub(t2.v0, t0.c0), t1.c0), 1);                  // the sums of t2's operands are N-class: w6_add_norm
+  r.c1.c1 = w2_xi_lin(t2.v2, 1, w2_sub(w2_sub(t2.y1, t0.c1), t1.c1), 1);
+  r.c1.c2 = w2_lin2(w2_sub(t2.y2, t0.c2), 1, t1.c2, -1);
+}
 BN_DEV W12 w12_mul(const W12& a, const W12& b) {
   const W6 t0 = w6_mul(a.c0, b.c0);
   const W6 t1 = w6_mul(a.c1, b.c1);
-  const W6 t2 = w6_mul(w6_add_norm(a.c0, a.c1), w6_add_norm(b.c0, b.c1));
+  const W6Raw t2 = w6_mul_raw(w6_add_norm(a.c0, a.c1), w6_add_norm(b.c0, b.c1));
   W12 r;
-  r.c1.c0 = w2_lin2(w2_sub(t2.c0, t0.c0), 1, t1.c0, -1);
-  r.c1.c1 = w2_lin2(w2_sub(t2.c1, t0.c1), 1, t1.c1, -1);
-  r.c1.c2 = w2_lin2(w2_sub(t2.c2, t0.c2), 1, t1.c2, -1);
+  w12_mul_c1(r, t2, t0, t1);
   r.c0.c0 = w2_xi_lin(t1.c2, 1, t0.c0, 1);                               // t0 + v t1
   r.c0.c1 = w2_norm(w2_add(t0.c1, t1.c0));                               // two R values: N with |V| < 1.1
   r.c0.c2 = w2_norm(w2_add(t0.c2, t1.c1));
@@ -191,46 +208,55 @@ BN_DEV W12 w12_mul(const W12& a, const W12& b) {
 // a * b for b with b.c1.c2 = 0 -- the product of two lines (w12_line_product): the middle Fp6 product has a zero coefficient on its
 // right-hand side, 5 products instead of 6 (17 for the Fp12 product instead of 18)
 BN_DEV W6 w6_mul_b2zero(const W6& a, const W6& b) {
+  // (a0 + a1 v + a2 v^2)(b0 + b1 v): v^0: a0 b0 + xi a2 b1, v^1: a0 b1 + a1 b0, v^2: a1 b1 + a2 b0 -- the two products with a2 directly, the
+  // cross term by subtractive Karatsuba (a0 - a1)(b0 - b1): five products, no carry-normalised pre-additions.  Operands R / N.
   const W2 v0 = w2_mul(a.c0, b.c0);
   const W2 v1 = w2_mul(a.c1, b.c1);
-  const W2 t0 = w2_mul(w2_norm(w2_add(a.c1, a.c2)), b.c1);
-  const W2 t1 = w2_mul(w2_norm(w2_add(a.c0, a.c1)), w2_norm(w2_add(b.c0, b.c1)));
-  const W2 t2 = w2_mul(w2_norm(w2_add(a.c0, a.c2)), b.c0);
+  const W2 p21 = w2_mul(a.c2, b.c1);
+  const W2 p20 = w2_mul(a.c2, b.c0);
+  const W2 s1 = w2_mul(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
   W6 r;
-  r.c0 = w2_xi_lin(w2_sub(t0, v1), 1, v0, 1);                            // v0 + xi (t0 - v1)
-  r.c1 = w2_reduce(w2_sub(w2_sub(t1, v0), v1));                          // t1 - v0 - v1
-  r.c2 = w2_reduce(w2_add(w2_sub(t2, v0), v1));                          // t2 - v0 + v1
+  r.c0 = w2_xi_lin(p21, 1, v0, 1);                                       // v0 + xi a2 b1
+  r.c1 = w2_reduce(w2_sub(w2_add(v0, v1), s1));                          // a0 b1 + a1 b0
+  r.c2 = w2_norm(w2_add(p20, v1));                                       // a2 b0 + a1 b1: two N values
   return r;
 }
 BN_DEV W12 w12_mul_line_pair(const W12& a, const W12& b) {
   const W6 t0 = w6_mul(a.c0, b.c0);
   const W6 t1 = w6_mul_b2zero(a.c1, b.c1);
-  const W6 t2 = w6_mul(w6_add_norm(a.c0, a.c1), W6{w2_norm(w2_add(b.c0.c0, b.c1.c0)), w2_norm(w2_add(b.c0.c1, b.c1.c1)), b.c0.c2});
+  const W6Raw t2 = w6_mul_raw(w6_add_norm(a.c0, a.c1), W6{w2_norm(w2_add(b.c0.c0, b.c1.c0)), w2_norm(w2_add(b.c0.c1, b.c1.c1)), b.c0.c2});
   W12 r;
-  r.c1.c0 = w2_lin2(w2_sub(t2.c0, t0.c0), 1, t1.c0, -1);
-  r.c1.c1 = w2_lin2(w2_sub(t2.c1, t0.c1), 1, t1.c1, -1);
-  r.c1.c2 = w2_lin2(w2_sub(t2.c2, t0.c2), 1, t1.c2, -1);
+  w12_mul_c1(r, t2, t0, t1);
   r.c0.c0 = w2_xi_lin(t1.c2, 1, t0.c0, 1);                               // t0 + v t1
   r.c0.c1 = w2_norm(w2_add(t0.c1, t1.c0));
   r.c0.c2 = w2_norm(w2_add(t0.c2, t1.c1));
   return r;
 }
-// complex squaring (fp12.rs:536-550): c0 = (a0 - a1)(a0 - v a1) + a0 a1 + v a0 a1, c1 = 2 a0 a1
+// complex squaring (fp12.rs:536-550): c0 = (a0 - a1)(a0 - v a1) + a0 a1 + v a0 a1, c1 = 2 a0 a1.  The product m = (a0 - a1)(a0 - v a1)
+// stays raw: each coefficient of c0 is ONE pass over m's piece plus the terms of c2 = a0 a1 (limb ranges: x0 + c2.c2 in (-2^29, 2^30 + 2^29), v0 + c2.c0 in
+// [0, 2^30), y1 + c2.c1 + c2.c0 in (-2^29, 2^31): as two terms; y2 and c2.c2 + c2.c1 as two terms)
 BN_DEV W12 w12_sqr(const W12& a) {
-  const W6 d = w6_sub(a.c0, a.c1);                                       // D
+  // both factors of m carry-normalised (N): the subtractive Karatsuba inside w6_mul_raw takes differences of their coefficients
+  const W6 d{w2_norm(w2_sub(a.c0.c0, a.c1.c0)), w2_norm(w2_sub(a.c0.c1, a.c1.c1)), w2_norm(w2_sub(a.c0.c2, a.c1.c2))};
   W6 e;                                                                  // a0 - v a1 = (a0.c0 - xi a1.c2, a0.c1 - a1.c0, a0.c2 - a1.c1)
   e.c0 = w2_xi_lin(a.c1.c2, -1, a.c0.c0, 1);
-  e.c1 = w2_sub(a.c0.c1, a.c1.c0);
-  e.c2 = w2_sub(a.c0.c2, a.c1.c1);
+  e.c1 = w2_norm(w2_sub(a.c0.c1, a.c1.c0));
+  e.c2 = w2_norm(w2_sub(a.c0.c2, a.c1.c1));
   const W6 c2 = w6_mul(a.c0, a.c1);
-  const W6 m = w6_mul(d, e);
+  const W6Raw m = w6_mul_raw(d, e);
   W12 r;
   r.c1.c0 = w2_norm(w2_add(c2.c0, c2.c0));
   r.c1.c1 = w2_norm(w2_add(c2.c1, c2.c1));
   r.c1.c2 = w2_norm(w2_add(c2.c2, c2.c2));
-  r.c0.c0 = w2_xi_lin(c2.c2, 1, w2_add(m.c0, c2.c0), 1);                 // m0 + c2.0 + xi c2.2
-  r.c0.c1 = w2_norm(w2_add(w2_add(m.c1, c2.c1), c2.c0));                 // three R values: N with |V| < 1.6
-  r.c0.c2 = w2_norm(w2_add(w2_add(m.c2, c2.c2), c2.c1));
+  r.c0.c0 = w2_xi_lin(w2_add(m.x0, c2.c2), 1, w2_add(m.v0, c2.c0), 1);   // m0 + c2.0 + xi c2.2
+  {                                                                      // m1 + c2.1 + c2.0 = xi v2 + y1 + (c2.1 + c2.0)
+    const F29 xo = xchg9(m.v2.c);
+    const W2 cc = w2_add(c2.c1, c2.c0);
+    const F29* const t[4] = {&m.v2.c, &xo, &m.y1.c, &cc.c};
+    const i32 c[4] = {bn_keep(9), bn_keep_v(lane_odd() ? 1 : -1), bn_keep(1), bn_keep(1)};
+    r.c0.c1 = W2{f29_reduce_terms(t, c)};
+  }
+  r.c0.c2 = w2_lin2(m.y2, 1, w2_add(c2.c2, c2.c1), 1);                   // m2 + c2.2 + c2.1
   return r;
 }
 // conjugate, N-class output (non-negative limbs: the result may feed a squaring)
@@ -268,17 +294,17 @@ BN_DEV W12 w12_sparse_mul(const W12& f, const W2& x0, const W2& x4, const W2& x2
   const W2 d4 = w2_mul(z4, x4);
   const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p10 = w2_mul(z1, x0);
   const W2 p34 = w2_mul(z3, x4), p30 = w2_mul(z3, x0), p52 = w2_mul(z5, x2);
-  const W2 x02 = w2_norm(w2_add(x0, x2)), x24 = w2_norm(w2_add(x2, x4)), x04 = w2_norm(w2_add(x0, x4));
-  const W2 q02 = w2_mul(w2_norm(w2_add(z0, z2)), x02);
-  const W2 q24 = w2_mul(w2_norm(w2_add(z2, z4)), x24);
-  const W2 q04 = w2_mul(w2_norm(w2_add(z0, z4)), x04);
-  const W2 qs = w2_mul(w2_norm(w2_add(w2_add(z1, z3), z5)), w2_norm(w2_add(x02, x4)));
+  // the three cross sums z_i x_j + z_j x_i by subtractive Karatsuba: d_i + d_j - (z_i - z_j)(x_i - x_j), differences lazy (D-class operands)
+  const W2 q02 = w2_mul(w2_sub(z0, z2), w2_sub(x0, x2));
+  const W2 q24 = w2_mul(w2_sub(z2, z4), w2_sub(x2, x4));
+  const W2 q04 = w2_mul(w2_sub(z0, z4), w2_sub(x0, x4));
+  const W2 qs = w2_mul(w2_norm(w2_add(w2_add(z1, z3), z5)), w2_norm(w2_add(w2_add(x0, x2), x4)));
   W12 o;
   o.c0.c0 = w2_xi_lin(w2_add(p12, d4), 1, d0, 1);                                            // xi (z1 x2 + d4) + d0
   o.c0.c1 = w2_xi_lin(w2_add(p54, d2), 1, p10, 1);                                           // xi (z5 x4 + d2) + z1 x0
-  o.c0.c2 = w2_reduce(w2_add(w2_sub(w2_sub(q02, d0), d2), p34));                             // (z0+z2)(x0+x2) - d0 - d2 + z3 x4
-  o.c1.c0 = w2_xi_lin(w2_sub(w2_sub(q24, d2), d4), 1, p30, 1);                               // xi ((z2+z4)(x2+x4) - d2 - d4) + z3 x0
-  o.c1.c1 = w2_xi_lin(p52, 1, w2_sub(w2_sub(q04, d0), d4), 1);                               // xi z5 x2 + (z0+z4)(x0+x4) - d0 - d4
+  o.c0.c2 = w2_reduce(w2_add(w2_sub(w2_add(d0, d2), q02), p34));                             // z0 x2 + z2 x0 + z3 x4          limbs in (-2^29, 2^30 + 2^29)
+  o.c1.c0 = w2_xi_lin(w2_sub(w2_add(d2, d4), q24), 1, p30, 1);                               // xi (z2 x4 + z4 x2) + z3 x0
+  o.c1.c1 = w2_xi_lin(p52, 1, w2_sub(w2_add(d0, d4), q04), 1);                               // xi z5 x2 + z0 x4 + z4 x0
   {                                                                                          // (z1+z3+z5)(x0+x2+x4) - all six cross products
     const W2 sa = w2_add(w2_add(p12, p54), p10), sb = w2_add(w2_add(p34, p30), p52);         // each < 3 * 2^29: fits int32
     const F29* const t[3] = {&qs.c, &sa.c, &sb.c};
@@ -305,46 +331,62 @@ BN_DEV W12 w12_sparse_mul_unit(const W12& f, i32 u, const W2& x4, const W2& x2) 
   const W2 d2 = w2_mul(z2, x2), d4 = w2_mul(z4, x4);
   const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p34 = w2_mul(z3, x4), p52 = w2_mul(z5, x2);
   const W2 a02 = w2_mul(z0, x2), a04 = w2_mul(z0, x4);
-  const W2 x24 = w2_norm(w2_add(x2, x4));
-  const W2 q24 = w2_mul(w2_norm(w2_add(z2, z4)), x24);
-  const W2 q13 = w2_mul(w2_norm(w2_add(z1, z3)), x24);
+  const W2 x24 = w2_sub(x2, x4);                                          // lazy difference (D-class): subtractive Karatsuba, see w6_mul_raw
+  const W2 q24 = w2_mul(w2_sub(z2, z4), x24);                             // d2 + d4 - (z2 x4 + z4 x2)
+  const W2 q13 = w2_mul(w2_sub(z1, z3), x24);                             // p12 + p34 - (z1 x4 + z3 x2)
   W12 o;
   o.c0.c0 = w2_xi_lin_v(w2_add(p12, d4), z0, u);                         // xi (z1 x2 + z4 x4) + u z0
   o.c0.c1 = w2_xi_lin_v(w2_add(p54, d2), z1, u);                         // xi (z5 x4 + z2 x2) + u z1
   o.c0.c2 = w2_lin_v(w2_add(a02, p34), z2, u);                           // z0 x2 + z3 x4 + u z2
-  o.c1.c0 = w2_xi_lin_v(w2_sub(w2_sub(q24, d2), d4), z3, u);             // xi (z2 x4 + z4 x2) + u z3
+  o.c1.c0 = w2_xi_lin_v(w2_sub(w2_add(d2, d4), q24), z3, u);             // xi (z2 x4 + z4 x2) + u z3
   {                                                                      // xi z5 x2 + z0 x4 + u z4
     const F29 xo = xchg9(p52.c);
     const F29* const t[4] = {&p52.c, &xo, &a04.c, &z4.c};
     const i32 c[4] = {bn_keep(9), bn_keep_v(lane_odd() ? 1 : -1), bn_keep(1), bn_keep_v(u)};
     o.c1.c1 = W2{f29_reduce_terms(t, c)};
   }
-  o.c1.c2 = w2_lin_v(w2_sub(w2_sub(q13, p12), p34), z5, u);              // z1 x4 + z3 x2 + u z5
+  o.c1.c2 = w2_lin_v(w2_sub(w2_add(p12, p34), q13), z5, u);              // z1 x4 + z3 x2 + u z5
   return o;
 }
 // pairing.rs:274-350 (Granger-Scott), input R / N with |V| <= 1.2, output R.
 // Fp4 squaring (a + b s)^2, s^2 = xi: c0 = a^2 + xi b^2, c1 = 2 a b.  Written with TWO products instead of three squarings:
-// m = a b, c0 = (a + b)(a + xi b) - m - xi m; on this core a lane-pair squaring is 162 multiply-adds and a product 243, so
-// 2 x 243 beats 3 x 162.  Returns c1 / 2 = m: the callers fold the factor into their linear combination.
-BN_DEV void w_fp4_square(W2& c0, W2& c1h, const W2& a, const W2& b) {
-  const W2 m = w2_mul(a, b);
-  const W2 w = w2_mul(w2_norm(w2_add(a, b)), w2_xi_lin(b, 1, a, 1));
-  c0 = w2_xi_lin(m, -1, w2_sub(w, m), 1);
-  c1h = m;
+// m = a b, w = (a + b)(a + xi b), c0 = w - m - xi m; on this core a lane-pair squaring is 162 multiply-adds and a product 243, so
+// 2 x 243 beats 3 x 162.  The linear layer is ONE pass per output (round 4; before: c0 was reduced and the output combination 3 c0 - 2 z
+// reduced it again):
+//   w = (a - b)(a - xi b) = a^2 + xi b^2 - (1 + xi) a b: the SUBTRACTIVE form -- a - b is a lazy difference (D-class operand, no carry
+//   pass), a - xi b only carry-normalised (f29_norm_terms: a product operand with |V| <= 5.6, no multiple of p needs to go)
+//   3 c0 - 2 z = 3 w + 30 m_own -/+ 3 m_partner - 2 z      (c0 = w + m + xi m;  xi m on this lane = 9 m_own -/+ m_partner)  one reduce pass
+// Returns m (= c1 / 2: the callers fold the factor into their own combination) and that output.  a, b: R / N (limbs in [0, 2^29)).
+BN_DEV W2 w2_xi_norm(const W2& x, const W2& y) {                      // norm(xi x + y), N-class (the wide routines keep the additive form)
+  const F29 xo = xchg9(x.c);
+  const F29* const t[3] = {&x.c, &xo, &y.c};
+  const i32 c[3] = {bn_keep(9), bn_keep_v(lane_odd() ? 1 : -1), bn_keep(1)};
+  return W2{f29_norm_terms(t, c)};
+}
+BN_DEV W2 w2_xi_norm_sub(const W2& x, const W2& y) {                  // norm(y - xi x), N-class
+  const F29 xo = xchg9(x.c);
+  const F29* const t[3] = {&x.c, &xo, &y.c};
+  const i32 c[3] = {bn_keep(-9), bn_keep_v(lane_odd() ? -1 : 1), bn_keep(1)};
+  return W2{f29_norm_terms(t, c)};
+}
+BN_DEV void w_fp4_square_fold(W2& out0, W2& m, const W2& a, const W2& b, const W2& z) {      // out0 = reduce(3 (a^2 + xi b^2) - 2 z), m = a b
+  m = w2_mul(a, b);
+  const W2 w = w2_mul(w2_sub(a, b), w2_xi_norm_sub(b, a));
+  const F29 mo = xchg9(m.c);
+  const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
+  const i32 c[4] = {bn_keep(3), bn_keep(30), bn_keep_v(lane_odd() ? 3 : -3), bn_keep(-2)};
+  out0 = W2{f29_reduce_terms(t, c)};
 }
 BN_DEV W12 w12_cyclotomic_sqr(const W12& f) {
   const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
-  W2 t0, t1, t2, t3;
+  W2 m;
   W12 r;
-  w_fp4_square(t0, t1, z0, z1);
-  r.c0.c0 = w2_lin2(t0, 3, z0, -2);
-  r.c1.c1 = w2_lin2(t1, 6, z1, 2);
-  w_fp4_square(t0, t1, z2, z3);
-  w_fp4_square(t2, t3, z4, z5);
-  r.c0.c1 = w2_lin2(t0, 3, z4, -2);
-  r.c1.c2 = w2_lin2(t1, 6, z5, 2);
-  r.c1.c0 = w2_xi_lin(t3, 6, z2, 2);
-  r.c0.c2 = w2_lin2(t2, 3, z3, -2);
+  w_fp4_square_fold(r.c0.c0, m, z0, z1, z0);               // z0' = 3 t0 - 2 z0
+  r.c1.c1 = w2_lin2(m, 6, z1, 2);                          // z1' = 3 t1 + 2 z1,  t1 = 2 m
+  w_fp4_square_fold(r.c0.c1, m, z2, z3, z4);               // z4' = 3 t0 - 2 z4
+  r.c1.c2 = w2_lin2(m, 6, z5, 2);                          // z5' = 3 t1 + 2 z5
+  w_fp4_square_fold(r.c0.c2, m, z4, z5, z3);               // z3' = 3 t2 - 2 z3
+  r.c1.c0 = w2_xi_lin(m, 6, z2, 2);                        // z2' = 3 xi t3 + 2 z2
   return r;
 }
 
@@ -420,15 +462,16 @@ BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l
 // Inputs R / N, outputs R.
 BN_DEV W12 w12_line_product(const W2& a0, const W2& a4, const W2& a2, const W2& b0, const W2& b4, const W2& b2) {
   const W2 d0 = w2_mul(a0, b0), d2 = w2_mul(a2, b2), d4 = w2_mul(a4, b4);
-  const W2 k02 = w2_mul(w2_norm(w2_add(a0, a2)), w2_norm(w2_add(b0, b2)));
-  const W2 k24 = w2_mul(w2_norm(w2_add(a2, a4)), w2_norm(w2_add(b2, b4)));
-  const W2 k04 = w2_mul(w2_norm(w2_add(a0, a4)), w2_norm(w2_add(b0, b4)));
+  // a_i b_j + a_j b_i = d_i + d_j - (a_i - a_j)(b_i - b_j): lazy differences as operands (coefficients R / N)
+  const W2 k02 = w2_mul(w2_sub(a0, a2), w2_sub(b0, b2));
+  const W2 k24 = w2_mul(w2_sub(a2, a4), w2_sub(b2, b4));
+  const W2 k04 = w2_mul(w2_sub(a0, a4), w2_sub(b0, b4));
   W12 r;
   r.c0.c0 = w2_xi_lin(d4, 1, d0, 1);
   r.c0.c1 = w2_xi_lin(d2, 1, d2, 0);
-  r.c0.c2 = w2_reduce(w2_sub(w2_sub(k02, d0), d2));
-  r.c1.c0 = w2_xi_lin(w2_sub(w2_sub(k24, d2), d4), 1, d2, 0);
-  r.c1.c1 = w2_reduce(w2_sub(w2_sub(k04, d0), d4));
+  r.c0.c2 = w2_reduce(w2_sub(w2_add(d0, d2), k02));
+  r.c1.c0 = w2_xi_lin(w2_sub(w2_add(d2, d4), k24), 1, d2, 0);
+  r.c1.c1 = w2_reduce(w2_sub(w2_add(d0, d4), k04));
   r.c1.c2 = W2{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   return r;
 }
@@ -662,7 +705,7 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
   // product p: pair k of (z0, z1), (z2, z3), (z4, z5);  s = 0: m = a b,  s = 1: w = (a + b)(a + xi b)   (w_fp4_square)
   {
     const W2 a = w2_sel3(k, z0, z2, z4), b = w2_sel3(k, z1, z3, z5);
-    const W2 xs = w2_pick(a, w2_norm(w2_add(a, b)), s), ys = w2_pick(b, w2_xi_lin(b, 1, a, 1), s);
+    const W2 xs = w2_pick(a, w2_norm(w2_add(a, b)), s), ys = w2_pick(b, w2_xi_norm(b, a), s);
     const W2 pr = w2_mul(xs, ys);
     if (j < 6) wide_put(x, p, odd, pr);
   }
@@ -673,7 +716,13 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
     const int ko = p >> 1;
     const W2 m = wide_get(x, 2 * ko, odd), w = wide_get(x, 2 * ko + 1, odd);
     const W2 z = p == 0 ? z0 : p == 1 ? z1 : p == 2 ? z4 : p == 3 ? z5 : p == 4 ? z2 : z3;
-    const W2 ra = w2_lin2(w2_xi_lin(m, -1, w2_sub(w, m), 1), 3, z, -2);
+    W2 ra;                                                            // 3 (w - m - xi m) - 2 z in one pass, as w_fp4_square_fold
+    {
+      const F29 mo = xchg9(m.c);
+      const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
+      const i32 c[4] = {bn_keep(3), bn_keep(-30), bn_keep_v(lane_odd() ? -3 : 3), bn_keep(-2)};
+      ra = W2{f29_reduce_terms(t, c)};
+    }
     const W2 rb = w2_lin2(m, 6, z, 2);
     const W2 rc = w2_xi_lin(m, 6, z, 2);
     const W2 r = (p == 1 || p == 3) ? rb : p == 4 ? rc : ra;
