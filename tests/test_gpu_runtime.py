@@ -131,3 +131,12 @@ def test_soak_short():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "20"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "soak ok" in r.stdout
+
+
+def test_soak_large_short():
+    """~25 s of tools/soak_large.py as a fresh child process: the LARGE-batch kernels (k_pairing, the fused verifier, the line-table multi-pair
+    route, byte-level ecPairing at 2^14 jobs) called over and over -- every repetition bit-identical to the first, the first checked against the
+    oracle / the planted pattern."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_large.py"), "25", "16"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "soak_large ok" in r.stdout

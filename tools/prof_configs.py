@@ -92,7 +92,8 @@ def main():
         d_off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
         d_res, d_st = eng.empty((nj,), np.uint8), eng.empty((nj,), np.uint8)
         config(f"C5_ecpairing_bytes_2^16_k{k}", nj, lambda: eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, k * nj, d_res.ptr, d_st.ptr), "job")
-        assert d_res.download().all() and not d_st.download().any()
+        r_, s_ = d_res.download(), d_st.download()
+        assert r_.all() and not s_.any(), ("ecPairing pattern broken", k, np.flatnonzero(r_ == 0)[:16].tolist(), np.flatnonzero(s_ != 0)[:16].tolist(), s_[s_ != 0][:16].tolist())
         off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
         gtj, iso = eng.empty((48, nj)), eng.empty((nj,), np.uint8)
         config(f"multi_pairing_2^16_k{k}", nj, lambda: eng._call("sylow_hip_multi_pairing_batch", p3.ptr, None, q3.ptr, None, off.ptr, nj, k * nj, 1, gtj.ptr, iso.ptr), "job")
