@@ -399,7 +399,7 @@ int32_t sylow_hip_bls_batch_verify_weighted(const uint64_t* pk_xy, const uint8_t
                                             uint64_t* gt_out, uint8_t* is_one, void* stream);
 
 /* ---- test hooks (stable enough for the repo's own tests; not part of the drop-in surface) ------------------------------------
- * Granger-Scott cyclotomic square (pairing.rs:309-350) and the raw Fp12 selector: 0..7 single-lane tower ops, 8 / 9 product /
+ * Granger-Scott cyclotomic square (pairing.rs:309-350) and the raw Fp12 selector: 0..7 one-element-per-lane tower ops (tower.hip), 8 / 9 product /
  * cyclotomic square on the carry-free core, 10 / 11 exp_by_neg_z (carry-free / saturated), 16..29 the lane-pair Fp12 layer. */
 int32_t sylow_hip_fp12_cyclotomic_sqr_batch(const uint64_t* a, uint64_t* out, size_t n, void* stream);
 int32_t sylow_hip_fp12_hook_batch(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);

@@ -2,18 +2,18 @@
 // coordinate and its partner the c1 coordinate ("even" / "odd" lane below; the geometry is defined under "lane-pair geometry").
 //
 // Why: with one pairing per lane an Fp12 is 96 VGPRs, so Fp12 products cannot keep their operands, result and
-// temporaries inside the 256-register budget of a 2-waves-per-SIMD kernel; the single-lane path therefore moves
+// temporaries inside the 256-register budget of a 2-waves-per-SIMD kernel; the one-pairing-per-lane kernels of round 1 therefore moved
 // ~0.9 KB of scratch per Fp12 operation through L2/HBM (0.93 TB per 2^20 pairings, profiles/r01_pairing_v5), which is
 // what bounds it.  Splitting every Fp2 across two lanes halves the per-lane state (Fp12 = 48 VGPRs, the whole Miller
 // state ~150): the tower lives in registers, and the only memory traffic left is the algorithmic input / output.
 //
-// The price is one DPP quad-permute exchange per Fp2 product: (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a1 b0 + a0 b1) u,
+// The price is one DPP exchange (row_half_mirror: lane l <-> lane 7 - l) per Fp2 product: (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a1 b0 + a0 b1) u,
 // so each lane needs its partner's coordinates of both operands (16 v_mov_dpp) and computes ONE fused two-product
-// Montgomery pass (fp_dot2_inline) -- the same arithmetic the single-lane path spends per coordinate.  Additions,
+// Montgomery pass (fp_dot2_inline) -- the same arithmetic a one-element-per-lane kernel spends per coordinate.  Additions,
 // subtractions, halvings and multiplications by Fp scalars are lane-local.
 //
-// Same formulas, digit schedule and line functions as bn254_tower.hpp / bn254_pairing.hpp (which cite the reference
-// lines they replay), so raw Miller values and Gt results are bit-identical to the single-lane path and the oracle.
+// Formulas, digit schedule and line functions are the reference's (each routine cites the lines it replays), so raw Miller values
+// and Gt results are bit-identical to the oracle.
 #pragma once
 #include "bn254_tower.hpp"
 

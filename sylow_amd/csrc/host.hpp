@@ -28,7 +28,7 @@ struct Lease {
 // per-device line tables of the G2 generator (G2Affine::precompute of the constant, pairing.rs:676-708), built on first use
 int32_t gen_lines29(const bn254::i32** out, hipStream_t st);    // carry-free lane-pair line table (plk_common.hpp: LINE_TABLE_WORDS)
 int32_t g1_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G1 generator (g1.hip), built on first use
-int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use         // single-lane Montgomery layout [87][48] uint32
+int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 }  // namespace host
 

@@ -4,7 +4,7 @@
 
 namespace plk {
 // ------------------------------------------------------------------ glued pairing ----------------------------------------
-// Same wave-uniform schedule as the single-lane k_multi_pairing (single.hip): chunks of KMAX pairs share the squarings of
+// Wave-uniform schedule: chunks of KMAX pairs share the squarings of
 // one accumulator, a lane pair whose job has fewer pairs multiplies by the unit line.  Pair states live in the stack frame
 // (they are touched once per loop iteration); the accumulator and the working point stay in registers.
 struct PairStateW { G2W r; W2 qx, qy; S2 qxs, qys; F29 px, py; bool qinf, live; };

@@ -86,7 +86,7 @@ __global__ void HEAVY_BOUNDS k_w12_op(int op, const u64* a, const u64* b, u64* o
 }
 }  // namespace plk
 
-// Fp12 on the lane-pair layer for the public tower entry points (single.hip keeps the one-element-per-lane twins)
+// Fp12 on the lane-pair layer for the public tower entry points (tower.hip forwards them here)
 namespace plkh {
 int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
   plk::k_w12_op<<<GRID(2 * n)>>>(op, a, b, out, n); LAUNCHED();
