@@ -31,6 +31,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -61,13 +62,18 @@ HOST_ONLY_UNITS = ("pipeline.hip",)     # no device code: editing them does not 
 
 
 def csrc_hash():
-    """Hash of every kernel source: the committed PMC summary (profiles/pmc_current.json) is only valid for the build it was measured on."""
+    """Hash of the kernel sources with comments and blank space removed (a comment edit is not a new build): the committed PMC summary
+    (profiles/pmc_current.json) is only valid for the build it was measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sylow_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".hpp")) and name not in HOST_ONLY_UNITS:
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+            with open(os.path.join(d, name), "r", encoding="utf-8") as f:
+                text = f.read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+            text = " ".join(text.split())
+            h.update(name.encode() + b"\0" + text.encode())
     return h.hexdigest()[:16]
 
 
