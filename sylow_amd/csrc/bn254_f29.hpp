@@ -62,6 +62,32 @@ BN_DEV F29 f29_norm(const F29& a) {
   r.v[8] = a.v[8] + c;
   return r;
 }
+// norm(8 a) for an N-class a (low limbs in [0, 2^29)): 8 a_i + carry < 2^32, carried through unsigned
+BN_DEV F29 f29_norm_x8(const F29& a) {
+  F29 r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u32 t = ((u32)a.v[i] << 3) + c;
+    r.v[i] = (i32)(t & BN_M29);
+    c = t >> 29;
+  }
+  r.v[8] = a.v[8] * 8 + (i32)c;
+  return r;
+}
+// norm(a - 3 b) for |limbs| < 2^29: every a_i - 3 b_i + carry stays inside 32 bits
+BN_DEV F29 f29_norm_sub3(const F29& a, const F29& b) {
+  F29 r;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const i32 t = a.v[i] - 3 * b.v[i] + c;
+    r.v[i] = t & BN_M29;
+    c = t >> 29;
+  }
+  r.v[8] = a.v[8] - 3 * b.v[8] + c;
+  return r;
+}
 
 // ---- Montgomery product, R' = 2^261 ----------------------------------------------------------------------
 // ONE 64-bit accumulator is carried through all 17 columns: every partial product is a v_mad_i64_i32 whose addend is the running

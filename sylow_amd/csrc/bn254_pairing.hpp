@@ -112,6 +112,54 @@ BN_DEV Proj<typename O::F> proj_add(const Proj<typename O::F>& p, const Proj<typ
   z3 = O::add(z3, t0);
   return Proj<F>{x3, y3, z3};
 }
+// The same two formulas for the carry-free policies (OpsF29, OpsW2), linear layer trimmed.  Coordinates are N-class (limbs in [0, 2^29)), so a
+// difference of two of them is a legal product operand as it stands (|limbs| < 2^29): the three cross terms of the addition come from
+// (a_i - a_j)(b_i - b_j) = t_i + t_j - (a_i b_j + a_j b_i) with no carry pass on the operands, sums of products get ONE carry pass, and values that
+// only feed products stay un-normalised where the leaf's bound (|limbs| products summing under 2.5 * 2^58 per column) allows.  Same group element
+// as proj_add / proj_double limb for limb after the canonical reduction (tests/test_gpu_group.py, test_gpu_small_rows.py compare affine results).
+// Policy extras: lsub / ladd (no carry pass), norm, norm_x8 (8 a), norm_sub3 (a - 3 b), mul_b3_lazy (operand limbs up to 2^30 in magnitude).
+template <class O>
+BN_DEV Proj<typename O::F> proj_double_lazy(const Proj<typename O::F>& p) {
+  typedef typename O::F F;
+  F t0 = O::sqr(p.y);
+  F z3 = O::norm_x8(t0);
+  F t1 = O::mul(p.y, p.z);
+  F t2 = O::mul_b3(O::sqr(p.z));
+  F x3 = O::mul(t2, z3);
+  F y3 = O::norm(O::ladd(t0, t2));
+  z3 = O::mul(t1, z3);
+  t0 = O::norm_sub3(t0, t2);
+  y3 = O::mul(t0, y3);
+  y3 = O::norm(O::ladd(x3, y3));
+  t1 = O::mul(p.x, p.y);
+  x3 = O::mul(t0, t1);
+  x3 = O::norm(O::ladd(x3, x3));
+  bool z = O::is_zero(p.z);
+  Proj<F> r;
+  r.x = O::select(x3, O::zero(), z);
+  r.y = O::select(y3, O::one(), z);
+  r.z = O::select(z3, O::zero(), z);
+  return r;
+}
+template <class O>
+BN_DEV Proj<typename O::F> proj_add_lazy(const Proj<typename O::F>& p, const Proj<typename O::F>& q) {
+  typedef typename O::F F;
+  F t0 = O::mul(p.x, q.x);
+  F t1 = O::mul(p.y, q.y);
+  F t2 = O::mul(p.z, q.z);
+  F t3 = O::norm(O::lsub(O::ladd(t0, t1), O::mul(O::lsub(p.x, p.y), O::lsub(q.x, q.y))));      // x1 y2 + x2 y1
+  F t4 = O::norm(O::lsub(O::ladd(t1, t2), O::mul(O::lsub(p.y, p.z), O::lsub(q.y, q.z))));      // y1 z2 + y2 z1
+  F y3 = O::lsub(O::ladd(t0, t2), O::mul(O::lsub(p.x, p.z), O::lsub(q.x, q.z)));               // x1 z2 + x2 z1, limbs in (-2^29, 2^30)
+  t0 = O::norm(O::ladd(O::ladd(t0, t0), t0));
+  t2 = O::mul_b3(t2);
+  F z3 = O::norm(O::ladd(t1, t2));
+  t1 = O::lsub(t1, t2);                                                                        // product operand only
+  y3 = O::mul_b3_lazy(y3);
+  F x3 = O::norm(O::lsub(O::mul(t3, t1), O::mul(t4, y3)));
+  y3 = O::norm(O::ladd(O::mul(t1, z3), O::mul(y3, t0)));
+  z3 = O::norm(O::ladd(O::mul(z3, t4), O::mul(t0, t3)));
+  return Proj<F>{x3, y3, z3};
+}
 template <class O> BN_DEV Proj<typename O::F> proj_neg(const Proj<typename O::F>& p) {
   return Proj<typename O::F>{p.x, O::neg(p.y), p.z};
 }
@@ -236,6 +284,13 @@ struct OpsF29 {
     return r;
   }
   static BN_DEV F mul_b3(const F& a) { return f29_reduce_from([&](int i) { return (i64)a.v[i] * 9; }); }   // 3 b = 9
+  // the lazy linear layer of proj_add_lazy / proj_double_lazy
+  static BN_DEV F ladd(const F& a, const F& b) { return f29_add(a, b); }
+  static BN_DEV F lsub(const F& a, const F& b) { return f29_sub(a, b); }
+  static BN_DEV F norm(const F& a) { return f29_norm(a); }
+  static BN_DEV F norm_x8(const F& a) { return f29_norm_x8(a); }
+  static BN_DEV F norm_sub3(const F& a, const F& b) { return f29_norm_sub3(a, b); }
+  static BN_DEV F mul_b3_lazy(const F& a) { return mul_b3(a); }            // a reduce pass over 64-bit terms: any 32-bit limbs
 };
 typedef Proj<F29> G1W;
 BN_DEV F29 f29_from_fp_reduced(const Fp& a) {
@@ -409,8 +464,8 @@ BN_DEV G1P g1_scalar_mul_t(G1P p, const u32 (&k)[8], TAB& tab) {
   glv_digits(d2, m2);
   // beta 2^261 mod p
   const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};
-  auto dbl = [](const G1W& a) { return proj_double<OpsF29>(a); };
-  auto add = [](const G1W& a, const G1W& b) { return proj_add<OpsF29>(a, b); };
+  auto dbl = [](const G1W& a) { return proj_double_lazy<OpsF29>(a); };
+  auto add = [](const G1W& a, const G1W& b) { return proj_add_lazy<OpsF29>(a, b); };
   {
     G1W t1{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
     // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0): the complete formulas keep Z = 0 only

@@ -145,7 +145,7 @@ __global__ void HEAVY_BOUNDS k_g1_generator_mul(const u64* ks, const i32* __rest
     q1.x = OpsF29::select(OpsF29::zero(), ex, nz);
     q1.y = OpsF29::select(OpsF29::one(), OpsF29::select(ey, OpsF29::neg(ey), d < 0), nz);
     q1.z = OpsF29::select(OpsF29::zero(), OpsF29::one(), nz);
-    res = proj_add<OpsF29>(res, q1);
+    res = proj_add_lazy<OpsF29>(res, q1);
   }
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, G1P{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)});
@@ -181,7 +181,7 @@ __global__ void HEAVY_BOUNDS k_g1_sum_fold_affine(const u64* pxy, const uint8_t*
     q.x = OpsF29::select(f29_from_fp_reduced(load_fp(pxy, n, i, 0)), OpsF29::zero(), inf);
     q.y = OpsF29::select(f29_from_fp_reduced(load_fp(pxy, n, i, 4)), OpsF29::one(), inf);
     q.z = OpsF29::select(OpsF29::one(), OpsF29::zero(), inf);
-    res = proj_add<OpsF29>(res, q);
+    res = proj_add_lazy<OpsF29>(res, q);
   }
   g1w_store_proj(acc, acc_stride, t, res);
 }
@@ -191,7 +191,7 @@ __global__ void HEAVY_BOUNDS k_g1_sum_fold_proj(u64* acc, size_t stride, size_t 
   if (t >= L) return;
   G1W res = g1w_load_proj(acc, stride, t);
 #pragma unroll 1
-  for (size_t i = t + L; i < m; i += L) res = proj_add<OpsF29>(res, g1w_load_proj(acc, stride, i));
+  for (size_t i = t + L; i < m; i += L) res = proj_add_lazy<OpsF29>(res, g1w_load_proj(acc, stride, i));
   g1w_store_proj(acc, stride, t, res);
 }
 // the last levels (m <= 2 * BLOCK live elements) and the finish in ONE block: a level per barrier instead of a launch per level

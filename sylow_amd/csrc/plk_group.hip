@@ -25,17 +25,24 @@ struct OpsW2 {
     const F29 k1{{0x01e5cc12, 0x15bda508, 0x18588eb7, 0x00f3e938, 0x18f2b0b4, 0x03bffebe, 0x13752c37, 0x0ec49a37, 0x0017dd10}};
     return w2_mul_ilp(a, W2{sel9(lane_odd(), k0, k1)});
   }
+  // the lazy linear layer of proj_add_lazy / proj_double_lazy, each lane on its own coordinate
+  static BN_DEV F ladd(const F& a, const F& b) { return w2_add(a, b); }
+  static BN_DEV F lsub(const F& a, const F& b) { return w2_sub(a, b); }
+  static BN_DEV F norm(const F& a) { return w2_norm(a); }
+  static BN_DEV F norm_x8(const F& a) { return W2{f29_norm_x8(a.c)}; }
+  static BN_DEV F norm_sub3(const F& a, const F& b) { return W2{f29_norm_sub3(a.c, b.c)}; }
+  static BN_DEV F mul_b3_lazy(const F& a) { return mul_b3(w2_norm(a)); }   // a product leaf: its operand must be N-class
 };
 typedef Proj<W2> G2Q;
-BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double<OpsW2>(p); }
-BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add<OpsW2>(p, q); }
+BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double_lazy<OpsW2>(p); }
+BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add_lazy<OpsW2>(p, q); }
 // `region`: this lane's G1_TABLE_BYTES_PER_LANE bytes of a leased global block for the window table (NULL: the stack frame) -- a lane of
 // the pair holds its own coordinate of every entry, 27 words like a G1 point
 BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64, void* region = nullptr) {
   auto dbl = [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; };
   auto add = [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; };
-  auto dbl_loop = [](const G2Q& a) { return proj_double<OpsW2>(a); };
-  auto add_loop = [](const G2Q& a, const G2Q& b) { return proj_add<OpsW2>(a, b); };
+  auto dbl_loop = [](const G2Q& a) { return proj_double_lazy<OpsW2>(a); };
+  auto add_loop = [](const G2Q& a, const G2Q& b) { return proj_add_lazy<OpsW2>(a, b); };
   if (region) {
     ProjTableGlobal<G2Q> tab{(ProjTableGlobal<G2Q>::gptr)region};
     out = scalar_mul_window<OpsW2>(p, k, dbl, add, nwin, dbl_loop, add_loop, tab);
@@ -88,7 +95,7 @@ BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB&
   for (int w = 16; w >= 0; --w) {
     if (w != 16) {
 #pragma unroll 1
-      for (int j = 0; j < 4; ++j) res = proj_double<OpsW2>(res);      // inlined in the loop: no point travels through the stack frame
+      for (int j = 0; j < 4; ++j) res = proj_double_lazy<OpsW2>(res);      // inlined in the loop: no point travels through the stack frame
     }
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
@@ -105,7 +112,7 @@ BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB&
         if (i == 3) flip = !flip;
       }
       q.y = OpsW2::select(q.y, OpsW2::neg(q.y), flip);
-      res = proj_add<OpsW2>(res, q);
+      res = proj_add_lazy<OpsW2>(res, q);
     }
   }
   out = res;
@@ -215,7 +222,7 @@ __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __rest
     q2.x = OpsW2::select(OpsW2::zero(), ex, nz);
     q2.y = OpsW2::select(OpsW2::one(), OpsW2::select(ey, OpsW2::neg(ey), d < 0), nz);
     q2.z = OpsW2::select(OpsW2::zero(), OpsW2::one(), nz);
-    res = proj_add<OpsW2>(res, q2);          // inlined in the loop: no point travels through the stack frame
+    res = proj_add_lazy<OpsW2>(res, q2);          // inlined in the loop: no point travels through the stack frame
   }
   store_g2q_affine(oxy, oinf, n, i, odd, res);
 }
