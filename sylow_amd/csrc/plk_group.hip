@@ -138,9 +138,19 @@ BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-29
 }
 // g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
 BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q) {
-  const u32 bx[8] = {(u32)BN_BLS_X, (u32)(BN_BLS_X >> 32), 0, 0, 0, 0, 0, 0};
-  G2Q a;
-  g2q_scalar_mul(a, q, bx, 17);                   // x < 2^63: 16 digits + the recoding carry
+  // x Q by the width-3 NAF of the CONSTANT x = sum d_i 2^i, d_i in {0, +-1, +-3}, d_62 = 1: 62 doublings + 17 additions + (2Q, 3Q), every branch
+  // wave-uniform, no table in memory (the general window schedule: 68 doublings + 24 additions and a 9-entry table in the scratch frame)
+  constexpr u64 NZ = 0x4908924444891211ull, NEG = 0x108000400880210ull, THREE = 0x108804404880200ull;        // tests/test_wnaf_constants.py re-derives them from x
+  const G2Q q3 = proj_add_lazy<OpsW2>(proj_double_lazy<OpsW2>(q), q);
+  G2Q a = q;
+  for (int i = 61; i >= 0; --i) {
+    a = proj_double_lazy<OpsW2>(a);
+    if ((NZ >> i) & 1) {
+      G2Q t = ((THREE >> i) & 1) ? q3 : q;
+      if ((NEG >> i) & 1) t.y = OpsW2::neg(t.y);
+      a = proj_add_lazy<OpsW2>(a, t);
+    }
+  }
   // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
   const W2 e0 = w2_const(C_EPS_EXP0), e1 = w2_const(C_EPS_EXP1);
   auto psi = [&](G2Q& r, const G2Q& p) {
