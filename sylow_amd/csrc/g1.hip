@@ -267,21 +267,6 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, co
   store_fp(out, n, i, 0, fp_from_be48(em));
   store_fp(out, n, i, 4, fp_from_be48(em + 48));
 }
-// lib.rs:179-187
-__global__ void HEAVY_BOUNDS k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
-  size_t i = TID;
-  if (i >= n) return;
-  G1P h;
-  hash_to_g1(h, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
-  u32 k[8];
-  load_scalar(k, sk, n, i);
-  G1P s = tables ? g1_scalar_mul_ws(h, k, tables + i * G1_TABLE_BYTES_PER_LANE) : g1_scalar_mul(h, k);
-  Fp x, y; bool inf;
-  g1_to_affine(x, y, inf, s);
-  store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
-  oinf[i] = inf ? 1 : 0;
-}
-
 // ------------------------------------------------------------------ EVM alt_bn128 adapter -------
 // Byte-level batches of the three precompile shapes of examples/reth_bn128.rs:99-217 (EIP-196/197):
 // 32-byte big-endian field elements (Fp::from_be_bytes rejects >= p, fp.rs:686-719), (0,0) encodes the
@@ -490,17 +475,6 @@ int32_t sylow_hip_hash_to_field_batch(const uint8_t* msgs, const uint64_t* msg_o
   ARGCHK(msgs && msg_offsets && out_u); if (!n) return SYLOW_HIP_OK;
   DstPrime dp; host::dst_arg(dp, dst_host, dst_len);
   k_hash_to_field<<<GRID(n)>>>(msgs, msg_offsets, dp, out_u, n); LAUNCHED();
-}
-int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets,
-                                 uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
-  ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
-  DstPrime dp; host::dst_arg(dp, nullptr, 0);
-  host::Lease ws;
-  uint8_t* tables = g1_window_tables(ws, n, stream);
-  k_bls_sign<<<GRID(n)>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n, tables);
-  const hipError_t e = hipGetLastError();
-  const int32_t rc = ws.release();
-  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
   ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sylow_amd", "csrc")
-units = sys.argv[1:] or ["plk_pairing", "plk_multi", "plk_verify", "plk_group", "g1", "hash", "runtime"]
+units = sys.argv[1:] or ["plk_pairing", "plk_multi", "plk_verify", "plk_group", "g1", "hash", "sign", "tower", "runtime"]
 for u in units:
     r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
                         "-c", os.path.join(CSRC, u + ".hip"), "-o", "/dev/null"], capture_output=True, text=True)
