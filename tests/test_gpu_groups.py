@@ -144,6 +144,48 @@ def test_g2_subgroup_check(engine, coracle):
     assert engine.g2_subgroup_check(pts, inf)[0] == 0                     # identity passes (Z == 0 branch)
 
 
+def test_g2_small_order_twist_points(engine, coracle):
+    """The twist E'(Fp2) has order r * (2p - r) and 2p - r = 10069 * 5864401 * 1875725156269 * (a 177-bit prime): points of SMALL order exist, and on
+    them a double-and-add chain keeps meeting P + P, P + (-P) and the identity.  The reference's complete formulas (group.rs:528-599) take all of
+    that in their stride; so must the lazy-linear-layer forms and the constant-digit chain of the subgroup check.  S = [r * (2p - r) / 10069] T."""
+    h2 = 2 * P - R.R_ORDER
+    assert h2 % 10069 == 0
+    rng = Xoshiro(SEED + 29)
+    tw = []
+    while len(tw) < 6:
+        x = (rng.fp(), rng.fp())
+        y = fp2_sqrt(R.fp2_add(R.fp2_mul(R.fp2_square(x), x), R.TWIST_B))
+        if y is not None:
+            tw.append(list(x) + list(y))
+    t = pack([v for q in tw for v in q], 16)
+    n = t.shape[0]
+    s1, i1 = engine.g2_scalar_mul(t, limbs([h2 // 10069] * n))
+    s, si = engine.g2_scalar_mul(s1, limbs([R.R_ORDER] * n), i1)
+    e1 = coracle.g2_scalar_mul(g2_proj(t), limbs([h2 // 10069] * n))
+    e_xy, e_inf = coracle.g2_to_affine(coracle.g2_scalar_mul(e1, limbs([R.R_ORDER] * n)))
+    assert np.array_equal(si, e_inf) and np.array_equal(s, e_xy)
+    assert not si.all()                                                   # 6 random twist points: some have a component of order 10069
+    live = np.flatnonzero(si == 0)
+    sl = s[live]
+    st = engine.g2_subgroup_check(sl)
+    assert st.tolist() == [2] * len(live)                                 # on the twist, order 10069: not in G2
+    assert np.array_equal(st, coracle.g2_projective_new(g2_proj(sl)))
+    # [10069] S = identity, [10068] S = -S, [k] S for k around multiples of the order: the window walk runs inside a group of 10069 elements
+    ks = [10069, 10068, 10070, 2 * 10069, 16 * 10069 + 3, 10069 * 10069, (1 << 200) + 12345, 8, 15, 16, 17]
+    for k in ks:
+        got_xy, got_inf = engine.g2_scalar_mul(sl, limbs([k] * len(live)))
+        exp_xy, exp_inf = coracle.g2_to_affine(coracle.g2_scalar_mul(g2_proj(sl), limbs([k] * len(live))))
+        assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_xy, exp_xy), k
+        if k % 10069 == 0:
+            assert got_inf.all()
+    # S + S, S + (-S), S + 2S ... through the batch addition and doubling
+    d_xy, d_inf = engine.g2_double(sl)
+    a_xy, a_inf = engine.g2_add(sl, sl)
+    assert np.array_equal(d_xy, a_xy) and np.array_equal(d_inf, a_inf)
+    z_xy, z_inf = engine.g2_sub(sl, sl)
+    assert z_inf.all()
+
+
 def test_scalar_mul_group_properties_large(engine):
     """size-independent properties at 2^14: (a+b)P = aP + bP and a(bP) = (ab)P (groups/mod.rs:699-768)."""
     n = 1 << 14

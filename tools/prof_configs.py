@@ -21,6 +21,55 @@ REPS = 2
 MARK_BASE = 512            # marker m launches k_fp_unop over 512 * (m + 1) elements: grid 256 * (m + 1) threads
 
 
+def stable_download(d):
+    """Device -> host copy for SET-UP data that goes back to the device as input: repeated until two consecutive copies agree.  Inside a
+    `rocprofv3 --pmc` pass a hipMemcpyAsync + hipStreamSynchronize of a freshly written array returned, about once in 50 passes, a host array in
+    which the tail of one staging chunk (4 - 6 KB ending on a page boundary) was still zero -- the same device array copied again was right
+    (tools/dbg/c5_pmc_hunt2.sh reproduces it, 18 of 300 passes; never outside the profiler).  The job bytes built from such a copy held
+    identities where points should be, and the ecPairing check of this driver failed on inputs that were wrong before any measured kernel ran."""
+    a = d.download()
+    for _ in range(8):
+        b = d.download()
+        if np.array_equal(a, b):
+            return a
+        print("prof_configs: a device -> host copy of set-up data changed between two reads (profiler artefact, see stable_download)", flush=True)
+        a = b
+    raise RuntimeError("device -> host copy never stabilised")
+
+
+def _runs(idx):
+    idx = np.asarray(idx)
+    if idx.size == 0:
+        return []
+    cut = np.flatnonzero(np.diff(idx) != 1)
+    starts, ends = np.concatenate([[0], cut + 1]), np.concatenate([cut, [idx.size - 1]])
+    return [(int(idx[a]), int(idx[b])) for a, b in zip(starts, ends)]
+
+
+def diagnose_ecpairing(eng, k, nj, res, st, d_in, d_off, d_res, d_st, jobs, first_downloads):
+    """Everything observable about a wrong ecPairing batch (seen twice in counter passes): which jobs, whether the device copy
+    of the input still equals the host copy, whether repeating the call reproduces it."""
+    z, e = np.flatnonzero(res == 0), np.flatnonzero(st != 0)
+    print("ecPairing k=%d WRONG: %d zero results in runs %s; %d nonzero statuses in runs %s values %s" % (k, z.size, _runs(z)[:16], e.size, _runs(e)[:16], sorted(set(st[e].tolist()))), flush=True)
+    dev_in = d_in.download()
+    same = np.array_equal(dev_in, np.ascontiguousarray(jobs).reshape(-1))
+    print("   device input == host input: %s" % same, flush=True)
+    if not same:
+        rows = np.flatnonzero((dev_in.reshape(nj, -1) != np.ascontiguousarray(jobs).reshape(nj, -1)).any(axis=1))
+        print("   differing input rows: %d in runs %s" % (rows.size, _runs(rows)[:16]), flush=True)
+    # the job bytes were built on the host from three device arrays downloaded during set-up: download them again and compare
+    for name, (dev, first) in first_downloads.items():
+        again = dev.download().reshape(-1, first.shape[1])[:first.shape[0]]
+        d = np.flatnonzero((again != first).any(axis=1))
+        byte0 = int(np.flatnonzero((again != first).reshape(-1))[0]) if d.size else -1
+        print("   set-up download of %s: %d rows differ from a second download of the same device array, runs %s, first differing byte offset %d (row width %d)" % (name, d.size, _runs(d)[:8], byte0, first.shape[1]), flush=True)
+    for rep in range(4):
+        eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, k * nj, d_res.ptr, d_st.ptr)
+        eng.sync()
+        r2, s2 = d_res.download(), d_st.download()
+        print("   repeat %d: %d zero results in runs %s, %d nonzero statuses" % (rep, int((r2 == 0).sum()), _runs(np.flatnonzero(r2 == 0))[:8], int((s2 != 0).sum())), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--manifest", default=None)
@@ -38,7 +87,7 @@ def main():
 
     def config(name, units, fn, unit_name):
         if only and name not in only:
-            return
+            return False
         fn()                                   # warm: tables, workspace blocks
         eng.sync()
         marker()
@@ -47,14 +96,15 @@ def main():
         marker()
         eng.sync()
         manifest.append({"name": name, "units": units, "unit": unit_name, "reps": REPS, "marker_open": state["m"] - 2, "marker_close": state["m"] - 1})
+        return True
 
     n = 1 << 20
     p, q, ka, kb = make_points(eng, n, SEED + 3)
     gt = eng.empty((48, n))
     config("pairing_2^20", n, lambda: eng._call("sylow_hip_pairing_batch", p.ptr, None, q.ptr, None, gt.ptr, n), "pairing")
     n3 = 1 << 18
-    p3 = eng.empty((8, n3)).upload(np.ascontiguousarray(p.download()[:, :n3]))
-    q3 = eng.empty((16, n3)).upload(np.ascontiguousarray(q.download()[:, :n3]))
+    p3 = eng.empty((8, n3)).upload(np.ascontiguousarray(stable_download(p)[:, :n3]))
+    q3 = eng.empty((16, n3)).upload(np.ascontiguousarray(stable_download(q)[:, :n3]))
     config("C3_pairing_2^18", n3, lambda: eng._call("sylow_hip_pairing_batch", p3.ptr, None, q3.ptr, None, gt.ptr, n3), "pairing")
     del gt
     for log2n in (20, 24):
@@ -79,21 +129,23 @@ def main():
     npts = 2 * nj
     ny = eng.empty((4, n3))
     eng._call("sylow_hip_fp_neg_batch", p3.ptr + 4 * n3 * 8, ny.ptr, n3)
-    pneg = eng.empty((8, n3)).upload(np.concatenate([p3.download()[:4], ny.download()], axis=0))
+    pneg = eng.empty((8, n3)).upload(np.concatenate([stable_download(p3)[:4], stable_download(ny)], axis=0))
     b1, b1n, b2 = eng.empty((n3 * 64,), np.uint8), eng.empty((n3 * 64,), np.uint8), eng.empty((n3 * 128,), np.uint8)
     eng._call("sylow_hip_g1_to_be_bytes_batch", p3.ptr, None, b1.ptr, n3)
     eng._call("sylow_hip_g1_to_be_bytes_batch", pneg.ptr, None, b1n.ptr, n3)
     eng._call("sylow_hip_g2_to_be_bytes_batch", q3.ptr, None, b2.ptr, n3)
-    g1b, g1nb, g2b = (x.download().reshape(n3, -1)[:npts] for x in (b1, b1n, b2))
+    g1b, g1nb, g2b = (stable_download(x).reshape(n3, -1)[:npts] for x in (b1, b1n, b2))
     pos, neg = np.concatenate([g1b, g2b], axis=1), np.concatenate([g1nb, g2b], axis=1)
     for k in (2, 4):
         jobs = np.concatenate([pos[:nj], neg[:nj]], axis=1) if k == 2 else np.concatenate([pos[0:2 * nj:2], neg[0:2 * nj:2], pos[1:2 * nj:2], neg[1:2 * nj:2]], axis=1)
         d_in = eng.to_device(np.ascontiguousarray(jobs).reshape(-1))
         d_off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
         d_res, d_st = eng.empty((nj,), np.uint8), eng.empty((nj,), np.uint8)
-        config(f"C5_ecpairing_bytes_2^16_k{k}", nj, lambda: eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, k * nj, d_res.ptr, d_st.ptr), "job")
+        ran = config(f"C5_ecpairing_bytes_2^16_k{k}", nj, lambda: eng._call("sylow_hip_evm_ecpairing_batch", d_in.ptr, d_off.ptr, nj, k * nj, d_res.ptr, d_st.ptr), "job")
         r_, s_ = d_res.download(), d_st.download()
-        assert r_.all() and not s_.any(), ("ecPairing pattern broken", k, np.flatnonzero(r_ == 0)[:16].tolist(), np.flatnonzero(s_ != 0)[:16].tolist(), s_[s_ != 0][:16].tolist())
+        if ran and not (r_.all() and not s_.any()):
+            diagnose_ecpairing(eng, k, nj, r_, s_, d_in, d_off, d_res, d_st, jobs, {"g1 bytes": (b1, g1b), "-g1 bytes": (b1n, g1nb), "g2 bytes": (b2, g2b)})
+            raise AssertionError(("ecPairing pattern broken", k))
         off = eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k))
         gtj, iso = eng.empty((48, nj)), eng.empty((nj,), np.uint8)
         config(f"multi_pairing_2^16_k{k}", nj, lambda: eng._call("sylow_hip_multi_pairing_batch", p3.ptr, None, q3.ptr, None, off.ptr, nj, k * nj, 1, gtj.ptr, iso.ptr), "job")
@@ -114,21 +166,21 @@ def main():
     config("hash_to_g1_2^20", nv, lambda: eng._call("sylow_hip_hash_to_g1_batch", dm.ptr, doff.ptr, None, 0, hx.ptr, hi.ptr, nv), "hash")
     del hx, hi
     config("bls_sign_2^20", nv, lambda: eng._call("sylow_hip_bls_sign_batch", sk.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv), "signature")
-    config("bls_verify_2^20", nv, lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), "verify")
-    assert ok.download().all()
+    if config("bls_verify_2^20", nv, lambda: eng._call("sylow_hip_bls_verify_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), "verify"):
+        assert ok.download().all()
     config("bls_verify_two_pairings_2^20", nv, lambda: eng._call("sylow_hip_bls_verify_two_pairings_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), "verify")
     config("bls_verify_same_signer_shape_2^20", nv, lambda: eng._call("sylow_hip_bls_verify_same_signer_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, nv), "verify")
     gt1, is1 = eng.empty((48, 1)), eng.empty((1,), np.uint8)
-    config("aggregate_verify_2^20", nv, lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, None, gt1.ptr, is1.ptr), "signature")
-    assert int(is1.download()[0]) == 1
+    if config("aggregate_verify_2^20", nv, lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, None, gt1.ptr, is1.ptr), "signature"):
+        assert int(is1.download()[0]) == 1
     k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
     sk1, sk1one = eng.empty((4, nv)).upload(np.repeat(k1, nv, axis=1)), eng.empty((4, 1)).upload(k1)
     pk1, pk1i = eng.empty((16, 1)), eng.empty((1,), np.uint8)
     g2one = eng.empty((16, 1)).upload(limbs_row(G2).T.copy())
     eng._call("sylow_hip_bls_sign_batch", sk1.ptr, dm.ptr, doff.ptr, sig.ptr, sigi.ptr, nv)
     eng._call("sylow_hip_g2_scalar_mul_subgroup_batch", g2one.ptr, None, sk1one.ptr, pk1.ptr, pk1i.ptr, 1)
-    config("aggregate_same_signer_2^20", nv, lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk1.ptr, None, 1, dm.ptr, doff.ptr, sig.ptr, None, nv, None, gt1.ptr, is1.ptr), "signature")
-    assert int(is1.download()[0]) == 1
+    if config("aggregate_same_signer_2^20", nv, lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk1.ptr, None, 1, dm.ptr, doff.ptr, sig.ptr, None, nv, None, gt1.ptr, is1.ptr), "signature"):
+        assert int(is1.download()[0]) == 1
     eng.sync()
     if args.manifest:
         with open(args.manifest, "w") as f:
