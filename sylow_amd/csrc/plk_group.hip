@@ -36,18 +36,49 @@ struct OpsW2 {
 typedef Proj<W2> G2Q;
 BN_NOINLINE void g2q_double(G2Q& r, const G2Q& p) { r = proj_double_lazy<OpsW2>(p); }
 BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add_lazy<OpsW2>(p, q); }
+// ---- the isomorphic twist of the multi-step routines --------------------------------------------------------------------------
+// In the complete formulas every addition multiplies twice and every doubling once by 3 b', and b' = 3 / (9 + u) is a generic Fp2 element: a
+// full product leaf each time (13 % of the leaves of a scalar multiplication).  The map phi(x, y) = (s^2 x, s^3 y) with s in Fp,
+// s^6 = 82 / 3, is a group isomorphism from E': y^2 = x^3 + b' onto E'': y^2 = x^3 + b' s^6 = x^3 + (9 - u), where 3 b'' = 27 - 3 u and
+// the multiplication is ONE two-term reduce pass (27 own -+ 3 partner's coordinate: 60 instructions against 345).  Scalar multiplications, the
+// fixed-base table and the subgroup relation are computed on E'' -- phi on the way in (two Fp scalings), phi^-1 on the way out -- and are
+// the same group elements / the same boolean: phi commutes with the group law, and with psi because s is in Fp (conj s = s, so
+// phi psi phi^-1 = psi coordinate for coordinate).  Single additions and doublings stay on E' (OpsW2): the map would cost more than it saves.
+// tests/test_device_constants.py checks s^6 = 82 / 3 and the four scaling constants; parity of every routine is against the oracle on E'.
+struct OpsW2I : OpsW2 {
+  static BN_DEV F mul_b3(const F& a) {                                  // (a0 + a1 u)(27 - 3 u) = (27 a0 + 3 a1) + (27 a1 - 3 a0) u, R-class
+    const F29 ao = xchg9(a.c);
+    const F29* const t[2] = {&a.c, &ao};
+    const i32 c[2] = {bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)};
+    return W2{f29_reduce_terms(t, c)};
+  }
+  static BN_DEV F mul_b3_lazy(const F& a) { return mul_b3(a); }         // 64-bit terms: limbs up to 2^30 in magnitude need no carry pass first
+};
+BN_DEV G2Q g2q_to_iso(const G2Q& p) {                                   // (X : Y : Z) -> (s^2 X : s^3 Y : Z)
+  const F29 s2{{0x05beeef0, 0x1f76bf90, 0x1d5e46cf, 0x17f6764e, 0x1df385e5, 0x0d7a8334, 0x152215eb, 0x01b6eac1, -290196}};
+  const F29 s3{{0x1af1f8a3, 0x00cd9858, 0x1dce6a34, 0x142e620a, 0x1bc0c667, 0x0ae94d20, 0x0db9310b, 0x12572b72, 0x000405e6}};
+  return G2Q{w2_scale(p.x, s2), w2_scale(p.y, s3), p.z};
+}
+BN_DEV G2Q g2q_from_iso(const G2Q& p) {                                 // (X : Y : Z) -> (s^-2 X : s^-3 Y : Z)
+  const F29 s2i{{0x0a58afee, 0x062df742, 0x0d946d23, 0x0efd68f7, 0x04fb80f1, 0x185fd309, 0x1b649eb6, 0x008a56c1, -689288}};
+  const F29 s3i{{0x01ede983, 0x09ec02f0, 0x0d7df454, 0x15cd1e1c, 0x11f38b74, 0x1a89d98e, 0x1671744d, 0x0f15cb65, 0x0006a386}};
+  return G2Q{w2_scale(p.x, s2i), w2_scale(p.y, s3i), p.z};
+}
+BN_NOINLINE void g2qi_double(G2Q& r, const G2Q& p) { r = proj_double_lazy<OpsW2I>(p); }
+BN_NOINLINE void g2qi_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add_lazy<OpsW2I>(p, q); }
 // `region`: this lane's G1_TABLE_BYTES_PER_LANE bytes of a leased global block for the window table (NULL: the stack frame) -- a lane of
 // the pair holds its own coordinate of every entry, 27 words like a G1 point
+// points in and out on E'' (g2q_to_iso / g2q_from_iso at the callers)
 BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int nwin = 64, void* region = nullptr) {
-  auto dbl = [](const G2Q& a) { G2Q r; g2q_double(r, a); return r; };
-  auto add = [](const G2Q& a, const G2Q& b) { G2Q r; g2q_add(r, a, b); return r; };
-  auto dbl_loop = [](const G2Q& a) { return proj_double_lazy<OpsW2>(a); };
-  auto add_loop = [](const G2Q& a, const G2Q& b) { return proj_add_lazy<OpsW2>(a, b); };
+  auto dbl = [](const G2Q& a) { G2Q r; g2qi_double(r, a); return r; };
+  auto add = [](const G2Q& a, const G2Q& b) { G2Q r; g2qi_add(r, a, b); return r; };
+  auto dbl_loop = [](const G2Q& a) { return proj_double_lazy<OpsW2I>(a); };
+  auto add_loop = [](const G2Q& a, const G2Q& b) { return proj_add_lazy<OpsW2I>(a, b); };
   if (region) {
     ProjTableGlobal<G2Q> tab{(ProjTableGlobal<G2Q>::gptr)region};
-    out = scalar_mul_window<OpsW2>(p, k, dbl, add, nwin, dbl_loop, add_loop, tab);
+    out = scalar_mul_window<OpsW2I>(p, k, dbl, add, nwin, dbl_loop, add_loop, tab);
   } else {
-    out = scalar_mul_window<OpsW2>(p, k, dbl, add, nwin, dbl_loop, add_loop);
+    out = scalar_mul_window<OpsW2I>(p, k, dbl, add, nwin, dbl_loop, add_loop);
   }
 }
 // k * Q for Q in the r-torsion (G2 proper): the 4-dimensional GLS split of bn254_pairing.hpp (gls4_decompose) -- four 64-bit
@@ -56,6 +87,7 @@ BN_NOINLINE void g2q_scalar_mul(G2Q& out, const G2Q& p, const u32 (&k)[8], int n
 //   psi (X:Y:Z) = (e0 conj X : e1 conj Y : conj Z),  psi^2 = (beta X : -Y : Z) with beta in Fp,  psi^3 = (e3 conj X : -e1 conj Y : conj Z)
 // (conj is a field automorphism, so the maps act on projective coordinates; the minus signs fold into the digit's sign).
 // Only valid on the r-torsion: elsewhere psi is not multiplication by lam -- callers with arbitrary twist points use g2q_scalar_mul.
+// Points in and out on E'' (psi has the same coordinate form there).
 template <class TAB>
 BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB& tab) {
   u32 m[4][2];
@@ -73,13 +105,13 @@ BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB&
     t1.z = OpsW2::select(t1.z, OpsW2::zero(), pinf);
     tab.put(0, proj_zero<OpsW2>());
     tab.put(1, t1);
-    g2q_double(t2, t1); tab.put(2, t2);
-    g2q_add(t3, t2, t1); tab.put(3, t3);
-    g2q_double(t4, t2); tab.put(4, t4);
-    g2q_add(t, t4, t1); tab.put(5, t);
-    g2q_double(t, t3); tab.put(6, t);
-    g2q_add(t, t, t1); tab.put(7, t);
-    g2q_double(t, t4); tab.put(8, t);
+    g2qi_double(t2, t1); tab.put(2, t2);
+    g2qi_add(t3, t2, t1); tab.put(3, t3);
+    g2qi_double(t4, t2); tab.put(4, t4);
+    g2qi_add(t, t4, t1); tab.put(5, t);
+    g2qi_double(t, t3); tab.put(6, t);
+    g2qi_add(t, t, t1); tab.put(7, t);
+    g2qi_double(t, t4); tab.put(8, t);
   }
   // R-class lane-pair digits of the constants (value 2^261 mod p, balanced): e0 = xi^((p-1)/3), e1 = xi^((p-1)/2), e3 = e0 conj(e0 conj e0), beta = e0 conj e0
   const F29 e0a{{0x0c289449, 0x05f0a422, 0x0f85cd6c, 0x144ada8b, 0x053ef805, 0x01e2f615, 0x0b280ae6, 0x0c277edf, -774555}};
@@ -95,7 +127,7 @@ BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB&
   for (int w = 16; w >= 0; --w) {
     if (w != 16) {
 #pragma unroll 1
-      for (int j = 0; j < 4; ++j) res = proj_double_lazy<OpsW2>(res);      // inlined in the loop: no point travels through the stack frame
+      for (int j = 0; j < 4; ++j) res = proj_double_lazy<OpsW2I>(res);      // inlined in the loop: no point travels through the stack frame
     }
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
@@ -112,7 +144,7 @@ BN_DEV void g2q_scalar_mul_gls_t(G2Q& out, const G2Q& p, const u32 (&k)[8], TAB&
         if (i == 3) flip = !flip;
       }
       q.y = OpsW2::select(q.y, OpsW2::neg(q.y), flip);
-      res = proj_add_lazy<OpsW2>(res, q);
+      res = proj_add_lazy<OpsW2I>(res, q);
     }
   }
   out = res;
@@ -137,18 +169,19 @@ BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-29
   return s2_eq(s2_sub(s2_sqr(y), s2_mul(s2_sqr(x), x)), s2_const(C_TWIST_B));
 }
 // g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
-BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q) {
+BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q_in) {
+  const G2Q q = g2q_to_iso(q_in);                  // the relation is checked on E'': same boolean (phi is a group isomorphism commuting with psi)
   // x Q by the width-3 NAF of the CONSTANT x = sum d_i 2^i, d_i in {0, +-1, +-3}, d_62 = 1: 62 doublings + 17 additions + (2Q, 3Q), every branch
   // wave-uniform, no table in memory (the general window schedule: 68 doublings + 24 additions and a 9-entry table in the scratch frame)
   constexpr u64 NZ = 0x4908924444891211ull, NEG = 0x108000400880210ull, THREE = 0x108804404880200ull;        // tests/test_wnaf_constants.py re-derives them from x
-  const G2Q q3 = proj_add_lazy<OpsW2>(proj_double_lazy<OpsW2>(q), q);
+  const G2Q q3 = proj_add_lazy<OpsW2I>(proj_double_lazy<OpsW2I>(q), q);
   G2Q a = q;
   for (int i = 61; i >= 0; --i) {
-    a = proj_double_lazy<OpsW2>(a);
+    a = proj_double_lazy<OpsW2I>(a);
     if ((NZ >> i) & 1) {
       G2Q t = ((THREE >> i) & 1) ? q3 : q;
       if ((NEG >> i) & 1) t.y = OpsW2::neg(t.y);
-      a = proj_add_lazy<OpsW2>(a, t);
+      a = proj_add_lazy<OpsW2I>(a, t);
     }
   }
   // psi on projective coordinates: conj is a field automorphism, so psi(X:Y:Z) = (eps0 conj X : eps1 conj Y : conj Z)
@@ -160,21 +193,21 @@ BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q) {
   };
   G2Q b, c, l, r;
   psi(b, a);
-  g2q_add(a, a, q);
+  g2qi_add(a, a, q);
   psi(c, b);
-  g2q_add(l, c, b);
-  g2q_add(l, l, a);
+  g2qi_add(l, c, b);
+  g2qi_add(l, l, a);
   psi(r, c);
-  g2q_double(r, r);
+  g2qi_double(r, r);
   const G2Q nl = proj_neg<OpsW2>(l);
-  g2q_add(r, r, nl);
+  g2qi_add(r, r, nl);
   return OpsW2::is_zero(r.z);
 }
 BN_DEV bool g2q_in_subgroup(const S2& x, const S2& y) { return g2q_in_subgroup_proj(G2Q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()}); }
 BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
   return G2Q{w2_from_s2(load_s2(xy, n, i, 0, odd)), w2_from_s2(load_s2(xy, n, i, 8, odd)), (inf && inf[i]) ? OpsW2::zero() : OpsW2::one()};
 }
-BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {
+BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {      // r on E'
   S2 x, y; bool rinf;
   g2q_to_affine(x, y, rinf, r);
   store_s2(oxy, n, i, 0, odd, x); store_s2(oxy, n, i, 8, odd, y);
@@ -183,7 +216,7 @@ BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int od
 // ------------------------------------------------------------------ k * G2gen with a fixed-base table ---------------------------
 // KeyPair::generate's public half (lib.rs:131-137: G2Projective::generator() * secret_key) for a batch of keys.  The base never
 // changes, so k mod r is cut into 32 signed 8-bit digits and the product is 32 complete additions of table entries
-// T[w][j] = j 256^w G (j = 1..128, affine, R-class lane-pair digits) -- no doublings.  The table (32 x 128 x 36 words = 590 KB,
+// T[w][j] = j 256^w G (j = 1..128, affine ON THE ISOMORPHIC TWIST E'', R-class lane-pair digits) -- no doublings.  The table (32 x 128 x 36 words = 590 KB,
 // resident in L2 / MALL) is built once per device by 4096 lane pairs, each with the generic window product.
 constexpr int COMB_WIN = 32, COMB_ENT = 128;
 constexpr size_t COMB_WORDS = (size_t)COMB_WIN * COMB_ENT * 36;
@@ -195,11 +228,11 @@ __global__ void HEAVY_BOUNDS k_g2_comb_table(i32* table) {
   u32 k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < 8; ++q) if (q == (w >> 2)) k[q] = (u32)j << (8 * (w & 3));
-  const G2Q g{w2_from_s2(s2_g2gen_x()), w2_from_s2(s2_g2gen_y()), OpsW2::one()};
+  const G2Q g = g2q_to_iso(G2Q{w2_from_s2(s2_g2gen_x()), w2_from_s2(s2_g2gen_y()), OpsW2::one()});
   G2Q r;
   g2q_scalar_mul(r, g, k);
   S2 x, y; bool inf;
-  g2q_to_affine(x, y, inf, r);                      // never the identity: j 256^w < r
+  g2q_to_affine(x, y, inf, r);                      // never the identity: j 256^w < r.  The table holds affine points of E''
   const W2 wx = w2_from_s2(x), wy = w2_from_s2(y);
   i32* dst = table + e * 36;
 #pragma unroll
@@ -232,9 +265,9 @@ __global__ void HEAVY_BOUNDS k_g2_generator_mul(const u64* ks, const i32* __rest
     q2.x = OpsW2::select(OpsW2::zero(), ex, nz);
     q2.y = OpsW2::select(OpsW2::one(), OpsW2::select(ey, OpsW2::neg(ey), d < 0), nz);
     q2.z = OpsW2::select(OpsW2::zero(), OpsW2::one(), nz);
-    res = proj_add_lazy<OpsW2>(res, q2);          // inlined in the loop: no point travels through the stack frame
+    res = proj_add_lazy<OpsW2I>(res, q2);         // inlined in the loop: no point travels through the stack frame
   }
-  store_g2q_affine(oxy, oinf, n, i, odd, res);
+  store_g2q_affine(oxy, oinf, n, i, odd, g2q_from_iso(res));
 }
 
 // tables: NULL, or 2 n * G1_TABLE_BYTES_PER_LANE bytes (thread t's window table contiguous)
@@ -245,8 +278,8 @@ __global__ void HEAVY_BOUNDS k_g2_scalar_mul(const u64* pxy, const uint8_t* pinf
   u32 k[8];
   load_scalar(k, ks, n, i);
   G2Q r;
-  g2q_scalar_mul(r, load_g2q(pxy, pinf, n, i, odd), k, 64, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
-  store_g2q_affine(oxy, oinf, n, i, odd, r);
+  g2q_scalar_mul(r, g2q_to_iso(load_g2q(pxy, pinf, n, i, odd)), k, 64, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
+  store_g2q_affine(oxy, oinf, n, i, odd, g2q_from_iso(r));
 }
 // the same for inputs in the r-torsion (G2Projective values of the reference are: G2Projective::new checks, g2.rs:460-525)
 __global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
@@ -256,8 +289,8 @@ __global__ void HEAVY_BOUNDS k_g2_scalar_mul_gls(const u64* pxy, const uint8_t* 
   u32 k[8];
   load_scalar(k, ks, n, i);
   G2Q r;
-  g2q_scalar_mul_gls(r, load_g2q(pxy, pinf, n, i, odd), k, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
-  store_g2q_affine(oxy, oinf, n, i, odd, r);
+  g2q_scalar_mul_gls(r, g2q_to_iso(load_g2q(pxy, pinf, n, i, odd)), k, tables ? tables + t * G1_TABLE_BYTES_PER_LANE : nullptr);
+  store_g2q_affine(oxy, oinf, n, i, odd, g2q_from_iso(r));
 }
 __global__ void HEAVY_BOUNDS k_g2_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
   const size_t t = TID, i = pair_index(t);

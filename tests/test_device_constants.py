@@ -74,6 +74,13 @@ def test_lane_pair_constant_digits():
     b3 = (3 * R.TWIST_B[0] % P, 3 * R.TWIST_B[1] % P)
     mulb3 = grp[grp.index("static BN_DEV F mul_b3"):]
     assert lit(mulb3, "k0") == digits(b3[0]) and lit(mulb3, "k1") == digits(b3[1])
+    # the isomorphic twist of the multi-step G2 routines: s in Fp with s^6 = 82 / 3, so that b' s^6 = 9 - u and 3 b' s^6 = 27 - 3 u
+    s2, s3, s2i, s3i = (sum(w << (29 * i) for i, w in enumerate(lit(grp, nm))) * pow(2, -261, P) % P for nm in ("s2", "s3", "s2i", "s3i"))
+    assert s2 * s2i % P == 1 and s3 * s3i % P == 1 and pow(s2, 3, P) == pow(s3, 2, P)        # s2 = s^2, s3 = s^3 for one s
+    s6 = pow(s2, 3, P)
+    assert s6 * 3 % P == 82
+    assert R.fp2_mul(R.TWIST_B, (s6, 0)) == (9, P - 1)
+    assert "bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)" in grp
     p29 = open(os.path.join(CSRC, "bn254_pair29.hpp")).read()
     tw = p29[p29.index("BN_DEV W2 w2_twist_b()"):]
     assert lit(tw, "k0") == digits(R.TWIST_B[0]) and lit(tw, "k1") == digits(R.TWIST_B[1])
