@@ -422,13 +422,30 @@ BN_DEV W2 w2_twist_b() {
   return W2{sel9(lane_odd(), k0, k1)};
 }
 // pairing.rs:798-818.  Line coefficients: l0 R, l1 D, l2 N.
+// ---- the isomorphic pair of curves for kernels whose Miller value goes straight into the final exponentiation ---------------
+// phi(x, y) = (s^2 x, s^3 y) with s in Fp, s^6 = 82 / 3, maps E: y^2 = x^3 + 3 onto y^2 = x^3 + 82 and the twist E' onto
+// E'': y^2 = x^3 + (9 - u) (plk_group.hip uses the same map for the G2 group law).  Run on (phi P, phi Q) with b'' = 9 - u the doubling and
+// addition steps give phi of the same points up to projective factors in Fp, and every line is the original line times a factor in Fp:
+// X, Y, Z of the stepped point carry weights s^2, s^3, 1, all three line coefficients weight s^6 -- so the Miller value differs from the
+// reference's by an element of Fp*, which the final exponentiation kills (c^(p^6 - 1) = 1).  pairing() and every verdict are unchanged;
+// what it buys is the product b' * 3c of every doubling step (a full leaf, b' = 3 / (9 + u) is generic) becoming the two-term reduce pass
+// (27 - 3 u) c.  NOT used where the raw Miller value is the result (miller_loop_batch, glued_miller_loop_batch, the line tables).
+BN_DEV F29 f29_iso_s2() { return F29{{0x05beeef0, 0x1f76bf90, 0x1d5e46cf, 0x17f6764e, 0x1df385e5, 0x0d7a8334, 0x152215eb, 0x01b6eac1, -290196}}; }   // s^2 2^261 mod p, balanced
+BN_DEV F29 f29_iso_s3() { return F29{{0x1af1f8a3, 0x00cd9858, 0x1dce6a34, 0x142e620a, 0x1bc0c667, 0x0ae94d20, 0x0db9310b, 0x12572b72, 0x000405e6}}; }   // s^3
+BN_DEV W2 w2_mul_27m3u(const W2& a) {                                    // (a0 + a1 u)(27 - 3 u) = (27 a0 + 3 a1) + (27 a1 - 3 a0) u, R-class; any 32-bit limbs
+  const F29 ao = xchg9(a.c);
+  const F29* const t[2] = {&a.c, &ao};
+  const i32 c[2] = {bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)};
+  return W2{f29_reduce_terms(t, c)};
+}
+template <bool ISO = false>
 BN_DEV void g2_doubling_step29(G2W& r, W2& l0, W2& l1, W2& l2) {
   const W2 a = w2_halve(w2_mul(r.x, r.y));                              // N
   l2 = w2_norm(w2_triple(w2_sqr(r.x)));                                  // 3 X^2, N, |V| < 3.4
   const W2 b = w2_sqr(r.y);
   const W2 c = w2_sqr(r.z);
   const W2 h = w2_norm(w2_sub(w2_sqr(w2_norm(w2_add(r.y, r.z))), w2_add(b, c)));   // (Y+Z)^2 - (b+c), N, |V| < 3.4
-  const W2 e = w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));                   // b' * 3c, N
+  const W2 e = ISO ? w2_mul_27m3u(c) : w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));   // b' * 3c (E'': (9 - u) * 3c), N
   l1 = w2_neg(h);                                                        // D
   r.z = w2_mul(b, h);
   l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);                                 // xi (e - b), R
@@ -498,13 +515,22 @@ BN_DEV F29 lds_get9(i32 (*lds)[256], int slot) {
 }
 // PARK: also park the working point (63 words = 64.5 KB per block of 256 threads: two blocks per CU still fit the 160 KB).  Kernels
 // that stage line tables in LDS as well (plk_verify.hip) take PARK = false (36 words), or only one block per CU would be resident.
-template <bool PARK>
-BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys) {
+// ISO: the loop runs on (phi P, phi Q) with the twist constant 9 - u (see g2_doubling_step29): same pairing, not the reference's raw Miller value
+template <bool PARK, bool ISO = false>
+BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs_in, const S2& qys_in) {
   __shared__ i32 lds[PARK ? MILLER_LDS_WORDS_PARK : MILLER_LDS_WORDS][256];   // blocks of 256 threads (BLOCK); each thread touches only its own column
-  lds_put9(lds, 0, f29_reduce(f29_from_fp(pxs)));
-  lds_put9(lds, 1, f29_reduce(f29_from_fp(pys)));
+  S2 qxs = qxs_in, qys = qys_in;
   {
-    const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+    const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
+    lds_put9(lds, 0, ISO ? f29_mul(px, f29_iso_s2()) : px);
+    lds_put9(lds, 1, ISO ? f29_mul(py, f29_iso_s3()) : py);
+  }
+  {
+    W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+    if (ISO) {
+      qx = w2_scale(qx, f29_iso_s2()); qy = w2_scale(qy, f29_iso_s3());
+      qxs = w2_to_s2(qx); qys = w2_to_s2(qy);                                 // the two Frobenius images at the end start from phi Q
+    }
     lds_put9(lds, 2, qx.c);
     lds_put9(lds, 3, qy.c);
   }
@@ -520,7 +546,7 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
   static_assert((BN_ATE_NAF_NZ >> 63) & 1, "the first digit of 6x+2 after the leading one is non-zero");
   {   // i = 0: f = 1, so f^2 * l_dbl * l_add is the product of the two lines
-    g2_doubling_step29(r, l0, l1, l2);
+    g2_doubling_step29<ISO>(r, l0, l1, l2);
     const W2 d0 = l0, d4 = w2_scale(l1, PY()), d2 = w2_scale(l2, PX());
     g2_addition_step29(r, QX(), QY((ng >> 63) & 1), l0, l1, l2);
     park(r);
@@ -529,7 +555,7 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
 #pragma unroll 1
   for (int i = 1; i < 64; ++i) {
     r = unpark(r);
-    g2_doubling_step29(r, l0, l1, l2);
+    g2_doubling_step29<ISO>(r, l0, l1, l2);
     park(r);
     f = w12_sqr(f);
     f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));

@@ -46,19 +46,10 @@ BN_NOINLINE void g2q_add(G2Q& r, const G2Q& p, const G2Q& q) { r = proj_add_lazy
 // phi psi phi^-1 = psi coordinate for coordinate).  Single additions and doublings stay on E' (OpsW2): the map would cost more than it saves.
 // tests/test_device_constants.py checks s^6 = 82 / 3 and the four scaling constants; parity of every routine is against the oracle on E'.
 struct OpsW2I : OpsW2 {
-  static BN_DEV F mul_b3(const F& a) {                                  // (a0 + a1 u)(27 - 3 u) = (27 a0 + 3 a1) + (27 a1 - 3 a0) u, R-class
-    const F29 ao = xchg9(a.c);
-    const F29* const t[2] = {&a.c, &ao};
-    const i32 c[2] = {bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)};
-    return W2{f29_reduce_terms(t, c)};
-  }
+  static BN_DEV F mul_b3(const F& a) { return w2_mul_27m3u(a); }      // bn254_pair29.hpp: (27 a0 + 3 a1) + (27 a1 - 3 a0) u, R-class
   static BN_DEV F mul_b3_lazy(const F& a) { return mul_b3(a); }         // 64-bit terms: limbs up to 2^30 in magnitude need no carry pass first
 };
-BN_DEV G2Q g2q_to_iso(const G2Q& p) {                                   // (X : Y : Z) -> (s^2 X : s^3 Y : Z)
-  const F29 s2{{0x05beeef0, 0x1f76bf90, 0x1d5e46cf, 0x17f6764e, 0x1df385e5, 0x0d7a8334, 0x152215eb, 0x01b6eac1, -290196}};
-  const F29 s3{{0x1af1f8a3, 0x00cd9858, 0x1dce6a34, 0x142e620a, 0x1bc0c667, 0x0ae94d20, 0x0db9310b, 0x12572b72, 0x000405e6}};
-  return G2Q{w2_scale(p.x, s2), w2_scale(p.y, s3), p.z};
-}
+BN_DEV G2Q g2q_to_iso(const G2Q& p) { return G2Q{w2_scale(p.x, f29_iso_s2()), w2_scale(p.y, f29_iso_s3()), p.z}; }      // (X : Y : Z) -> (s^2 X : s^3 Y : Z)
 BN_DEV G2Q g2q_from_iso(const G2Q& p) {                                 // (X : Y : Z) -> (s^-2 X : s^-3 Y : Z)
   const F29 s2i{{0x0a58afee, 0x062df742, 0x0d946d23, 0x0efd68f7, 0x04fb80f1, 0x185fd309, 0x1b649eb6, 0x008a56c1, -689288}};
   const F29 s3i{{0x01ede983, 0x09ec02f0, 0x0d7df454, 0x15cd1e1c, 0x11f38b74, 0x1a89d98e, 0x1671744d, 0x0f15cb65, 0x0006a386}};

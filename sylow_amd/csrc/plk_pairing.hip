@@ -36,7 +36,7 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
     const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
     S12 f;
-    miller_loop29g<true>(f, px, py, qx, qy);
+    miller_loop29g<true, true>(f, px, py, qx, qy);          // on the isomorphic curves: the value differs from the reference's raw Miller value by a factor in Fp*, gone after the next line
     final_exponentiation29(g, f);
   }
   store_s12(gout, n, i, odd, g);

@@ -171,8 +171,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const F29 f29_zero{{0, 0, 0, 0, 0, 0, 0, 0, 0}};
   lds_put9(lds, 0, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 0))) : f29_zero);
   lds_put9(lds, 1, liveA ? f29_reduce(f29_from_fp(load_fp(sigxy, n, ii, 4))) : f29_zero);
-  lds_put9(lds, 2, liveB ? f29_reduce(f29_from_fp(hxs)) : f29_zero);
-  lds_put9(lds, 3, liveB ? f29_reduce(f29_from_fp(hys)) : f29_zero);
+  // Without a key table pair B runs on the isomorphic curves (bn254_pair29.hpp: g2_doubling_step29<ISO>): -H and the key go through phi, the
+  // pair's Miller value picks up a factor in Fp* that the final exponentiation kills, and every doubling step saves its twist-constant product
+  constexpr bool ISO = !PK_TABLE;
+  lds_put9(lds, 2, liveB ? (ISO ? f29_mul(f29_reduce(f29_from_fp(hxs)), f29_iso_s2()) : f29_reduce(f29_from_fp(hxs))) : f29_zero);
+  lds_put9(lds, 3, liveB ? (ISO ? f29_mul(f29_reduce(f29_from_fp(hys)), f29_iso_s3()) : f29_reduce(f29_from_fp(hys))) : f29_zero);
   auto SX = [&]() { return lds_get9(lds, 0); };
   auto SY = [&]() { return lds_get9(lds, 1); };
   auto HX = [&]() { return lds_get9(lds, 2); };
@@ -182,7 +185,8 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   auto key_y = [&]() { return (PK_TABLE || !liveB) ? s2_g2gen_y() : load_s2(pkxy, n, ii, 8, odd); };
   G2W r;
   {
-    const W2 qx = w2_from_s2(key_x()), qy = w2_from_s2(key_y());
+    W2 qx = w2_from_s2(key_x()), qy = w2_from_s2(key_y());
+    if (ISO) { qx = w2_scale(qx, f29_iso_s2()); qy = w2_scale(qy, f29_iso_s3()); }
     if (!PK_TABLE) { lds_put9(lds, 4, qx.c); lds_put9(lds, 5, qy.c); }
     r = G2W{qx, qy, w2_from_s2(s2_one())};
   }
@@ -215,7 +219,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   for (int it = 0; it < 64; ++it) {
     f = w12_sqr(f);
     lineA();
-    if (!PK_TABLE) g2_doubling_step29(r, l0, l1, l2);
+    if (!PK_TABLE) g2_doubling_step29<ISO>(r, l0, l1, l2);
     lineB();
     ++idx;
     if ((nz >> (63 - it)) & 1) {
@@ -226,7 +230,7 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
     }
   }
   S2 q1x, q1y, q2x, q2y;
-  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, key_x(), key_y()); g2_psi_affine(q2x, q2y, q1x, q1y); }   // the key is read again: 64 B instead of 16 live registers
+  if (!PK_TABLE) { g2_psi_affine(q1x, q1y, w2_to_s2(QX()), w2_to_s2(QY(false))); g2_psi_affine(q2x, q2y, q1x, q1y); }   // phi(key) from LDS: no live registers across the loop
   lineA();
   if (!PK_TABLE) g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
   lineB();

@@ -75,12 +75,19 @@ def test_lane_pair_constant_digits():
     mulb3 = grp[grp.index("static BN_DEV F mul_b3"):]
     assert lit(mulb3, "k0") == digits(b3[0]) and lit(mulb3, "k1") == digits(b3[1])
     # the isomorphic twist of the multi-step G2 routines: s in Fp with s^6 = 82 / 3, so that b' s^6 = 9 - u and 3 b' s^6 = 27 - 3 u
-    s2, s3, s2i, s3i = (sum(w << (29 * i) for i, w in enumerate(lit(grp, nm))) * pow(2, -261, P) % P for nm in ("s2", "s3", "s2i", "s3i"))
+    p29 = open(os.path.join(CSRC, "bn254_pair29.hpp")).read()
+
+    def fn_lit(text, name):
+        m = re.search(r"BN_DEV F29 %s\(\) \{ return F29\{\{([^}]*)\}\}; \}" % re.escape(name), text)
+        assert m, name
+        return [int(w.strip(), 0) for w in m.group(1).split(",")]
+
+    val = lambda d: sum(w << (29 * i) for i, w in enumerate(d)) * pow(2, -261, P) % P
+    s2, s3, s2i, s3i = val(fn_lit(p29, "f29_iso_s2")), val(fn_lit(p29, "f29_iso_s3")), val(lit(grp, "s2i")), val(lit(grp, "s3i"))
     assert s2 * s2i % P == 1 and s3 * s3i % P == 1 and pow(s2, 3, P) == pow(s3, 2, P)        # s2 = s^2, s3 = s^3 for one s
     s6 = pow(s2, 3, P)
     assert s6 * 3 % P == 82
     assert R.fp2_mul(R.TWIST_B, (s6, 0)) == (9, P - 1)
-    assert "bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)" in grp
-    p29 = open(os.path.join(CSRC, "bn254_pair29.hpp")).read()
+    assert "bn_keep(27), bn_keep_v(lane_odd() ? -3 : 3)" in p29
     tw = p29[p29.index("BN_DEV W2 w2_twist_b()"):]
     assert lit(tw, "k0") == digits(R.TWIST_B[0]) and lit(tw, "k1") == digits(R.TWIST_B[1])
