@@ -290,6 +290,7 @@ BN_DEV LineW line_get(PTR at, size_t stride) {
 // PHASE A: lane pair u = slot * jb + (job - job0) owns pair offsets[job] + slot.  A slot without a pair -- the job is shorter, or
 // skip_infinity drops the pair (EIP-197: an identity on either side contributes 1) -- writes 87 unit lines.  In replay mode a G2
 // identity walks through the formulas with Z = 0 exactly as in glued_miller_chunks.
+template <bool ISO>
 __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, const u64* offsets,
                                           size_t job0, size_t jb, size_t n_pairs, int kt, int skip_infinity, u32x4* table) {
   const size_t t = TID, u = pair_index(t);
@@ -309,9 +310,16 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
     for (int l = 0; l < LT_LINES; ++l) line_put(at + (size_t)l * line_step, stride, unit);
     return;
   }
-  const F29 px = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 0))), py = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 4)));
-  const S2 qxs = load_s2(qxy, n_pairs, idx, 0, odd), qys = load_s2(qxy, n_pairs, idx, 8, odd);
-  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+  // ISO (jobs that end in a final exponentiation): the pair is walked on the isomorphic curves (bn254_pair29.hpp, g2_doubling_step29) -- its
+  // lines are the reference's times factors in Fp*, which the final exponentiation kills; raw Miller values are built with ISO = false
+  F29 px = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 0))), py = f29_reduce(f29_from_fp(load_fp(pxy, n_pairs, idx, 4)));
+  S2 qxs = load_s2(qxy, n_pairs, idx, 0, odd), qys = load_s2(qxy, n_pairs, idx, 8, odd);
+  W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+  if (ISO) {
+    px = f29_mul(px, f29_iso_s2()); py = f29_mul(py, f29_iso_s3());
+    qx = w2_scale(qx, f29_iso_s2()); qy = w2_scale(qy, f29_iso_s3());
+    qxs = w2_to_s2(qx); qys = w2_to_s2(qy);
+  }
   // G2Projective::from(&G2Affine): Z = infinity ? 0 : 1 (group.rs:506-517); the glued loop never looks at the flag again
   G2W r{qx, qy, qi ? w_zero : w_one};
   W2 l0, l1, l2;
@@ -323,7 +331,7 @@ __global__ void HEAVY_BOUNDS k_pair_lines(const u64* pxy, const uint8_t* pinf, c
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
-    g2_doubling_step29(r, l0, l1, l2);
+    g2_doubling_step29<ISO>(r, l0, l1, l2);
     emit();
     if ((nz >> (63 - i)) & 1) {
       g2_addition_step29(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2);
@@ -804,7 +812,8 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   u64* raw = (u64*)((uint8_t*)ws.p + per_job * jb_max);
   for (size_t job0 = 0; job0 < n_jobs; job0 += jb_max) {
     const size_t jb = n_jobs - job0 < jb_max ? n_jobs - job0 : jb_max;
-    plk::k_pair_lines<<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
+    if (raw_miller) plk::k_pair_lines<false><<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
+    else plk::k_pair_lines<true><<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
     if (raw_miller) {
       plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, gt_out, n_jobs, job0);
     } else {
