@@ -210,3 +210,34 @@ def test_svdw_map_and_compute_naf_entry_points(engine, coracle):
         ep, em = R.compute_naf(k)
         assert sum(int(np_[i, j]) << (64 * j) for j in range(4)) == ep and sum(int(nm_[i, j]) << (64 * j) for j in range(4)) == em, hex(k)
         assert ep & em == 0 and (ep | em) & ((ep | em) << 1) & ((1 << 256) - 1) == 0 or k >= (1 << 255)      # non-adjacent form
+
+def test_large_batch_verify_kernels_agree(engine):
+    """Above the wide-route threshold bls_verify_batch is k_bls_verify_fused, whose key side runs on the isomorphic curves,
+    and the literal two-pairing form is k_bls_verify on the reference's curves: same booleans for valid and planted-invalid signatures,
+    identity flags on either side, and keys that are twist points OUTSIDE the r-torsion (phi is an isomorphism of the whole curve)."""
+    from test_gpu_groups import fp2_sqrt
+    rng = Xoshiro(SEED + 34)
+    n = 1500
+    sk = engine.xoshiro_fp_soa(SEED + 35, n).T.copy()
+    msgs = [bytes([(7 * i) & 255, i >> 8]) * (1 + i % 23) for i in range(n)]
+    sig_xy, _ = engine.bls_sign(sk, msgs)
+    pk_xy, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    wild = []
+    while len(wild) < 40:
+        x = (rng.fp(), rng.fp())
+        y = fp2_sqrt(R.fp2_add(R.fp2_mul(R.fp2_square(x), x), R.TWIST_B))
+        if y is not None:
+            wild.append(list(x) + list(y))
+    pk_xy[100:140] = pack([v for q in wild for v in q], 16)
+    g = np.random.default_rng(12)
+    plant = g.random(n) < 0.15
+    mixed = np.where(plant[:, None], np.roll(sig_xy, 3, axis=0), sig_xy)
+    pinf, sinf = (g.random(n) < 0.05).astype(np.uint8), (g.random(n) < 0.05).astype(np.uint8)
+    for flags in ((None, None), (pinf, sinf)):
+        a = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=flags[0], sig_inf=flags[1], pipelined=False)
+        b = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=flags[0], sig_inf=flags[1], two_pairings=True, pipelined=False)
+        assert np.array_equal(a, b)
+    a = engine.bls_verify(pk_xy, msgs, mixed, pipelined=False).astype(bool)
+    expect = ~plant
+    expect[100:140] = False
+    assert np.array_equal(a, expect)

@@ -47,6 +47,23 @@ def test_miller_and_final_exp_vs_oracle(engine, coracle):
     assert np.array_equal(engine.pairing(p_xy, q_xy), gt)
 
 
+def test_large_batch_kernel_equals_raw_miller_then_final_exp(engine, coracle):
+    """Above the wide-route threshold pairing() is ONE kernel (k_pairing) whose Miller loop runs on the isomorphic curves y^2 = x^3 + 82 /
+    y^2 = x^3 + (9 - u): its Miller value differs from the reference's raw value by a factor in Fp*, its OUTPUT must not.
+    The raw entry point keeps the reference's value bit for bit (oracle), and final_exp of it is the same Gt as the one-kernel route."""
+    rng = Xoshiro(SEED + 33)
+    n = 2600
+    _, _, p_xy, q_xy = random_points(engine, rng, n)
+    raw = engine.miller_loop(p_xy, q_xy)
+    idx = np.arange(0, n, 217)
+    assert np.array_equal(raw[idx], coracle.miller_loop(p_xy[idx], q_xy[idx]))
+    gt = engine.pairing(p_xy, q_xy, pipelined=False)
+    assert np.array_equal(gt, engine.final_exp(raw))
+    assert np.array_equal(gt[idx], coracle.final_exponentiation(raw[idx]))
+    # the same rows through the one-wavefront-per-pairing route (reference curves) agree with the big kernel
+    assert np.array_equal(engine.pairing(p_xy[idx], q_xy[idx], pipelined=False), gt[idx])
+
+
 def test_pairing_identities(engine):
     """pairing.rs:1101-1120: infinity on either side -> identity; e(-P,Q) = e(P,-Q) = e(P,Q)^-1"""
     one = np.zeros((1, 48), dtype=np.uint64)
