@@ -267,8 +267,10 @@ int32_t sylow_hip_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n
 int32_t sylow_hip_glued_miller_loop_precomputed_batch(const uint64_t* coeffs, size_t n_tables, const uint64_t* table_idx, const uint64_t* p_xy,
                                                       const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs, uint64_t* f_out, void* stream);
 /* The two halves of pairing_product_batch, for hosts that split one product over several GPUs:
- * partial: f_out [48][1] = prod_i miller(P_i, Q_i) of this shard, the raw MillerLoopResult (no final exponentiation;
- *          n_pairs = 0 gives 1);
+ * partial: f_out [48][1] = c * prod_i miller(P_i, Q_i) of this shard (no final exponentiation; n_pairs = 0 gives 1) with some c in Fp* that
+ *          depends on the route taken -- an intermediate for _final_ only, where c disappears (c^(p^6 - 1) = 1): the Miller loops of a value
+ *          that ends in a final exponentiation may run on isomorphic curves.  The reference's raw MillerLoopResult
+ *          itself comes from sylow_hip_miller_loop_batch / sylow_hip_glued_miller_loop_batch;
  * final:   gt_out [48][1] = final_exponentiation(prod_{j<k} parts_j), parts SoA [48][k]; is_one[0] = (== Gt::identity()).
  * glued_pairing over all shards == fp12_product_final_exp over the shards' partials (Fp12 products commute). */
 int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf,
@@ -377,8 +379,8 @@ int32_t sylow_hip_pairing_product_all(const uint64_t* p_xy, const uint8_t* p_inf
  * message; n_pk = 1: pk_xy [16][1].  Identity signatures / keys contribute 1 (pairing() semantics).  n = 0 gives the identity.
  * (As in the reference's example there are no random weights: it answers "is the PRODUCT the identity" -- the product sees the
  * signatures only through their sum, so signatures permuted among the messages still pass; per-element flags: bls_verify_batch.)
- *   _partial_: f_out [48][1] = this shard's raw Miller product (for hosts that combine shards themselves,
- *              with sylow_hip_fp12_product_final_exp);
+ *   _partial_: f_out [48][1] = this shard's Miller product up to a factor in Fp* (see sylow_hip_pairing_product_partial_batch; for hosts
+ *              that combine shards themselves, with sylow_hip_fp12_product_final_exp);
  *   _verify_:  the whole check; comm = the host's ncclComm_t for a batch sharded over the GPUs of a node (every rank passes its
  *              shard and receives the same answer; 384 bytes per rank are all-gathered), NULL = this process alone. */
 int32_t sylow_hip_bls_aggregate_partial_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,

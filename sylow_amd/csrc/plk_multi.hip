@@ -785,7 +785,9 @@ static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinit
 static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                   size_t n_jobs, size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream);
 static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
-                                    size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, void* stream) {
+                                    size_t n_jobs, size_t n_pairs, int32_t skip_infinity, uint64_t* gt_out, uint8_t* is_one, int raw_miller, int iso, void* stream) {
+  // iso: the line tables may be built on the isomorphic curves (k_pair_lines<true>) -- whenever the value ends in a final exponentiation, here or
+  // in the caller; 0 only where the reference's raw Miller value itself is the result (glued_miller_loop_batch)
   hipStream_t st = (hipStream_t)stream;
   size_t kt = (n_pairs + n_jobs - 1) / n_jobs;                 // slots per job: the batch average, rounded up; longer jobs take the in-register tail
   if (kt < 1) kt = 1;
@@ -812,7 +814,7 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   u64* raw = (u64*)((uint8_t*)ws.p + per_job * jb_max);
   for (size_t job0 = 0; job0 < n_jobs; job0 += jb_max) {
     const size_t jb = n_jobs - job0 < jb_max ? n_jobs - job0 : jb_max;
-    if (raw_miller) plk::k_pair_lines<false><<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
+    if (!iso) plk::k_pair_lines<false><<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
     else plk::k_pair_lines<true><<<GRID(2 * kt * jb)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, table);
     if (raw_miller) {
       plk::k_glued_from_tables<<<GRID(2 * jb)>>>(table, p_xy, p_inf, q_xy, q_inf, pair_offsets, job0, jb, n_pairs, (int)kt, skip_infinity, gt_out, n_jobs, job0);
@@ -832,7 +834,7 @@ int32_t sylow_hip_multi_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf
                                       uint64_t* gt_out, uint8_t* is_one, void* stream) {
   ARGCHK(pair_offsets && (gt_out || is_one) && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
   if (single_job_route(n_jobs, n_pairs, skip_infinity)) return single_job_product(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, gt_out, is_one, stream);
-  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, stream);
+  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0, /*iso=*/1, stream);
   // chunks of KMAX pairs share the squarings; any KMAX is correct for any job size.  Batches that average at most two pairs per
   // job (the BLS / ecPairing k = 2 shape) take the two-slot instantiation: its pair states are a third of the stack frame
   if (n_pairs <= 2 * n_jobs) { plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, pair_offsets, n_jobs, n_pairs, skip_infinity, gt_out, is_one, 0); LAUNCHED(); }
@@ -845,7 +847,7 @@ int32_t sylow_hip_g2_precompute_batch(const uint64_t* q_xy, uint64_t* coeffs, si
 int32_t sylow_hip_glued_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, const uint64_t* pair_offsets, size_t n_jobs, size_t n_pairs,
                                            uint64_t* f_out, void* stream) {
   ARGCHK(pair_offsets && f_out && (n_pairs == 0 || (p_xy && q_xy))); if (!n_jobs) return SYLOW_HIP_OK;
-  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1, stream);
+  if (use_tables(n_jobs, n_pairs)) return multi_pairing_tables(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1, /*iso=*/0, stream);
   plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, nullptr, q_xy, nullptr, pair_offsets, n_jobs, n_pairs, 0, f_out, nullptr, 1); LAUNCHED();
 }
 
@@ -885,7 +887,7 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk, range);
   // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
   if (chunk >= 2 && multi_tables_mode() != 0) {
-    rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, stream);
+    rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, /*iso=*/1, stream);
     if (rc != SYLOW_HIP_OK) return rc;
   }
   else if (chunk <= 2) plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
@@ -1132,7 +1134,7 @@ int32_t sylow_hip_evm_ecpairing_batch(const uint8_t* in, const uint64_t* pair_of
   if (n_pairs) rc = plkh::evm_decode_pairs(in, n_pairs, pxy, pinf, qxy, qinf, pst, stream);
   if (rc == SYLOW_HIP_OK) {
     if (single_job_route(n_jobs, n_pairs, 1)) rc = single_job_product(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, nullptr, isone, stream);
-    else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, stream);
+    else if (use_tables(n_jobs, n_pairs)) rc = multi_pairing_tables(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0, /*iso=*/1, stream);
     else if (n_pairs <= 2 * n_jobs) plk::k_multi_pairing<2><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
     else plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(pxy, pinf, qxy, qinf, pair_offsets, n_jobs, n_pairs, /*skip_infinity=*/1, nullptr, isone, 0);
   }

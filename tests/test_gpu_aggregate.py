@@ -37,7 +37,7 @@ def test_sharded_product_equals_glued_pairing(engine, coracle, pairs):
         parts = np.concatenate([engine.pairing_product_partial(p[a:b], q[a:b]) for a, b in zip(cuts, cuts[1:])], axis=0)
         gt, one = engine.fp12_product_final_exp(parts)
         assert np.array_equal(gt, exp) and not one, shards
-    # the partial IS the raw glued Miller value of the shard (product of the per-pair Miller values)
+    # the partial is the glued Miller value of the shard up to a factor in Fp* (isomorphic curves): its final exponentiation is the glued pairing
     part = engine.pairing_product_partial(p[:9], q[:9])
     assert np.array_equal(engine.final_exp(part), coracle.glued_pairing(proj1(p[:9]), proj2(q[:9]), np.array([0, 9], dtype=np.uint64)))
     # empty product and k = 0
