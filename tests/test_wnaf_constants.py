@@ -20,3 +20,24 @@ def test_masks_encode_x():
             total += (-d if (neg >> i) & 1 else d) << i
     assert total == X
     assert bin(nz).count("1") == 18                   # the top digit + the 17 additions the kernel comment quotes
+
+
+def test_expx_chain_masks_encode_x():
+    """exp_by_neg_z29 (bn254_pair29.hpp): f^x by a signed-digit chain over {f^17, f^35} -- the three masks and the top digit 35 at bit 57
+    reproduce the BN parameter, with 11 products in the loop."""
+    src = open(os.path.join(os.path.dirname(__file__), "..", "sylow_amd", "csrc", "bn254_pair29.hpp")).read()
+    vals = {}
+    for name in ("BN_X_C_NZ", "BN_X_C_NEG", "BN_X_C_17"):
+        m = re.search(r"#define %s (0x[0-9a-f]+)ull" % name, src)
+        assert m, name
+        vals[name] = int(m.group(1), 16)
+    nz, neg, is17 = vals["BN_X_C_NZ"], vals["BN_X_C_NEG"], vals["BN_X_C_17"]
+    assert neg & ~nz == 0 and is17 & ~nz == 0 and nz >> 57 == 0
+    total = 35 << 57
+    for i in range(57):
+        if (nz >> i) & 1:
+            d = 17 if (is17 >> i) & 1 else 35
+            total += (-d if (neg >> i) & 1 else d) << i
+    assert total == X
+    assert bin(nz).count("1") == 11
+    assert "for (int i = 56; i >= 0; --i)" in src and "W12 res = tab[1];" in src
