@@ -162,15 +162,25 @@ BN_DEV bool g2q_on_curve_affine(const S2& x, const S2& y) {      // g2.rs:279-29
 // g2.rs:488-513: (x+1)Q + psi(xQ) + psi^2(xQ) == psi^3(2xQ) for Q on the twist, affine
 BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q_in) {
   const G2Q q = g2q_to_iso(q_in);                  // the relation is checked on E'': same boolean (phi is a group isomorphism commuting with psi)
-  // x Q by the width-3 NAF of the CONSTANT x = sum d_i 2^i, d_i in {0, +-1, +-3}, d_62 = 1: 62 doublings + 17 additions + (2Q, 3Q), every branch
-  // wave-uniform, no table in memory (the general window schedule: 68 doublings + 24 additions and a 9-entry table in the scratch frame)
-  constexpr u64 NZ = 0x4908924444891211ull, NEG = 0x108000400880210ull, THREE = 0x108804404880200ull;        // tests/test_wnaf_constants.py re-derives them from x
-  const G2Q q3 = proj_add_lazy<OpsW2I>(proj_double_lazy<OpsW2I>(q), q);
-  G2Q a = q;
-  for (int i = 61; i >= 0; --i) {
+  // x Q by the signed-digit chain of the CONSTANT x over the table {17 Q, 35 Q} (the chain of exp_by_neg_z29, bn254_pair29.hpp: the same three
+  // masks, tests/test_wnaf_constants.py): 62 doublings + 13 additions in all, every branch wave-uniform, no table in memory.  (The width-3 NAF
+  // of the first half of the round: 63 + 18; the general window schedule: 68 + 24 and a nine-entry table in the scratch frame.)
+  G2Q q17, q35;
+  {
+    G2Q t = proj_double_lazy<OpsW2I>(q);
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) t = proj_double_lazy<OpsW2I>(t);            // 16 Q
+    q17 = proj_add_lazy<OpsW2I>(t, q);
+    t = proj_double_lazy<OpsW2I>(q17);
+    q35 = proj_add_lazy<OpsW2I>(t, q);
+  }
+  G2Q a = q35;                                                               // top digit (bit 57) is +35
+  constexpr u64 NZ = BN_X_C_NZ, NEG = BN_X_C_NEG, IS17 = BN_X_C_17;
+#pragma unroll 1
+  for (int i = 56; i >= 0; --i) {
     a = proj_double_lazy<OpsW2I>(a);
     if ((NZ >> i) & 1) {
-      G2Q t = ((THREE >> i) & 1) ? q3 : q;
+      G2Q t = ((IS17 >> i) & 1) ? q17 : q35;
       if ((NEG >> i) & 1) t.y = OpsW2::neg(t.y);
       a = proj_add_lazy<OpsW2I>(a, t);
     }

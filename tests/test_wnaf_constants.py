@@ -1,25 +1,9 @@
-"""The digit masks of the subgroup check's constant-scalar schedule (plk_group.hip: g2q_in_subgroup_proj) encode the width-3 NAF of the BN
-parameter x (g2.rs:488-513 multiplies by the same x): sum d_i 2^i == x, digits in {0, +-1, +-3}, top digit +1 at bit 62."""
+"""The digit masks of the constant-exponent chain shared by f^x (bn254_pair29.hpp: exp_by_neg_z29) and x Q (plk_group.hip:
+g2q_in_subgroup_proj; g2.rs:488-513 multiplies by the same x): sum d_i 2^i == x with digits in {0, +-17, +-35}, top digit +35 at bit 57."""
 import os
 import re
 
 X = 4965661367192848881
-
-
-def test_masks_encode_x():
-    src = open(os.path.join(os.path.dirname(__file__), "..", "sylow_amd", "csrc", "plk_group.hip")).read()
-    m = re.search(r"constexpr u64 NZ = (0x[0-9a-f]+)ull, NEG = (0x[0-9a-f]+)ull, THREE = (0x[0-9a-f]+)ull;", src)
-    assert m, "digit masks not found"
-    nz, neg, three = (int(g, 16) for g in m.groups())
-    assert neg & ~nz == 0 and three & ~nz == 0
-    total = 1 << 62                                   # the loop starts from a = Q: the top digit
-    assert nz >> 62 == 1 and not (neg >> 62) and not (three >> 62)
-    for i in range(62):
-        if (nz >> i) & 1:
-            d = 3 if (three >> i) & 1 else 1
-            total += (-d if (neg >> i) & 1 else d) << i
-    assert total == X
-    assert bin(nz).count("1") == 18                   # the top digit + the 17 additions the kernel comment quotes
 
 
 def test_expx_chain_masks_encode_x():
@@ -41,3 +25,5 @@ def test_expx_chain_masks_encode_x():
     assert total == X
     assert bin(nz).count("1") == 11
     assert "for (int i = 56; i >= 0; --i)" in src and "W12 res = tab[1];" in src
+    grp = open(os.path.join(os.path.dirname(__file__), "..", "sylow_amd", "csrc", "plk_group.hip")).read()
+    assert "constexpr u64 NZ = BN_X_C_NZ, NEG = BN_X_C_NEG, IS17 = BN_X_C_17;" in grp and "G2Q a = q35;" in grp

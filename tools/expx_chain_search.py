@@ -4,35 +4,31 @@ free.  Family searched: signed sliding windows over a table of odd powers T (1 i
 entries).  Prints the best (multiplications, squarings) per table size.   python3 tools/expx_chain_search.py"""
 import itertools, sys
 X = 4965661367192848881
-S_COST, M_COST = 6, 18
+S_COST, M_COST = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (6, 18)      # group law on lane pairs: 7.5 12.4
 
 def recode(x, T):
-    """min #nonzero signed digits d_i in +-T with sum d_i 2^i = x; returns (count, digits LSB first)"""
-    from functools import lru_cache
+    """min #nonzero signed digits d_i in +-T with sum d_i 2^i = x: exact search over the remaining value v -> (v - d) / 2 (memoised; a value
+    being expanded counts as unreachable, which only removes cycles).  Returns (count, digits LSB first)."""
+    sys.setrecursionlimit(100000)
     Tset = sorted(T)
-    sys.setrecursionlimit(10000)
-    best = {}
+    INF = (10 ** 9, None)
+    memo = {}
     def go(v):
-        # v: remaining value (can be negative), returns (count, list)
         if v == 0: return (0, [])
-        if v in best: return best[v]
+        if v in memo: return memo[v]
+        memo[v] = INF                                   # in progress
         if v % 2 == 0:
             c, d = go(v // 2)
-            r = (c, [0] + d)
+            r = (c, [0] + d) if d is not None else INF
         else:
-            r = None
+            r = INF
             for t in Tset:
-                for sgn in (1, -1):
-                    d0 = sgn * t
+                for d0 in (t, -t):
                     w = v - d0
-                    if w % 2: continue
-                    if abs(w) >= abs(v) * 2 and abs(v) > 64: continue
-                    if abs(w // 2) > abs(v) and abs(v) > 2 * max(Tset): continue
-                    if abs(v) <= max(Tset) and w != 0 and abs(w//2) >= abs(v): continue
+                    if abs(w) > 2 * abs(v) + 2: continue          # never useful: the value would grow
                     c, d = go(w // 2)
-                    if r is None or c + 1 < r[0]:
-                        r = (c + 1, [d0] + d)
-        best[v] = r
+                    if d is not None and c + 1 < r[0]: r = (c + 1, [d0] + d)
+        memo[v] = r
         return r
     return go(x)
 
@@ -68,12 +64,15 @@ def build_cost(T):
     return (99, 99, [])
 
 def main():
-    odds = list(range(3, 64, 2))
+    top_odd = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    max_size = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    odds = list(range(3, top_odd, 2))
     results = []
-    for size in range(0, 4):
+    for size in range(0, max_size + 1):
         for extra in itertools.combinations(odds, size):
             T = (1,) + extra
             cnt, digs = recode(X, T)
+            if digs is None: continue
             top = len(digs) - 1
             while digs[top] == 0: top -= 1
             # chain: start from digs[top] (a table entry), then `top` squarings, one mul per further nonzero digit
@@ -82,13 +81,13 @@ def main():
             results.append((muls, sq, T, digs))
     out = []
     for muls, sq, T, digs in results:
-        if muls > 14: continue
+        if muls > 17: continue
         bm, bs, path = build_cost(T)
         out.append((muls + bm, sq + bs, T, path, digs))
     out.sort(key=lambda r: r[0] * M_COST + r[1] * S_COST)
     for r in out[:12]:
-        print("M=%d S=%d cost=%d  T=%s  build=%s" % (r[0], r[1], r[0] * M_COST + r[1] * S_COST, r[2], r[3]))
+        print("M=%d S=%d cost=%.1f  T=%s  build=%s" % (r[0], r[1], r[0] * M_COST + r[1] * S_COST, r[2], r[3]))
         print("   digits MSB first:", [d for d in r[4][::-1]])
-    print("current: width-4 signed windows: M=16 S=63 cost=%d" % (16 * M_COST + 63 * S_COST))
+    print("rounds 1-3: width-4 signed windows: M=16 S=63 cost=%.1f" % (16 * M_COST + 63 * S_COST))
 
 main()
