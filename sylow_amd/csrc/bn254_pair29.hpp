@@ -891,6 +891,7 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
 // g2_doubling_step29 with its ten products in three levels: five on five lane pairs (x y, x^2, y^2, z^2, (y + z)^2), the twist-constant
 // product replicated (one product: nothing to spread), four on four lane pairs (b h, a (b - f), g^2, e^2).  Inputs and outputs replicated;
 // the squares are taken with the product leaf (same values).  Products of level 1 meet in the P slots, those of level 3 in the T slots.
+template <bool ISO = false>
 BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   {
@@ -907,7 +908,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
   const W2 a = w2_halve(xy);
   l2 = w2_norm(w2_triple(xx));
   const W2 h = w2_norm(w2_sub(s, w2_add(b, c)));
-  const W2 e = w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));
+  const W2 e = ISO ? w2_mul_27m3u(c) : w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));      // E'': (9 - u) * 3c in one reduce pass
   l1 = w2_neg(h);
   l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);
   const W2 f = w2_norm(w2_triple(e));
@@ -972,10 +973,19 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
 // The Miller loop of ONE pair on a whole wavefront (the other tail of the one-boolean shapes): the G2 steps run replicated, the
 // accumulator's squaring and its product with each line are w12_mul_wide -- a line (l0, l4 = l1 y_P, l2 = l2 x_P) is the Fp12 element
 // (l0, 0, l2; 0, l4, 0) of mul_by_024 (fp12.rs:426-503), and spread over 18 lane pairs the dense product costs less than the 13-product
-// sparse form on one.  Same field values step by step, so the raw Miller value (canonical at the exit) is the reference's.
-BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs, const S2& qys, WideLds* xg) {
-  const F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
-  const W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
+// sparse form on one.  With ISO = false: same field values step by step, so the raw Miller value (canonical at the exit) is the reference's.
+// ISO: on (phi P, phi Q) with the twist constant 9 - u (g2_doubling_step29): the value is the reference's Miller value times a factor in Fp* --
+// every caller feeds it to a final exponentiation (the raw-value entry points use the lane-pair kernels with ISO = false)
+template <bool ISO>
+BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs_in, const S2& qys_in, WideLds* xg) {
+  F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
+  W2 qx = w2_from_s2(qxs_in), qy = w2_from_s2(qys_in);
+  S2 qxs = qxs_in, qys = qys_in;
+  if (ISO) {
+    px = f29_mul(px, f29_iso_s2()); py = f29_mul(py, f29_iso_s3());
+    qx = w2_scale(qx, f29_iso_s2()); qy = w2_scale(qy, f29_iso_s3());
+    qxs = w2_to_s2(qx); qys = w2_to_s2(qy);
+  }
   const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   G2W r{qx, qy, w2_from_s2(s2_one())};
   W12 f;
@@ -994,7 +1004,7 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
     w12_mul_wide_nl(f, f, f, xg);
-    g2_doubling_step29_wide(r, l0, l1, l2, (WideLdsPtr)xg);
+    g2_doubling_step29_wide<ISO>(r, l0, l1, l2, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
       g2_addition_step29_wide(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, (WideLdsPtr)xg);

@@ -553,7 +553,8 @@ __global__ void k_g2_set_column(u64* qxy, uint8_t* qinf, size_t stride, size_t c
   store_s2(qxy, stride, col, 8, odd, src_xy ? load_s2(src_xy, 1, 0, 8, odd) : s2_g2gen_y());
   if (!odd) qinf[col] = (src_xy && src_inf && src_inf[0]) ? 1 : 0;
 }
-// The raw Miller value of ONE pair (SoA stride-1 views of P, Q and the output), launched as <<<1, 64>>>: miller_loop29_wide.  An identity
+// The Miller value of ONE pair up to a factor in Fp* (isomorphic curves: it only ever feeds a final exponentiation; SoA stride-1 views of
+// P, Q and the output), launched as <<<1, 64>>>: miller_loop29_wide.  An identity
 // on either side gives 1 (the skip_infinity reading; the reference-replay reading of a G2 identity stays on the generic kernels).
 __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, size_t stride, const u64* range, u64* fout) {
   __shared__ WideLds lds;
@@ -567,12 +568,13 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
   } else {
     const Fp px = load_fp(pxy, stride, i, 0), py = load_fp(pxy, stride, i, 4);
     const S2 qx = load_s2(qxy, stride, i, 0, odd), qy = load_s2(qxy, stride, i, 8, odd);
-    miller_loop29_wide(f, px, py, qx, qy, &lds);
+    miller_loop29_wide<true>(f, px, py, qx, qy, &lds);
   }
   if (pair_index(t) == 0) store_s12(fout, 1, 0, odd, f);
 }
 // Small batches, one WAVEFRONT per element (grid = n blocks of 64): block b takes pair b of set A, block n + b pair b of set B (B optional).
-// qxy NULL = the G2 generator for every pair of that set.  An identity on either side gives 1.  Raw Miller values, SoA stride n.
+// qxy NULL = the G2 generator for every pair of that set.  An identity on either side gives 1.  Miller values up to factors in Fp*
+// (isomorphic curves), SoA stride n: input of the k_final_exp_wide_* kernels only.
 __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
                                                  const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n) {
   __shared__ WideLds lds;
@@ -588,7 +590,7 @@ __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* p
   } else {
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
     const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
-    miller_loop29_wide(f, px, py, qx, qy, &lds);
+    miller_loop29_wide<true>(f, px, py, qx, qy, &lds);
   }
   if (pair_index(threadIdx.x) == 0) store_s12(fout, n, i, odd, f);
 }
