@@ -393,7 +393,7 @@ pub fn all_valid(dev: &Device, flags: &DeviceBuf<u8>, comm: *mut c_void) -> Resu
     Ok(dev.download(&out)?[0] == 1)
 }
 
-/// `glued_pairing` over the union of all ranks' pairs: every rank contributes the raw Miller product of its shard, the 384-byte
+/// `glued_pairing` over the union of all ranks' pairs: every rank contributes the Miller product of its shard (up to a factor in Fp*), the 384-byte
 /// partials are all-gathered, each rank multiplies them and runs ONE final exponentiation.  Every rank gets the same answer.
 pub fn glued_pairing_all(dev: &Device, p: &[G1Affine], q: &[G2Affine], skip_identity: bool, comm: *mut c_void) -> Result<(GtOut, bool), HipError> {
     assert_eq!(p.len(), q.len());

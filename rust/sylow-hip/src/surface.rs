@@ -549,7 +549,8 @@ pub fn glued_miller_loop_precomputed(dev: &Device, coeffs: &DeviceBuf<u64>, n_ta
     })?;
     Ok(f)
 }
-/// The two halves of a product split over GPUs by a host with its own transport: this shard's raw Miller product,
+/// The two halves of a product split over GPUs by a host with its own transport: this shard's Miller product up to a factor in Fp*
+/// (an opaque intermediate: the factor disappears in the final exponentiation; the reference's raw value comes from `miller_loop_batch`),
 /// and product + final exponentiation over gathered partials (`parts` = [48][k] SoA).
 pub fn pairing_product_partial(dev: &Device, p: &DeviceG1, q: &DeviceG2, skip_identity: bool) -> Result<DeviceBuf<u64>, HipError> {
     assert_eq!(p.n, q.n);
@@ -568,7 +569,7 @@ pub fn fp12_product_final_exp(dev: &Device, parts: &DeviceBuf<u64>, k: usize) ->
     let words = dev.download_aos::<48>(&gt, 1)?;
     Ok((gt_from_words(&words[0]), dev.download(&one)?[0] != 0))
 }
-/// This shard's raw Miller product of the aggregate check (signatures summed in G1 first), for a host-side gather.
+/// This shard's Miller product (up to a factor in Fp*) of the aggregate check (signatures summed in G1 first), for a host-side gather.
 pub fn aggregate_partial(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &DeviceG1) -> Result<DeviceBuf<u64>, HipError> {
     assert!(sig.n == msgs.len() && (pk.n == msgs.len() || pk.n == 1));
     let (d_msgs, d_off) = messages(dev, msgs)?;
@@ -596,7 +597,7 @@ pub fn batch_verify_weighted(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &
     let words = dev.download_aos::<48>(&gt, 1)?;
     Ok((gt_from_words(&words[0]), dev.download(&one)?[0] != 0))
 }
-/// This shard's raw Miller product of the weighted test, for a host-side gather (`fp12_product_final_exp` finishes it).
+/// This shard's Miller product (up to a factor in Fp*) of the weighted test, for a host-side gather (`fp12_product_final_exp` finishes it).
 pub fn weighted_partial(dev: &Device, pk: &DeviceG2, msgs: &[&[u8]], sig: &DeviceG1, weights: &[Fp]) -> Result<DeviceBuf<u64>, HipError> {
     assert!(sig.n == msgs.len() && weights.len() == msgs.len() && (pk.n == msgs.len() || pk.n == 1));
     let (d_msgs, d_off) = messages(dev, msgs)?;
