@@ -384,6 +384,24 @@ def end_to_end(eng, p_h, q_h, gt_h, pk_h, sig_h, msgs_np, off, dev_pairings_per_
     return res
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) as fresh child processes of
+    torch.distributed.run with this very command line, stdout / stderr inherited (rank 0 prints the one JSON line), and return
+    the launcher's exit code.  The parent holds no GPU state — nothing that initialises HIP has been imported — and does not exec."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,6 +414,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (and the native ncclComm_t) even for one rank")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: this process has not touched the GPU (no torch import yet) and never will — it starts the
+        # N ranks as fresh children through torch.distributed.run, lets rank 0's JSON line through on stdout, and exits with their code
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
 
     from sylow_amd import sharding
@@ -404,8 +427,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run the bare command, which spawns them)")
     dist = None
     # debugging aid for boxes with fewer GPUs than ranks: SYLOW_BENCH_BACKEND=gloo SYLOW_BENCH_SINGLE_DEVICE=1 runs every
     # rank on cuda:0 with host-side collectives, exercising the same barrier / MAX / MIN logic as the RCCL path

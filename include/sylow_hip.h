@@ -69,7 +69,8 @@ int32_t sylow_hip_set_device(int32_t device);
  * block the call frees nothing and returns SYLOW_HIP_E_ARG. */
 int32_t sylow_hip_shutdown(void);
 /* Frees the current device's idle scratch blocks larger than keep_bytes whose last user has completed (blocks grow with the largest
- * batch seen and are otherwise kept for reuse until sylow_hip_shutdown).  Never blocks, never touches a block that is in use. */
+ * batch seen and are otherwise kept for reuse until sylow_hip_shutdown).  Never touches a block that is in use and does not hold the
+ * library's lock while the driver frees (hipFree may wait for the device: the CALLER can block, other host threads' entry points do not). */
 int32_t sylow_hip_trim(size_t keep_bytes);
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
@@ -424,7 +425,10 @@ int32_t sylow_hip_bls_verify_host(const uint64_t* pk_aos, const uint8_t* pk_inf,
  * (non-repr(C)) memory layout: p_be / sig_be [n][64] = G1Affine::to_be_bytes (g1.rs:151-180), q_be / pk_be [n][128] =
  * G2Affine::to_be_bytes (g2.rs:319-359).  Decoding and validation run on the device inside the pipeline (from_be_bytes + curve check;
  * G2 also the r-torsion check of G2Projective::new, g2.rs:460-525); status_* [n] (HOST) receive SYLOW_HIP_ST_* per element, and an
- * element that failed enters the computation as the identity (its Gt is one; its `ok` is the reference's answer for identities). */
+ * element that failed enters the computation as the identity: its Gt is one, and its `ok` is forced to ZERO -- the reference returns Err
+ * from from_be_bytes / G2Projective::new and never reaches verify, and identity inputs can satisfy the pairing equation (a rejected key
+ * with an all-zero signature), so a caller that reads only `ok` must not see 1 for a rejected blob.  msg_offsets must be non-decreasing
+ * over the whole batch (checked on the host: SYLOW_HIP_E_ARG otherwise). */
 int32_t sylow_hip_pairing_host_bytes(const uint8_t* p_be, const uint8_t* q_be, uint64_t* gt_aos, uint8_t* status_p, uint8_t* status_q,
                                      size_t n, size_t chunk);
 int32_t sylow_hip_bls_verify_host_bytes(const uint8_t* pk_be, const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sig_be,

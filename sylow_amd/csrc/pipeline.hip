@@ -16,6 +16,7 @@
 // (sylow_hip_host_malloc) every call is asynchronous and the same order holds.
 // Same kernels, same values as the device-pointer entry points: outputs are bit-identical to the unpipelined call.
 #include "host.hpp"
+#include "pipeline_schedule.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -43,35 +44,7 @@ struct Pipe {
   ~Pipe() { (void)close(); }
 };
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-// Chunk schedule.  A launch costs ~1 ms beyond its share of the work however large it is (its wavefronts start in step and drain
-// unevenly; measured on k_pairing: 2^16 elements 8.6 ms, 2^18 30.7 ms, 2^20 119.5 ms), and the first chunk's upload and the last
-// chunk's download are the only copies nothing hides.  So: a geometric ramp -- base, 4 base, 16 base, ... (chunk k + 1's upload, ~8 ns
-// per element even from pageable memory, hides behind chunk k's ~115 ns per element as long as it is at most ~4 times as large), capped at
-// 32 base, the rest in one piece -- and, when the results are large (Gt values: 384 bytes per element), one base chunk at the END so that the
-// exposed download is short.  Returns the chunk boundaries (k + 1 offsets); the largest chunk is *cmax.
-inline std::vector<size_t> schedule(size_t n, size_t base, bool large_results, size_t* cmax) {
-  // sizes of the ramp-down at the end (large results only): ..., 4 base, base -- chunk k's download (~15 ns per element) hides behind chunk
-  // k + 1's kernels as long as that chunk is not much smaller than a quarter of it, and only the last, small download is exposed
-  std::vector<size_t> down;
-  size_t reserved = 0;
-  if (large_results)
-    for (size_t c = base; c <= 4 * base && reserved + c + base <= n / 2; c *= 4) { down.push_back(c); reserved += c; }
-  std::vector<size_t> cut(1, 0);
-  size_t pos = 0, c = base;
-  const size_t body = n - reserved;
-  while (pos < body) {
-    size_t m = std::min(c, body - pos);
-    if (body - pos - m < c) m = body - pos;             // what would be left is smaller than this chunk: take it along
-    pos += m;
-    cut.push_back(pos);
-    c = std::min(4 * c, 32 * base);                     // bounded device blocks: at most 2^21 elements (2.4 GB) per chunk at the default base
-  }
-  for (size_t i = down.size(); i-- > 0;) { pos += down[i]; cut.push_back(pos); }
-  size_t mx = 0;
-  for (size_t i = 1; i < cut.size(); ++i) mx = std::max(mx, cut[i] - cut[i - 1]);
-  *cmax = mx;
-  return cut;
-}
+using pipeline::schedule;
 #define RCCHK(x) do { const int32_t rc_ = (x); if (rc_ != SYLOW_HIP_OK) return rc_; } while (0)
 }  // namespace
 
@@ -131,12 +104,12 @@ static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const u
   size_t c = 0;
   const std::vector<size_t> cut = schedule(n, chunk ? chunk : DEFAULT_CHUNK, /*large_results=*/false, &c);     // one flag byte per element comes back
   const size_t nchunks = cut.size() - 1;
+  // the offsets are host memory: check ALL of them (a kernel reads msgs + offsets[i] .. msgs + offsets[i + 1] of a window that holds only
+  // [offsets[lo], offsets[hi]) of the blob, so one interior offset out of order would read outside it)
+  for (size_t i = 0; i < n; ++i) ARGCHK(msg_offsets[i] <= msg_offsets[i + 1]);
   size_t max_msg = 0;
-  for (size_t k = 0; k < nchunks; ++k) {
-    const size_t lo = cut[k], hi = cut[k + 1];
-    ARGCHK(msg_offsets[hi] >= msg_offsets[lo]);
-    max_msg = std::max(max_msg, (size_t)(msg_offsets[hi] - msg_offsets[lo]));
-  }
+  for (size_t k = 0; k < nchunks; ++k) max_msg = std::max(max_msg, (size_t)(msg_offsets[cut[k + 1]] - msg_offsets[cut[k]]));
+  ARGCHK(max_msg <= (size_t(1) << 46) && c <= (size_t(1) << 32));          // the block layout below cannot overflow size_t
   // block layout: pk_in 128 c | sig_in 64 c | pk_soa 128 c | sig_soa 64 c | offsets 8 (c + 1) | msgs | ok c | pk_inf c | sig_inf c | st_pk c | st_sig c
   const size_t o_ka = 0, o_sa = o_ka + 128 * c, o_ks = o_sa + 64 * c, o_ss = o_ks + 128 * c, o_of = o_ss + 64 * c, o_ms = align256(o_of + 8 * (c + 1)),
                o_ok = align256(o_ms + max_msg + 1), o_ki = align256(o_ok + c), o_si = align256(o_ki + c), o_tk = align256(o_si + c),
@@ -180,7 +153,14 @@ static int32_t verify_pipeline(const void* pk_in, const uint8_t* pk_inf, const u
     }
     HIPCHK(hipMemcpyAsync(ok + lo, b + o_ok, m, hipMemcpyDeviceToHost, pp.st[k & 1]));
   }
-  return pp.close();
+  RCCHK(pp.close());
+  // A blob that failed decoding / the curve test / the r-torsion test entered the check as the identity, and identity inputs can
+  // satisfy the pairing equation (rejected key + all-zero signature: e(O, g2) e(-H(m), O) = 1).  The reference never gets that far --
+  // from_be_bytes / G2Projective::new return Err (g1.rs:204-280, g2.rs:460-525) -- so a rejected element is NOT verified, whatever its flag says.
+  if (WIRE)
+    for (size_t i = 0; i < n; ++i)
+      if (st_pk[i] | st_sig[i]) ok[i] = 0;
+  return SYLOW_HIP_OK;
 }
 
 extern "C" {

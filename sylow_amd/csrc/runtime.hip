@@ -386,18 +386,24 @@ int32_t sylow_hip_shutdown(void) {
 // Scratch blocks grow with the largest batch a call has seen (the line tables of a 2^20-pair product take ~10 GB) and are kept for reuse.
 // trim frees every block that is idle AND whose last user has completed (its event has fired) and is larger than keep_bytes; blocks in
 // use, or still referenced by queued work, stay.  Cheap; hosts that share the GPU call it after a large batch.
+// hipFree synchronises the device, so the blocks are only UNLINKED under the pool's mutex and freed after it is dropped: other host
+// threads keep acquiring / releasing leases while the driver waits for unrelated streams.
 int32_t sylow_hip_trim(size_t keep_bytes) {
-  std::lock_guard<std::mutex> lock(host::g_mu);
-  int d = 0;
-  int32_t rc = host::current_device(d);
-  if (rc != SYLOW_HIP_OK) return rc;
-  for (host::Block& b : host::g_dev[d].blocks) {
-    if (b.leased || !b.p || b.cap <= keep_bytes) continue;
-    if (b.recorded && hipEventQuery(b.done) != hipSuccess) continue;
-    (void)hipFree(b.p);
-    b.p = nullptr; b.cap = 0; b.recorded = false;
+  std::vector<void*> victims;
+  {
+    std::lock_guard<std::mutex> lock(host::g_mu);
+    int d = 0;
+    int32_t rc = host::current_device(d);
+    if (rc != SYLOW_HIP_OK) return rc;
+    for (host::Block& b : host::g_dev[d].blocks) {
+      if (b.leased || !b.p || b.cap <= keep_bytes) continue;
+      if (b.recorded && hipEventQuery(b.done) != hipSuccess) continue;
+      victims.push_back(b.p);
+      b.p = nullptr; b.cap = 0; b.recorded = false;
+    }
+    (void)hipGetLastError();        // hipEventQuery reports hipErrorNotReady through the sticky error too
   }
-  (void)hipGetLastError();          // hipEventQuery reports hipErrorNotReady through the sticky error too
+  for (void* p : victims) (void)hipFree(p);
   return SYLOW_HIP_OK;
 }
 int32_t sylow_hip_malloc(void** dptr, size_t bytes) { ARGCHK(dptr); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return SYLOW_HIP_OK; }

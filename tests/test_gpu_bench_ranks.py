@@ -40,6 +40,25 @@ def test_two_rank_bench_all_valid():
     assert out["rccl_ranks"] is None and out["collective_backend"] == "gloo"        # two ranks on one GPU: RCCL cannot run here
 
 
+def test_bare_command_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (the shape of the driver's N = 1 command):
+    the parent must start the two ranks itself, relay exactly one JSON line, and exit 0."""
+    env = dict(os.environ, SYLOW_BENCH_BACKEND="gloo", SYLOW_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "12", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-aux"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "rccl_ranks" in out
+    assert out["config"]["bls_all_valid"] == 1
+    # a failing rank must fail the bare command too
+    bad = subprocess.run(cmd + ["--log2n", "99"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0
+
+
 def test_two_rank_bench_planted_bad_signature_on_rank_1():
     out = run_bench(["--plant-bad", "1"])
     aux = out["aux"]

@@ -119,3 +119,22 @@ def test_wire_format_pipelines(engine, coracle):
     sb[3], sb[4] = sb[4], sb[3]
     ok2, _, _ = engine.bls_verify_from_bytes(engine.g2_to_be_bytes(pk_xy), msgs, sb)
     assert not ok2[3] and not ok2[4] and ok2.sum() == n - 2
+    # a REJECTED key next to an all-zero (identity) signature: e(O, g2) e(-H(m), O) = 1 satisfies the pairing equation, but the reference
+    # never reaches verify for such a key (from_be_bytes / G2Projective::new return Err) -- ok must be 0 for every rejected blob
+    kb = engine.g2_to_be_bytes(pk_xy)
+    kb2, sb2 = list(kb), list(engine.g1_to_be_bytes(sig_xy))
+    ident_sig = bytes(64)                                       # to_be_bytes_scrubbed of the identity (g1.rs:151-180, EVM convention)
+    kb2[7] = bytes([0xFF]) * 128;            sb2[7] = ident_sig   # garbage key (non-canonical coordinates)
+    kb2[8] = engine.g2_to_be_bytes(off_sub)[0]; sb2[8] = ident_sig   # key outside the r-torsion
+    kb2[11] = kb[11][:127] + bytes([kb[11][127] ^ 1]); sb2[11] = ident_sig   # key off the curve
+    sb2[12] = sb[12][:63] + bytes([sb[12][63] ^ 1])              # rejected signature under a good key
+    ok3, k3, s3 = engine.bls_verify_from_bytes(kb2, msgs, sb2, chunk=128)
+    assert k3[7] != 0 and k3[8] == 2 and k3[11] == 1 and s3[12] == 1
+    assert not ok3[[7, 8, 11, 12]].any() and ok3.sum() == n - 4
+    # offsets out of order INSIDE a chunk are refused on the host
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(m) for m in msgs]); off[50], off[51] = off[51], off[50]
+    blob = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    kk, ss = np.frombuffer(b"".join(kb), dtype=np.uint8), np.frombuffer(b"".join(sb2), dtype=np.uint8)
+    o, a, b = (np.empty(n, dtype=np.uint8) for _ in range(3))
+    rc = engine.lib.sylow_hip_bls_verify_host_bytes(kk.ctypes.data, blob.ctypes.data, off.ctypes.data, ss.ctypes.data, o.ctypes.data, a.ctypes.data, b.ctypes.data, n, 0)
+    assert rc != 0
