@@ -60,7 +60,7 @@ def test_c3_pairings_2_18_bilinearity(engine, coracle):
     assert np.array_equal(lhs[idx], coracle.pairing(p_proj, q_proj))
 
 
-def test_c4_bls_verify_2_20_planted(engine):
+def test_c4_bls_verify_2_20_planted(engine, coracle):
     n = 1 << 20
     g = np.random.default_rng(107)
     blob = g.integers(0, 256, size=(n, 32), dtype=np.uint8)
@@ -76,6 +76,13 @@ def test_c4_bls_verify_2_20_planted(engine):
     # corrupt 1/1024 of the signatures: sig + G1gen at PRNG-chosen indices
     plant = g.random(n) < 1 / 1024
     sig_aos = engine.from_device_soa(sig)
+    assert not sigi.download().any()
+    # 256 PRNG-chosen signatures of the FULL-SIZE launch against the oracle's sign (lib.rs:179-187): the flags below are otherwise
+    # judged against the GPU's own signatures only
+    sidx = np.sort(np.random.default_rng(4).choice(n, 256, replace=False))
+    smsgs = [blob[i].tobytes() for i in sidx]
+    exp_sig, exp_inf = coracle.g1_to_affine(coracle.sign(sk_aos[sidx], smsgs))
+    assert np.array_equal(sig_aos[sidx], exp_sig) and not exp_inf.any()
     bad, _ = engine.g1_add(sig_aos[plant], np.repeat(pack(G1, 8), int(plant.sum()), 0))
     sig_aos[plant] = bad
     sig2 = engine.to_device_soa(sig_aos, 8)
@@ -84,6 +91,15 @@ def test_c4_bls_verify_2_20_planted(engine):
     flags = ok.download().astype(bool)
     assert np.array_equal(flags, ~plant)
     assert engine.flags_all(ok) == 0
+    # 256 flags of the full-size launch against the oracle's verify (two pairings + compare, lib.rs:223-236): 192 PRNG-chosen rows and
+    # 64 of the planted ones
+    vidx = np.concatenate([np.random.default_rng(5).choice(n, 192, replace=False), np.flatnonzero(plant)[:64]])
+    pk_aos = engine.from_device_soa(pk)[vidx]
+    one4 = np.zeros((vidx.size, 4), dtype=np.uint64); one4[:, 0] = 1
+    pk_proj = np.concatenate([pk_aos, one4, np.zeros((vidx.size, 4), dtype=np.uint64)], axis=1)
+    sig_proj = np.concatenate([sig_aos[vidx], one4], axis=1)
+    assert not pki.download().any()
+    assert np.array_equal(flags[vidx], coracle.verify(pk_proj, [blob[i].tobytes() for i in vidx], sig_proj).astype(bool))
     engine._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig2.ptr, None, ok.ptr, n)
     assert np.array_equal(ok.download().astype(bool), ~plant)
     engine._call("sylow_hip_bls_verify_fused_batch", pk.ptr, None, dm.ptr, doff.ptr, sig.ptr, None, ok.ptr, n)
@@ -91,7 +107,7 @@ def test_c4_bls_verify_2_20_planted(engine):
 
 
 @pytest.mark.parametrize("k", [2, 4])
-def test_c5_ecpairing_2_16_jobs(engine, k):
+def test_c5_ecpairing_2_16_jobs(engine, coracle, k):
     nj = 1 << 16
     n = nj * k
     g = np.random.default_rng(109 + k)
@@ -105,9 +121,19 @@ def test_c5_ecpairing_2_16_jobs(engine, k):
             b[j * k + k - 1] = (b[j * k + k - 1] + 1) % R_ORDER
     p, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs(a))
     q, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), limbs(b))
-    _, is_one = engine.multi_pairing(p, q, np.arange(nj + 1, dtype=np.uint64) * np.uint64(k), skip_infinity=True, want_gt=False)
+    gt, is_one = engine.multi_pairing(p, q, np.arange(nj + 1, dtype=np.uint64) * np.uint64(k), skip_infinity=True, want_gt=True)
     expect = np.array([0 if j % 5 == 4 else 1 for j in range(nj)], dtype=np.uint8)
     assert np.array_equal(is_one, expect)
+    # 128 PRNG-chosen jobs of the full-size launch against the oracle's glued_pairing (pairing.rs:1029-1037), Gt values bit for bit
+    # (about a fifth of them are the spoiled jobs, whose value is not one)
+    jidx = np.sort(np.random.default_rng(6 + k).choice(nj, 128, replace=False))
+    rows = (jidx[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+    one4 = np.zeros((rows.size, 4), dtype=np.uint64); one4[:, 0] = 1
+    p_proj = np.concatenate([p[rows], one4], axis=1)
+    q_proj = np.concatenate([q[rows], one4, np.zeros((rows.size, 4), dtype=np.uint64)], axis=1)
+    exp_gt = coracle.glued_pairing(p_proj, q_proj, np.arange(129, dtype=np.uint64) * np.uint64(k))
+    assert np.array_equal(gt[jidx], exp_gt)
+    assert (jidx % 5 == 4).sum() >= 10
     # the same jobs from BYTES (BASELINE.json configs[4] as the precompile sees it: EIP-197 192-byte pairs, decode + curve / subgroup
     # checks + glued pairing), all 2^16 jobs in one call
     dp, dq = engine.to_device_soa(p, 8), engine.to_device_soa(q, 16)
