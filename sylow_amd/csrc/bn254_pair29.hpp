@@ -117,6 +117,13 @@ BN_NOINLINE F29 w2_sqr_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 
   return f29_mul(sel9(odd, f29_add(a, o), o), sel9(odd, f29_sub(a, o), f29_dbl(a)));   // L(x) L(y) = 2
 }
 BN_DEV W2 w2_mul(const W2& a, const W2& b) { return W2{w2_mul_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
+// the same product INLINED at its call site (no argument / result moves, no call): for the few routines whose whole loop stays inside the
+// instruction cache with it (the cyclotomic squarings of the f^x chains)
+BN_DEV W2 w2_mul_inl(const W2& a, const W2& bin) {
+  F29 b = bin.c, U, W;
+  w2_exchange(a.c, b, U, W);
+  return W2{f29_dot2(a.c, U, W, b)};
+}
 BN_DEV W2 w2_mul_ilp(const W2& a, const W2& b) { return W2{w2_mul_ilp_leaf(W_ARGS(a.c), W_ARGS(b.c))}; }
 BN_DEV W2 w2_sqr(const W2& a) { return W2{w2_sqr_leaf(W_ARGS(a.c))}; }
 BN_DEV W2 w2_scale(const W2& a, const F29& k) { return W2{f29_mul_leaf(W_ARGS(a.c), W_ARGS(k))}; }
@@ -164,17 +171,20 @@ BN_DEV void w12_to_s12(S12& r, const W12& a) {
 // w6_mul finishes each coefficient with one reduce pass; a caller that only adds further terms to a coefficient (the second Fp6 product of an
 // Fp12 squaring, the third of an Fp12 product) folds them into the SAME pass instead of reducing twice.
 struct W6Raw { W2 v0, x0, y1, v2, y2; };
+template <bool INL = false> BN_DEV W2 w2_mul_sel(const W2& a, const W2& b) { return INL ? w2_mul_inl(a, b) : w2_mul(a, b); }
+template <bool INL = false>
 BN_DEV W6Raw w6_mul_raw(const W6& a, const W6& b) {
-  const W2 v0 = w2_mul(a.c0, b.c0);
-  const W2 v1 = w2_mul(a.c1, b.c1);
-  const W2 v2 = w2_mul(a.c2, b.c2);
-  const W2 s0 = w2_mul(w2_sub(a.c1, a.c2), w2_sub(b.c1, b.c2));
-  const W2 s1 = w2_mul(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
-  const W2 s2 = w2_mul(w2_sub(a.c0, a.c2), w2_sub(b.c0, b.c2));
+  const W2 v0 = w2_mul_sel<INL>(a.c0, b.c0);
+  const W2 v1 = w2_mul_sel<INL>(a.c1, b.c1);
+  const W2 v2 = w2_mul_sel<INL>(a.c2, b.c2);
+  const W2 s0 = w2_mul_sel<INL>(w2_sub(a.c1, a.c2), w2_sub(b.c1, b.c2));
+  const W2 s1 = w2_mul_sel<INL>(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
+  const W2 s2 = w2_mul_sel<INL>(w2_sub(a.c0, a.c2), w2_sub(b.c0, b.c2));
   return W6Raw{v0, w2_sub(w2_add(v1, v2), s0), w2_sub(w2_add(v0, v1), s1), v2, w2_add(w2_sub(w2_add(v0, v2), s2), v1)};
 }
+template <bool INL = false>
 BN_DEV W6 w6_mul(const W6& a, const W6& b) {
-  const W6Raw m = w6_mul_raw(a, b);
+  const W6Raw m = w6_mul_raw<INL>(a, b);
   W6 r;
   r.c0 = w2_xi_lin(m.x0, 1, m.v0, 1);                                   // v0 + xi (t0 - v1 - v2)
   r.c1 = w2_xi_lin(m.v2, 1, m.y1, 1);                                   // (t1 - v0 - v1) + xi v2
@@ -235,6 +245,7 @@ BN_DEV W12 w12_mul_line_pair(const W12& a, const W12& b) {
 // complex squaring (fp12.rs:536-550): c0 = (a0 - a1)(a0 - v a1) + a0 a1 + v a0 a1, c1 = 2 a0 a1.  The product m = (a0 - a1)(a0 - v a1)
 // stays raw: each coefficient of c0 is ONE pass over m's piece plus the terms of c2 = a0 a1 (limb ranges: x0 + c2.c2 in (-2^29, 2^30 + 2^29), v0 + c2.c0 in
 // [0, 2^30), y1 + c2.c1 + c2.c0 in (-2^29, 2^31): as two terms; y2 and c2.c2 + c2.c1 as two terms)
+template <bool INL = false>
 BN_DEV W12 w12_sqr(const W12& a) {
   // both factors of m carry-normalised (N): the subtractive Karatsuba inside w6_mul_raw takes differences of their coefficients
   const W6 d{w2_norm(w2_sub(a.c0.c0, a.c1.c0)), w2_norm(w2_sub(a.c0.c1, a.c1.c1)), w2_norm(w2_sub(a.c0.c2, a.c1.c2))};
@@ -242,8 +253,8 @@ BN_DEV W12 w12_sqr(const W12& a) {
   e.c0 = w2_xi_lin(a.c1.c2, -1, a.c0.c0, 1);
   e.c1 = w2_norm(w2_sub(a.c0.c1, a.c1.c0));
   e.c2 = w2_norm(w2_sub(a.c0.c2, a.c1.c1));
-  const W6 c2 = w6_mul(a.c0, a.c1);
-  const W6Raw m = w6_mul_raw(d, e);
+  const W6 c2 = w6_mul<INL>(a.c0, a.c1);
+  const W6Raw m = w6_mul_raw<INL>(d, e);
   W12 r;
   r.c1.c0 = w2_norm(w2_add(c2.c0, c2.c0));
   r.c1.c1 = w2_norm(w2_add(c2.c1, c2.c1));
@@ -369,23 +380,25 @@ BN_DEV W2 w2_xi_norm_sub(const W2& x, const W2& y) {                  // norm(y 
   const i32 c[3] = {bn_keep(-9), bn_keep_v(lane_odd() ? -1 : 1), bn_keep(1)};
   return W2{f29_norm_terms(t, c)};
 }
+template <bool INL = false>
 BN_DEV void w_fp4_square_fold(W2& out0, W2& m, const W2& a, const W2& b, const W2& z) {      // out0 = reduce(3 (a^2 + xi b^2) - 2 z), m = a b
-  m = w2_mul(a, b);
-  const W2 w = w2_mul(w2_sub(a, b), w2_xi_norm_sub(b, a));
+  m = INL ? w2_mul_inl(a, b) : w2_mul(a, b);
+  const W2 w = INL ? w2_mul_inl(w2_sub(a, b), w2_xi_norm_sub(b, a)) : w2_mul(w2_sub(a, b), w2_xi_norm_sub(b, a));
   const F29 mo = xchg9(m.c);
   const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
   const i32 c[4] = {bn_keep(3), bn_keep(30), bn_keep_v(lane_odd() ? 3 : -3), bn_keep(-2)};
   out0 = W2{f29_reduce_terms(t, c)};
 }
+template <bool INL = false>
 BN_DEV W12 w12_cyclotomic_sqr(const W12& f) {
   const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
   W2 m;
   W12 r;
-  w_fp4_square_fold(r.c0.c0, m, z0, z1, z0);               // z0' = 3 t0 - 2 z0
+  w_fp4_square_fold<INL>(r.c0.c0, m, z0, z1, z0);          // z0' = 3 t0 - 2 z0
   r.c1.c1 = w2_lin2(m, 6, z1, 2);                          // z1' = 3 t1 + 2 z1,  t1 = 2 m
-  w_fp4_square_fold(r.c0.c1, m, z2, z3, z4);               // z4' = 3 t0 - 2 z4
+  w_fp4_square_fold<INL>(r.c0.c1, m, z2, z3, z4);          // z4' = 3 t0 - 2 z4
   r.c1.c2 = w2_lin2(m, 6, z5, 2);                          // z5' = 3 t1 + 2 z5
-  w_fp4_square_fold(r.c0.c2, m, z4, z5, z3);               // z3' = 3 t2 - 2 z3
+  w_fp4_square_fold<INL>(r.c0.c2, m, z4, z5, z3);          // z3' = 3 t2 - 2 z3
   r.c1.c0 = w2_xi_lin(m, 6, z2, 2);                        // z2' = 3 xi t3 + 2 z2
   return r;
 }
@@ -516,6 +529,9 @@ BN_DEV F29 lds_get9(i32 (*lds)[256], int slot) {
 // PARK: also park the working point (63 words = 64.5 KB per block of 256 threads: two blocks per CU still fit the 160 KB).  Kernels
 // that stage line tables in LDS as well (plk_verify.hip) take PARK = false (36 words), or only one block per CU would be resident.
 // ISO: the loop runs on (phi P, phi Q) with the twist constant 9 - u (see g2_doubling_step29): same pairing, not the reference's raw Miller value
+#ifndef BN_MILLER_SQR_INL
+#define BN_MILLER_SQR_INL false
+#endif
 template <bool PARK, bool ISO = false>
 BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs_in, const S2& qys_in) {
   __shared__ i32 lds[PARK ? MILLER_LDS_WORDS_PARK : MILLER_LDS_WORDS][256];   // blocks of 256 threads (BLOCK); each thread touches only its own column
@@ -557,7 +573,7 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
     r = unpark(r);
     g2_doubling_step29<ISO>(r, l0, l1, l2);
     park(r);
-    f = w12_sqr(f);
+    f = w12_sqr<BN_MILLER_SQR_INL>(f);
     f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
     if ((nz >> (63 - i)) & 1) {
       r = unpark(r);
@@ -611,6 +627,9 @@ template <int E> BN_NOINLINE void w12_frobenius_nl(W12& r, const W12& a) {
 // for f^17, 1 + 1 for f^35, then 57 + 11), against 63 + 16 for the width-4 windows over {f, f^3, f^5, f^7} of rounds 1-3 -- a product costs
 // three cyclotomic squarings, so the chain is 9 percent cheaper; the reference's 256-step square-and-multiply reaches the same field element
 // with 27 products.   digit i != 0: BN_X_C_NZ;  negative: _NEG;  |d| = 17 (else 35): _17
+#ifndef BN_EXP_INL
+#define BN_EXP_INL true
+#endif
 #define BN_X_C_NZ 0x0008144402208421ull
 #define BN_X_C_NEG 0x0008004400000020ull
 #define BN_X_C_17 0x0000100000008021ull
@@ -630,7 +649,7 @@ BN_NOINLINE void exp_by_neg_z29(W12& r, const W12& f) {
   const u64 nz = BN_X_C_NZ, ng = BN_X_C_NEG, i17 = BN_X_C_17;
 #pragma unroll 1
   for (int i = 56; i >= 0; --i) {
-    res = w12_cyclotomic_sqr(res);
+    res = w12_cyclotomic_sqr<BN_EXP_INL>(res);
     if ((nz >> i) & 1) {
       W12 m = tab[((i17 >> i) & 1) ? 0 : 1];
       if ((ng >> i) & 1) m = w12_conj(m);

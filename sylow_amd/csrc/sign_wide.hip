@@ -1,0 +1,235 @@
+// sign_wide.hip -- BLS signing (lib.rs:179-187: sk * H(m)) for SINGLE calls and small batches: EIGHT lanes per signature.
+//
+// One signature on one lane (sign.hip) is a chain of ~2 900 dependent field multiplications: 2.1 ms whatever the batch size, because a lone
+// lane issues a multiply-add every ~8 cycles.  What is independent inside one signature is spread over the 8 lanes of a group here:
+//   * the two SvdW maps of hash_to_curve (g1.rs:307-331) run side by side, one per QUAD (4 lanes); inside a map the two Jacobi symbols
+//     (is_square(gx1), is_square(gx2): svdw.rs:218-232) run on two lanes at once; the maps' inversions stay shared (Montgomery's trick);
+//   * the scalar multiplication is GLV-split (k = k1 + k2 lambda, bn254_pairing.hpp) with k1 * (+-P) on quad 0 and k2 * (+-phi P) on quad 1,
+//     each with its own accumulator and window table (LDS), added once at the end;
+//   * inside a quad every point is REPLICATED on the four lanes and each lane computes one of the independent products of a formula level:
+//     a doubling (RCB'15 alg. 9, group.rs:339-386) is two levels of four products, a complete addition (alg. 7, group.rs:528-599) four
+//     levels (6 + 6 products on 4 lanes); results travel by DPP quad_perm broadcasts.  128 doublings + 33 additions per half become
+//     ~390 product latencies instead of ~2 050.
+// Same formulas, same operand classes as proj_double_lazy / proj_add_lazy on the carry-free core; the affine result is the same field
+// elements (tests/test_gpu_hash_bls.py, test_gpu_hash_chain.py run through this route at their batch sizes; tests/test_gpu_routes.py forces
+// the one-lane kernel over the same files).  A unit of its own: sign.hip's kernels are compiled for three wavefronts per SIMD, this one is
+// latency-bound at one and takes the default budget.
+#include "host.hpp"
+
+namespace wsign {
+constexpr int GROUP = 8;                     // lanes per signature
+constexpr int WBLOCK = 64;                   // one wavefront per block: 8 signatures
+constexpr int EPB = WBLOCK / GROUP;
+
+template <int S> BN_DEV int qbi(int v) { return __builtin_amdgcn_mov_dpp(v, S * 0x55, 0xF, 0xF, true); }   // lane S of this lane's quad
+template <int S> BN_DEV F29 qb(const F29& a) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = qbi<S>(a.v[i]);
+  return r;
+}
+BN_DEV F29 qsel(int j, const F29& a0, const F29& a1, const F29& a2, const F29& a3) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = j == 0 ? a0.v[i] : (j == 1 ? a1.v[i] : (j == 2 ? a2.v[i] : a3.v[i]));
+  return r;
+}
+BN_DEV Fp xq_fp(const Fp& a) {               // the other quad's value
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (u32)__shfl_xor((int)a.v[i], 4);
+  return r;
+}
+BN_DEV F29 xq_f29(const F29& a) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = __shfl_xor(a.v[i], 4);
+  return r;
+}
+
+// proj_double_lazy<OpsF29> (bn254_pairing.hpp) with its eight products on the four lanes of a quad, two levels.  p replicated, N-class.
+// No identity select: the accumulators and table entries here only ever hold the CANONICAL identity (0 : 1 : 0), which the formulas map to itself.
+BN_DEV G1W qdouble(const G1W& p, int j) {
+  const F29 m1 = OpsF29::mul(qsel(j, p.y, p.y, p.z, p.x), qsel(j, p.y, p.z, p.z, p.y));
+  const F29 t0 = qb<0>(m1), t1 = qb<1>(m1), zz = qb<2>(m1), xy = qb<3>(m1);      // y^2, y z, z^2, x y
+  const F29 z8 = f29_norm_x8(t0);
+  const F29 t2 = OpsF29::mul_b3(zz);
+  const F29 s = f29_norm(f29_add(t0, t2));
+  const F29 d = f29_norm_sub3(t0, t2);
+  const F29 m2 = OpsF29::mul(qsel(j, t2, t1, d, d), qsel(j, z8, z8, s, xy));
+  const F29 x3a = qb<0>(m2), z3 = qb<1>(m2), y3a = qb<2>(m2), x3b = qb<3>(m2);
+  return G1W{f29_norm(f29_add(x3b, x3b)), f29_norm(f29_add(x3a, y3a)), z3};
+}
+// proj_add_lazy<OpsF29> with its twelve products on the four lanes of a quad, four levels (4 + 2 + 4 + 2).  p, q replicated, N-class.
+BN_DEV G1W qadd(const G1W& p, const G1W& q, int j) {
+  const F29 pxy = f29_sub(p.x, p.y), qxy = f29_sub(q.x, q.y), pyz = f29_sub(p.y, p.z), qyz = f29_sub(q.y, q.z),
+            pxz = f29_sub(p.x, p.z), qxz = f29_sub(q.x, q.z);
+  const F29 m1 = OpsF29::mul(qsel(j, p.x, p.y, p.z, pxy), qsel(j, q.x, q.y, q.z, qxy));
+  F29 t0 = qb<0>(m1), t1 = qb<1>(m1), t2 = qb<2>(m1);
+  const F29 c3 = qb<3>(m1);
+  const F29 m2 = OpsF29::mul(qsel(j, pyz, pxz, pyz, pxz), qsel(j, qyz, qxz, qyz, qxz));
+  const F29 c4 = qb<0>(m2), c5 = qb<1>(m2);
+  const F29 t3 = f29_norm(f29_sub(f29_add(t0, t1), c3));            // x1 y2 + x2 y1
+  const F29 t4 = f29_norm(f29_sub(f29_add(t1, t2), c4));            // y1 z2 + y2 z1
+  F29 y3 = f29_sub(f29_add(t0, t2), c5);                            // x1 z2 + x2 z1 (lazy)
+  t0 = f29_norm(f29_add(f29_add(t0, t0), t0));
+  t2 = OpsF29::mul_b3(t2);
+  const F29 z3 = f29_norm(f29_add(t1, t2));
+  t1 = f29_sub(t1, t2);                                             // product operand only
+  y3 = OpsF29::mul_b3_lazy(y3);
+  const F29 m3 = OpsF29::mul(qsel(j, t3, t4, t1, y3), qsel(j, t1, y3, z3, t0));
+  const F29 a = qb<0>(m3), b = qb<1>(m3), c = qb<2>(m3), d = qb<3>(m3);
+  const F29 m4 = OpsF29::mul(qsel(j, z3, t0, z3, t0), qsel(j, t4, t3, t4, t3));
+  const F29 e = qb<0>(m4), f = qb<1>(m4);
+  return G1W{f29_norm(f29_sub(a, b)), f29_norm(f29_add(c, d)), f29_norm(f29_add(e, f))};
+}
+
+// svdw_back (bn254_hash.hpp; svdw.rs:180-262) with the two Jacobi symbols on two lanes of the quad at once
+BN_DEV bool svdw_back_quad(Fp& xo, Fp& yo, const Fp& u, const Fp& tv1, const Fp& tv2, const Fp& tv3, int j) {
+  const Fp c2 = fp_const(C_SVDW[1]), c3 = fp_const(C_SVDW[2]), c4 = fp_const(C_SVDW[3]), z = fp_const(C_SVDW[4]);
+  const Fp b = fp_small(3);
+  const Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
+  const Fp x1 = fp_sub(c2, tv4);
+  const Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
+  const Fp x2 = fp_add(c2, tv4);
+  const Fp gx2 = fp_add(fp_mul(fp_mul(x2, x2), x2), b);
+  const int sq = fp_is_square(fp_select(gx1, gx2, (j & 1) != 0)) ? 1 : 0;       // even lanes: gx1, odd lanes: gx2
+  const bool e1 = qbi<0>(sq) != 0;
+  const bool e2 = qbi<1>(sq) != 0 && !e1;
+  Fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
+  x3 = fp_mul(fp_mul(x3, x3), c4);
+  x3 = fp_add(x3, z);
+  Fp x = fp_select(x3, x1, e1);
+  x = fp_select(x, x2, e2);
+  const Fp gx = fp_add(fp_mul(fp_mul(x, x), x), b);
+  Fp y = fp_mul(gx, fp_pow_pm3_quarter(gx));
+  const bool ok = fp_eq(fp_mul(y, y), gx);
+  const bool e3 = fp_sgn0(u) == fp_sgn0(y);
+  y = fp_select(fp_neg(y), y, e3);
+  xo = x;
+  yo = y;
+  return ok;
+}
+
+// STAMPS (tools/ubench/sign_wide_phases.hip only): clock64() at the phase boundaries of the block's first group into stamps[0..7]
+template <bool STAMPS>
+__global__ void __launch_bounds__(WBLOCK)
+k_bls_sign_wide(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, u64* stamps) {
+  auto stamp = [&](int k) { if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (u64)clock64(); };
+  stamp(0);
+  __shared__ i32 tab[2 * EPB][9][28];                       // per quad: 0P .. 8P, 27 words each
+  const int lane = threadIdx.x & (GROUP - 1), q = lane >> 2, j = lane & 3, slot = (int)(threadIdx.x >> 2);
+  size_t i = (size_t)blockIdx.x * EPB + (threadIdx.x >> 3);
+  const bool live = i < n;
+  if (!live) i = n - 1;                                     // tail groups repeat the last element and store nothing (no lane leaves early)
+  // ---- H(m): both quads expand the message; quad 0 maps u0, quad 1 maps u1
+  G1P h;
+  {
+    uint8_t em[96];
+    expand_message_xmd96(em, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+    stamp(1);
+    const Fp u = fp_from_be48(em + 48 * q);
+    const SvdwHalf me = svdw_front(u);
+    const bool zme = fp_is_zero(me.d);
+    const Fp one = fp_one(), zero = fp_zero();
+    const Fp dme = fp_select(me.d, one, zme), dot = xq_fp(dme);
+    const Fp t = fp_inv(fp_mul(dme, dot));                  // one inversion for both maps (svdw_map2)
+    const Fp inv = fp_select(fp_mul(t, dot), zero, zme);
+    stamp(2);
+    Fp x, y;
+    (void)svdw_back_quad(x, y, me.u, me.tv1, me.tv2, inv, j);
+    stamp(3);
+    const Fp xo = xq_fp(x), yo = xq_fp(y);
+    const G1P a{q ? xo : x, q ? yo : y, one}, b{q ? x : xo, q ? y : yo, one};       // map(u0), map(u1) on every lane
+    h = g1_add(a, b);
+  }
+  stamp(4);
+  // ---- sk * H: GLV halves on the two quads
+  u32 k[8];
+  load_scalar(k, sk, n, i);
+  u32 m1[4], m2[4];
+  bool n1, n2;
+  glv_decompose(m1, n1, m2, n2, k);
+  signed char dig[33];
+  {
+    u32 mq[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mq[w] = q ? m2[w] : m1[w];
+    glv_digits(dig, mq);
+  }
+  auto put = [&](int m, const G1W& v) {
+    if (j == 0) {
+#pragma unroll
+      for (int w = 0; w < 9; ++w) { tab[slot][m][w] = v.x.v[w]; tab[slot][m][9 + w] = v.y.v[w]; tab[slot][m][18 + w] = v.z.v[w]; }
+    }
+  };
+  auto get = [&](int m) {
+    G1W r;
+#pragma unroll
+    for (int w = 0; w < 9; ++w) { r.x.v[w] = tab[slot][m][w]; r.y.v[w] = tab[slot][m][9 + w]; r.z.v[w] = tab[slot][m][18 + w]; }
+    return r;
+  };
+  {
+    const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};   // beta 2^261 mod p
+    G1W t1{f29_from_fp_reduced(h.x), f29_from_fp_reduced(h.y), f29_from_fp_reduced(h.z)};
+    const bool pinf = OpsF29::is_zero(t1.z);                // canonical identity, as g1_scalar_mul_t
+    t1.x = OpsF29::select(t1.x, OpsF29::zero(), pinf);
+    t1.y = OpsF29::select(t1.y, OpsF29::one(), pinf);
+    t1.z = OpsF29::select(t1.z, OpsF29::zero(), pinf);
+    if (q) t1.x = OpsF29::mul(t1.x, beta);                  // quad 1 works on phi(P) = (beta x, y)
+    if (q ? n2 : n1) t1.y = OpsF29::neg(t1.y);              // the table holds multiples of sign(k_q) times the base
+    put(0, proj_zero<OpsF29>());
+    put(1, t1);
+    const G1W t2 = qdouble(t1, j);
+    put(2, t2);
+    const G1W t3 = qadd(t2, t1, j);
+    put(3, t3);
+    const G1W t4 = qdouble(t2, j);
+    put(4, t4);
+    put(5, qadd(t4, t1, j));
+    const G1W t6 = qdouble(t3, j);
+    put(6, t6);
+    put(7, qadd(t6, t1, j));
+    put(8, qdouble(t4, j));
+  }
+  __syncthreads();
+  stamp(5);
+  G1W res = proj_zero<OpsF29>();
+#pragma unroll 1
+  for (int w = 32; w >= 0; --w) {
+    if (w != 32) {
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) res = qdouble(res, j);
+    }
+    const int d = dig[w], m = d < 0 ? -d : d;
+    G1W e = get(m);
+    e.y = OpsF29::select(e.y, OpsF29::neg(e.y), d < 0);
+    res = qadd(res, e, j);
+  }
+  stamp(6);
+  // ---- k1 P + k2 phi(P), to affine, stored by the group's first lane
+  {
+    const G1W o{xq_f29(res.x), xq_f29(res.y), xq_f29(res.z)};
+    const G1W a{q ? o.x : res.x, q ? o.y : res.y, q ? o.z : res.z}, b{q ? res.x : o.x, q ? res.y : o.y, q ? res.z : o.z};
+    res = qadd(a, b, j);
+  }
+  const G1P s{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)};
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, s);
+  if (live && lane == 0) {
+    store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+    oinf[i] = inf ? 1 : 0;
+  }
+  stamp(7);
+}
+}  // namespace wsign
+
+namespace g1h {
+// signatures of n <= sign_wide_max() messages on eight lanes each
+int32_t sign_wide(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
+  if (!n) return SYLOW_HIP_OK;
+  DstPrime dp; host::dst_arg(dp, nullptr, 0);
+  wsign::k_bls_sign_wide<false><<<dim3((unsigned)((n + wsign::EPB - 1) / wsign::EPB)), dim3(wsign::WBLOCK), 0, (hipStream_t)stream>>>(sk, msgs, msg_offsets, dp, sig_xy, sig_inf, n, nullptr);
+  LAUNCHED();
+}
+}  // namespace g1h

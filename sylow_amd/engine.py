@@ -10,7 +10,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _shapes
 
 
 class DeviceArray:
@@ -24,9 +24,11 @@ class DeviceArray:
         p = ctypes.c_void_p()
         _lib.check(engine.lib.sylow_hip_malloc(ctypes.byref(p), self.nbytes), "malloc")
         self.ptr = p.value
+        engine._live[self.ptr] = self.nbytes              # what _shapes.check_call compares against the header's @shape lines
 
     def free(self):
         if self.ptr:
+            self.engine._live.pop(self.ptr, None)
             self.engine.lib.sylow_hip_free(self.ptr)
             self.ptr = None
 
@@ -66,6 +68,7 @@ class Engine:
         _lib.check(self.lib.sylow_hip_init(device), "sylow_hip_init")
         self.device = device
         self.stream = stream  # raw hipStream_t as int, or None for the default stream
+        self._live = {}       # base pointer -> bytes of every live DeviceArray (checked against the header's @shape lines in _call)
 
     # ---- buffers ---------------------------------------------------------------------------
     def empty(self, shape, dtype=np.uint64) -> DeviceArray:
@@ -122,6 +125,10 @@ class Engine:
 
     def _call(self, name, *args):
         # launches go to the calling thread's current device: re-assert ours (other code in the process may have switched it)
+        try:
+            _shapes.check_call(name, args, self._live)       # every buffer at least as large as include/sylow_hip.h's @shape says
+        except ValueError as e:
+            raise _lib.SylowHipError(str(e)) from None
         _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
         _lib.check(getattr(self.lib, name)(*args, self.stream), name)
 

@@ -98,3 +98,127 @@ def test_every_entry_point_is_reached_by_a_wrapper():
     missing = sorted(set(h) - reached)
     assert not missing, missing
     assert reached <= set(h), sorted(reached - set(h))
+
+
+# ---- buffer sizes: every `dev.alloc::<T>(EXPR)` that reaches an ffi call against the header's @shape lines ---------------------------
+def _split_top(s, sep=","):
+    """split at top-level separators (ignores those inside (), [], {}, <>)"""
+    out, depth, cur = [], 0, ""
+    for i, ch in enumerate(s):
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        elif ch == "<" and cur.endswith("::"):
+            depth += 1
+        elif ch == ">" and depth and "::<" in cur and cur.count("<") > cur.count(">"):
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _rust_functions(text):
+    """(name, body) of every `fn` in a Rust source file (brace matching)"""
+    for m in re.finditer(r"\bfn\s+(\w+)[^{;]*\{", text):
+        i, depth = m.end(), 1
+        while depth and i < len(text):
+            depth += {"{": 1, "}": -1}.get(text[i], 0)
+            i += 1
+        yield m.group(1), text[m.end():i]
+
+
+def _allocations(body):
+    """{binding or binding.field: (T, EXPR)} for `let x = dev.alloc::<T>(E)?`, tuple lets and struct literals"""
+    allocs = {}
+    alloc_re = r"dev\.alloc::<(\w+)>\(((?:[^()]|\([^()]*\))*)\)\?"
+    for m in re.finditer(r"let\s+(?:mut\s+)?(\w+)\s*=\s*" + alloc_re, body):
+        allocs[m.group(1)] = (m.group(2), m.group(3))
+    for m in re.finditer(r"let\s+\(([^)]*)\)\s*=\s*\((.*?)\);", body, flags=re.S):
+        names, vals = [x.strip() for x in m.group(1).split(",")], _split_top(m.group(2))
+        if len(names) == len(vals):
+            for nm, v in zip(names, vals):
+                mm = re.fullmatch(alloc_re, v)
+                if mm:
+                    allocs[nm] = (mm.group(1), mm.group(2))
+    for m in re.finditer(r"let\s+(?:mut\s+)?(\w+)\s*=\s*\w+\s*\{([^{}]*)\}", body):
+        for fld in _split_top(m.group(2)):
+            mm = re.fullmatch(r"(\w+)\s*:\s*" + alloc_re, fld)
+            if mm:
+                allocs[f"{m.group(1)}.{mm.group(1)}"] = (mm.group(2), mm.group(3))
+    return allocs
+
+
+def _numeric(expr, env):
+    """value of a size expression with every identifier-like atom (`n`, `W`, `q.len()`, `p.n`) replaced by a number from env"""
+    expr = re.sub(r"([A-Za-z_][\w.]*?)\.max\((\d+)\)", r"max(\1, \2)", expr)              # `n_jobs.max(1)`: never an empty allocation
+    atoms = sorted(set(re.findall(r"[A-Za-z_][\w.]*(?:\(\))?", expr)) - {"max"}, key=len, reverse=True)
+    for a in atoms:
+        if a not in env:
+            env[a] = 1000003 + 7919 * len(env)               # distinct large primes-ish: no accidental equalities
+        expr = re.sub(r"(?<![\w.])" + re.escape(a) + r"(?![\w(])", str(env[a]), expr)
+    return eval(expr, {"__builtins__": {}}, {"max": max})
+
+
+def rust_size_mismatches(sources, shapes, protos):
+    """[(function, entry point, parameter, rust expr, header expr)] for every allocation passed to an ffi call whose size differs"""
+    from sylow_amd._shapes import ITEMSIZE
+    rust_size = {"u64": 8, "u8": 1, "i32": 4, "u32": 4}
+    bad, checked = [], 0
+    for text in sources:
+        for fname, body in _rust_functions(text):
+            allocs = _allocations(body)
+            if not allocs:
+                continue
+            for m in re.finditer(r"ffi::(sylow_hip_\w+)\(((?:[^()]|\((?:[^()]|\([^()]*\))*\))*)\)", body):
+                ent = shapes.get(m.group(1))
+                if ent is None:
+                    continue
+                names, shp = ent
+                args = _split_top(" ".join(m.group(2).split()))
+                if len(args) != len(names):
+                    continue
+                actual = {nm: a for nm, a in zip(names, args) if nm not in shp}
+                for nm, a in zip(names, args):
+                    mm = re.fullmatch(r"([\w.]+)\.as_(?:mut_)?ptr\(\)", a)
+                    if nm not in shp or not mm or mm.group(1) not in allocs or shp[nm].expr == "*":
+                        continue
+                    ty, expr = allocs[mm.group(1)]
+                    env = {}
+                    header_expr = re.sub(r"\b([A-Za-z_]\w*)\b", lambda t: "(" + actual.get(t.group(1), t.group(1)) + ")", shp[nm].expr)
+                    have = _numeric(expr, env) * rust_size[ty]
+                    need = _numeric(header_expr, env) * ITEMSIZE[shp[nm].dtype]
+                    checked += 1
+                    if have < need or (have != need and ".max(" not in expr):
+                        bad.append((fname, m.group(1), nm, f"{ty}[{expr}]", f"{shp[nm].dtype}[{shp[nm].expr}]"))
+    return bad, checked
+
+
+def _rust_sources():
+    base = os.path.join(ROOT, "rust", "sylow-hip", "src")
+    return [open(os.path.join(base, f)).read() for f in ("lib.rs", "surface.rs", "device.rs")]
+
+
+def test_rust_allocations_match_header_shapes():
+    """Every buffer a Rust wrapper allocates and hands to an entry point has exactly the size include/sylow_hip.h's @shape line gives for
+    the size arguments of that very call (the unsafe blocks' SAFETY comments, checked by a tool instead of by eye)."""
+    sys.path.insert(0, ROOT)
+    from sylow_amd import _shapes
+    bad, checked = rust_size_mismatches(_rust_sources(), _shapes.parse(), parse_header())
+    assert checked >= 70, checked
+    assert not bad, bad
+
+
+def test_rust_allocation_check_catches_a_wrong_size():
+    """The same check on a deliberately broken copy of lib.rs: `dev.alloc::<u64>(48 * n)` for pairing_batch's gt shrunk to 24 * n."""
+    sys.path.insert(0, ROOT)
+    from sylow_amd import _shapes
+    src = _rust_sources()
+    broken = src[0].replace("let gt = dev.alloc::<u64>(48 * n)?;", "let gt = dev.alloc::<u64>(24 * n)?;", 1)
+    assert broken != src[0]
+    bad, _ = rust_size_mismatches([broken], _shapes.parse(), parse_header())
+    assert any(b[1] == "sylow_hip_pairing_batch" and b[2] == "gt_out" for b in bad), bad
