@@ -320,7 +320,7 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs=None):
                               "note": "one element per call, HIP-event timed: latency of the single-wavefront routes"}
     return res
 
-def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n):
+def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n, sk_h=None):
     """Per-element time against the batch size for the two headline operations (HIP events on the launch stream, device-resident SoA
     inputs re-packed to each size's stride outside the clock): where single ecPairing calls, Groth16-size batches and the metric's
     2^20 sit on the same curve (examples/reth_bn128.rs:156-217)."""
@@ -336,9 +336,16 @@ def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n):
         tv = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_verify_batch", pkm.ptr, None, dm.ptr, offm.ptr, sgm.ptr, None, okm.ptr, m), reps)
         rows.append({"n": m, "pairing_ms": tp * 1e3, "pairing_us_per_element": tp * 1e6 / m, "pairings_per_s": m / tp,
                      "verify_ms": tv * 1e3, "verify_us_per_element": tv * 1e6 / m, "verifies_per_s": m / tv, "verify_all_ok": int(okm.download().all()), "reps": reps})
+        if sk_h is not None:                              # sign (lib.rs:179-187): n <= 8192 on eight lanes per signature (sign_wide.hip), one lane above
+            skm, so, soi = eng.empty((4, m)).upload(np.ascontiguousarray(sk_h[:, :m])), eng.empty((8, m)), eng.empty((m,), np.uint8)
+            ts = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_sign_batch", skm.ptr, dm.ptr, offm.ptr, so.ptr, soi.ptr, m), reps)
+            rows[-1].update({"sign_ms": ts * 1e3, "sign_us_per_element": ts * 1e6 / m, "signs_per_s": m / ts,
+                             "sign_equals_batch_signature": int(np.array_equal(so.download(), sig_h[:, :m]))})
+            del skm, so, soi
         del pm, qm, pkm, sgm, gtm, okm, offm
     mono = lambda key: int(all(rows[i + 1][key] <= rows[i][key] * 1.02 for i in range(len(rows) - 1)))
     return {"rows": rows, "pairing_us_per_element_monotone": mono("pairing_us_per_element"), "verify_us_per_element_monotone": mono("verify_us_per_element"),
+            **({"sign_us_per_element_monotone": mono("sign_us_per_element")} if sk_h is not None else {}),
             "note": "per-element time must not rise with n (2 % tolerance): one call per row, mean of `reps` back-to-back calls"}
 
 
@@ -610,7 +617,10 @@ def main():
         na = nv
         gt1, is1 = eng.empty((48, 1)), eng.empty((1,), np.uint8)
         agg = lambda: eng._call("sylow_hip_bls_aggregate_verify_batch", pk.ptr, None, nv, dm.ptr, doff.ptr, sig.ptr, None, nv, comm_ptr, gt1.ptr, is1.ptr)
+        eng.sync(); eng.trim(0)
+        free_before = torch.cuda.mem_get_info()[0]
         dta, agg_ms = timed_ranks(agg, 3, "aggregate")
+        agg_scratch = int(free_before - torch.cuda.mem_get_info()[0])        # what the library's leased blocks hold after the call: the line tables of the n-pair product
         agg_ok = int(is1.download()[0]) if comm is not None else sharding.all_valid(int(is1.download()[0]), dist)
         # the same with ONE signer for the whole batch: both halves collapse (n hashes, two G1 sums, a two-pair product)
         k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
@@ -625,6 +635,8 @@ def main():
         agg1_ok = int(is1.download()[0])
         del sk1, sig1, sig1i
         aux = {"aggregate_verify_sigs_per_s": world * na / dta, "aggregate_all_valid": agg_ok, "aggregate_batch_per_gpu": na,
+               "aggregate_scratch_bytes": agg_scratch, "aggregate_scratch_note": "device memory the library holds after aggregate_verify (leased blocks, kept for reuse; "
+               "sylow_hip_trim returns them, sylow_hip_set_scratch_limit bounds the line tables -- DESIGN.md 4.1)",
                "aggregate_same_signer_sigs_per_s": world * nv / dta1, "aggregate_same_signer_all_valid": agg1_ok,
                "aggregate_path": ("native: sylow_hip_bls_aggregate_verify_batch over this rank's ncclComm_t (all-gather of %d partial products)" % rccl_ranks) if comm is not None
                                  else "per-rank product, booleans AND-ed through the process group",
@@ -650,7 +662,7 @@ def main():
                        "aggregate_same_signer = one key: hash + two G1 sums + a two-pair product"}
         if world == 1 and not args.force_dist:
             p_h, q_h, pk_h, sig_h = p.download(), q.download(), pk.download(), sig.download()
-            aux["size_sweep"] = size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n)
+            aux["size_sweep"] = size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n, sk_h=sk.download())
             aux["e2e"] = end_to_end(eng, p_h, q_h, gt.download(), pk_h, sig_h, msgs_np, off, n * args.steps / elapsed, nv * args.steps / v_elapsed)
             del p_h, q_h, pk_h, sig_h
             del dm, doff, sk, g2, pk, pki, sig, sigi, ok, pk1, pk1i, g2one, sk1one

@@ -72,6 +72,13 @@ int32_t sylow_hip_shutdown(void);
  * batch seen and are otherwise kept for reuse until sylow_hip_shutdown).  Never touches a block that is in use and does not hold the
  * library's lock while the driver frees (hipFree may wait for the device: the CALLER can block, other host threads' entry points do not). */
 int32_t sylow_hip_trim(size_t keep_bytes);
+/* Bounds the one scratch user whose size is NOT proportional to its input: the line tables of the multi-pair routes (multi_pairing_batch,
+ * glued_miller_loop_batch, evm_ecpairing_batch with >= 2 pairs per job, pairing_product*, the aggregate verifiers; 19.5 KB per pair, by
+ * default as many whole rounds of 2^16 jobs as fit 12 GB).  With a limit the job slices shrink to what fits (slower below one round of
+ * k-slot jobs = 1.28 GB * k: the table-driven loop then runs under-filled), and a batch-wide product whose chunks no longer fit takes the
+ * in-register schedule (no table at all, ~25 % more Miller-loop work).  Results are identical for every limit.  0 restores the default.
+ * Process-wide; takes effect at the next call. */
+int32_t sylow_hip_set_scratch_limit(size_t bytes);
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
 int32_t sylow_hip_malloc(void** dptr, size_t bytes);

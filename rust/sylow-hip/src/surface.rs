@@ -772,6 +772,13 @@ pub fn g1_sum(dev: &Device, p: &DeviceG1) -> Result<G1Projective, HipError> {
     Ok(download_g1(dev, &out)?.remove(0))
 }
 
+/// Upper bound for the line tables of the multi-pair routes (`sylow_hip_set_scratch_limit`; 0 = the default of 12 GB): the one scratch
+/// user whose size is not proportional to its input.  Process-wide; results do not depend on it.
+pub fn set_scratch_limit(bytes: usize) -> Result<(), device::Error> {
+    // SAFETY: no pointers.
+    device::check(unsafe { ffi::sylow_hip_set_scratch_limit(bytes) })
+}
+
 /// Hand the current device's idle scratch blocks above `keep_bytes` back to the driver (`sylow_hip_trim`): the library keeps the largest
 /// block a call has needed for reuse, which after a 2^20-pair product is several GB.
 pub fn trim(keep_bytes: usize) -> Result<(), device::Error> {

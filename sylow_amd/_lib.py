@@ -136,6 +136,7 @@ SIGNATURES = {
     "sylow_hip_fp12_cyclotomic_sqr_batch": [c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_fp12_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_trim": [c_sz],
+    "sylow_hip_set_scratch_limit": [c_sz],
     "sylow_hip_g1_sum_batch": [c_u64p, c_u8p, c_sz, c_u64p, c_u8p, c_vp],
     "sylow_hip_pairing_host": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz],
     "sylow_hip_bls_verify_host": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],

@@ -72,7 +72,7 @@ def check_call(name, args, live):
         if sh is None:
             continue
         if a is None or a == 0:
-            if not sh.optional:
+            if not sh.optional and sh.nbytes(values) != 0:       # NULL is fine where the call needs zero elements (an empty batch)
                 raise ValueError(f"{name}: {n} must not be NULL")
             continue
         have = live.get(a) if isinstance(a, int) else None

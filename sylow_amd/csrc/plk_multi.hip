@@ -751,6 +751,11 @@ static int multi_tables_mode() {
   static const int v = [] { const char* e = getenv("SYLOW_HIP_MULTI_TABLES"); return e ? atoi(e) : -1; }();
   return v;
 }
+// Bytes the line tables of one call may take: 12 GB, or the host's bound (sylow_hip_set_scratch_limit)
+static size_t table_budget() {
+  const size_t lim = host::scratch_limit();
+  return lim ? lim : (size_t)12 << 30;
+}
 static bool use_tables(size_t n_jobs, size_t n_pairs) {
   const int m = multi_tables_mode();
   if (m == 0) return false;
@@ -794,11 +799,15 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   size_t kt = (n_pairs + n_jobs - 1) / n_jobs;                 // slots per job: the batch average, rounded up; longer jobs take the in-register tail
   if (kt < 1) kt = 1;
   if (kt > 8) kt = 8;
-  constexpr size_t ROUND = 65536, TBL_BYTES = (size_t)12 << 30;
+  constexpr size_t ROUND = 65536;
+  const size_t TBL_BYTES = table_budget();
   const size_t per_job = (size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);
-  size_t rounds = TBL_BYTES / (per_job * ROUND);
-  if (rounds < 1) rounds = 1;
-  size_t jb_max = n_jobs < rounds * ROUND ? n_jobs : rounds * ROUND;
+  const size_t rounds = TBL_BYTES / (per_job * ROUND);
+  // whole rounds of the GPU's 2^16 resident lane pairs while the budget allows; under a host-set limit below one round
+  // (sylow_hip_set_scratch_limit) as many jobs as fit, in blocks of 1024 -- phase B / C then run under-filled, the price of the bound
+  size_t slice = rounds >= 1 ? rounds * ROUND : (TBL_BYTES / per_job) & ~(size_t)1023;
+  if (slice < 1024) slice = 1024;
+  size_t jb_max = n_jobs < slice ? n_jobs : slice;
   size_t w_raw = raw_miller ? 0 : 48 * jb_max * sizeof(u64);
   host::Lease ws;
   int32_t rc = ws.acquire(per_job * jb_max + w_raw, st);
@@ -888,7 +897,8 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   }
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk, range);
   // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
-  if (chunk >= 2 && multi_tables_mode() != 0) {
+  const size_t round_table = (size_t)65536 * chunk * plk::LT_LINES * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);     // one round of chunk-slot jobs
+  if (chunk >= 2 && multi_tables_mode() != 0 && (round_table <= table_budget() || multi_tables_mode() == 1)) {
     rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, /*iso=*/1, stream);
     if (rc != SYLOW_HIP_OK) return rc;
   }

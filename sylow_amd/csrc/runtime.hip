@@ -2,6 +2,7 @@
 // and the HBM-bound Fp / Fr micro-batch kernels.  gfx950 only.  No CPU fallback: every entry point launches HIP kernels or fails.
 #include "host.hpp"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -187,6 +188,8 @@ int32_t fail(hipError_t e, const char* what) {
   return SYLOW_HIP_E_HIP;
 }
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
+static std::atomic<size_t> g_scratch_limit{0};
+size_t scratch_limit() { return g_scratch_limit.load(std::memory_order_relaxed); }
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
   if (!dst) { dst = SYLOW_DST; len = 30; }
   make_dst_prime(dp, dst, len);
@@ -406,6 +409,9 @@ int32_t sylow_hip_trim(size_t keep_bytes) {
   for (void* p : victims) (void)hipFree(p);
   return SYLOW_HIP_OK;
 }
+// Upper bound for the line tables of the multi-pair routes (plk_multi.hip), the one scratch user whose size is not proportional to its
+// input: 0 = the default (12 GB).  Process-wide; read at the start of each call.
+int32_t sylow_hip_set_scratch_limit(size_t bytes) { host::g_scratch_limit.store(bytes, std::memory_order_relaxed); return SYLOW_HIP_OK; }
 int32_t sylow_hip_malloc(void** dptr, size_t bytes) { ARGCHK(dptr); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return SYLOW_HIP_OK; }
 int32_t sylow_hip_free(void* dptr) { HIPCHK(hipFree(dptr)); return SYLOW_HIP_OK; }
 int32_t sylow_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {

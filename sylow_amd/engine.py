@@ -137,6 +137,10 @@ class Engine:
         _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
         _lib.check(self.lib.sylow_hip_trim(keep_bytes), "sylow_hip_trim")
 
+    def set_scratch_limit(self, nbytes: int = 0):
+        """Upper bound for the multi-pair routes' line tables (sylow_hip_set_scratch_limit; 0 = the default of 12 GB).  Process-wide."""
+        _lib.check(self.lib.sylow_hip_set_scratch_limit(nbytes), "sylow_hip_set_scratch_limit")
+
     def shutdown(self):
         """Free the library's scratch blocks and generator tables on every device (it stays usable)."""
         _lib.check(self.lib.sylow_hip_shutdown(), "sylow_hip_shutdown")

@@ -140,3 +140,44 @@ def test_soak_large_short():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_large.py"), "25", "16"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "soak_large ok" in r.stdout
+
+
+def test_scratch_limit_bounds_the_line_tables_and_keeps_results(engine, coracle):
+    """sylow_hip_set_scratch_limit: the multi-pair routes' line tables (19.5 KB per pair, by default whole rounds of 2^16 jobs up to 12 GB) shrink
+    to the host's bound -- job slices below one round, batch-wide products on the in-register schedule -- and every result stays the same:
+    4096 three-pair jobs and a 140 000-pair product (three pairs per lane pair) under a 64 MB bound against the unbounded run and (a sample) the oracle; device memory held
+    by the library afterwards stays under the bound + the n-proportional buffers."""
+    import torch
+    from helpers import pack, limbs
+    from oracle import pyref as R
+    g1, g2 = [1, 2], list(R.G2_GEN_AFF[0]) + list(R.G2_GEN_AFF[1])
+    nj, k = 4096, 3
+    n = nj * k
+    rng = np.random.default_rng(77)
+    a = limbs([int(x) for x in rng.integers(1, 1 << 62, size=n)])
+    b = limbs([int(x) for x in rng.integers(1, 1 << 62, size=n)])
+    p, _ = engine.g1_scalar_mul(np.repeat(pack(g1, 8), n, 0), a)
+    q, _ = engine.g2_scalar_mul(np.repeat(pack(g2, 16), n, 0), b)
+    off = np.arange(nj + 1, dtype=np.uint64) * np.uint64(k)
+    gt0, one0 = engine.multi_pairing(p, q, off, skip_infinity=True)
+    pp, qq = np.tile(p, (12, 1))[:140000], np.tile(q, (12, 1))[:140000]
+    prod0, _ = engine.pairing_product(pp, qq, skip_infinity=True)
+    engine.sync(); engine.trim(0)
+    free0 = torch.cuda.mem_get_info()[0]
+    try:
+        engine.set_scratch_limit(64 << 20)
+        gt1, one1 = engine.multi_pairing(p, q, off, skip_infinity=True)
+        prod1, _ = engine.pairing_product(pp, qq, skip_infinity=True)
+        engine.sync()
+        held = free0 - torch.cuda.mem_get_info()[0]
+    finally:
+        engine.set_scratch_limit(0)
+    assert np.array_equal(gt0, gt1) and np.array_equal(one0, one1) and np.array_equal(prod0, prod1)
+    assert held <= (64 << 20) + 48 * 8 * (nj + 140000) + (32 << 20), held          # the bound + raw Miller values / product tree + allocator slack
+    idx = np.sort(rng.choice(nj, 24, replace=False))
+    rows = (idx[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+    one4 = np.zeros((rows.size, 4), dtype=np.uint64); one4[:, 0] = 1
+    exp = coracle.glued_pairing(np.concatenate([p[rows], one4], axis=1), np.concatenate([q[rows], one4, np.zeros((rows.size, 4), dtype=np.uint64)], axis=1),
+                                np.arange(25, dtype=np.uint64) * np.uint64(k))
+    assert np.array_equal(gt1[idx], exp)
+    engine.trim(0)

@@ -58,6 +58,16 @@ d_res, d_st = eng.empty((nj,), np.uint8), eng.empty((nj,), np.uint8)
 offk = {k: eng.to_device(np.arange(nj + 1, dtype=np.uint64) * np.uint64(k)) for k in (2, 3, 4)}
 gtj, iso = eng.empty((48, nj)), eng.empty((nj,), np.uint8)
 mp0 = {}
+# host pipelines on PAGEABLE arrays (pipeline.hip: H2D / kernels / D2H on two streams, results through pageable hipMemcpyAsync + stream
+# synchronise -- the copy pattern whose set-up twin once came back stale under rocprofv3 --pmc): every repetition against what the
+# device-resident launches wrote
+from sylow_amd import _lib
+h_p, h_q = np.ascontiguousarray(p.download().T), np.ascontiguousarray(q.download().T)
+h_pk, h_sig = np.ascontiguousarray(pk.download().T), np.ascontiguousarray(sig.download().T)
+h_blob, h_off = np.ascontiguousarray(msgs.reshape(-1)), np.arange(n + 1, dtype=np.uint64) * np.uint64(32)
+h_gt, h_ok = np.empty((n, 48), dtype=np.uint64), np.empty((n,), dtype=np.uint8)
+gt0_aos = np.ascontiguousarray(gt0.T)
+host_rounds = 0
 t0 = time.time()
 rounds = 0
 while time.time() - t0 < budget:
@@ -78,5 +88,12 @@ while time.time() - t0 < budget:
             if k not in mp0:
                 mp0[k] = g
             assert np.array_equal(g, mp0[k]), ("multi_pairing nondeterministic", k, rounds)
+    if rounds % 3 == 0:
+        h_gt.fill(0); h_ok.fill(2)
+        _lib.check(eng.lib.sylow_hip_pairing_host(h_p.ctypes.data, None, h_q.ctypes.data, None, h_gt.ctypes.data, n, 0), "pairing_host")
+        assert np.array_equal(h_gt, gt0_aos), ("pairing_host differs from the device-resident result", rounds, np.flatnonzero((h_gt != gt0_aos).any(axis=1))[:8].tolist())
+        _lib.check(eng.lib.sylow_hip_bls_verify_host(h_pk.ctypes.data, None, h_blob.ctypes.data, h_off.ctypes.data, h_sig.ctypes.data, None, h_ok.ctypes.data, n, 0), "bls_verify_host")
+        assert np.array_equal(h_ok, ok0), ("bls_verify_host differs from the device-resident result", rounds, np.flatnonzero(h_ok != ok0)[:8].tolist())
+        host_rounds += 1
     rounds += 1
-print("soak_large ok: %d rounds at n = 2^%d in %.0f s" % (rounds, L, time.time() - t0))
+print("soak_large ok: %d rounds (%d of them also through the pageable host pipelines) at n = 2^%d in %.0f s" % (rounds, host_rounds, L, time.time() - t0))
