@@ -21,7 +21,7 @@ run stall SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INS
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 python3 tools/prof_summarize.py $OUT "profiles/$TAG"
-python3 tools/kernel_usage.py plk_pairing plk_multi plk_verify plk_group g1 hash sign tower runtime > $OUT/kernel_usage.txt 2>&1
+python3 tools/kernel_usage.py plk_pairing plk_multi plk_verify plk_group g1 hash sign sign_wide tower runtime > $OUT/kernel_usage.txt 2>&1
 cp profiles/pmc_current.json $OUT/pmc_previous.json 2>/dev/null
 cp $OUT/pmc_current.json profiles/pmc_current.json          # on the GPU box's copy of the tree: bench.py reads it from there
 python3 bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > $OUT/bench_full_line.json 2> $OUT/bench.err
