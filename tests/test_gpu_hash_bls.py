@@ -241,3 +241,25 @@ def test_large_batch_verify_kernels_agree(engine):
     expect = ~plant
     expect[100:140] = False
     assert np.array_equal(a, expect)
+
+
+def test_sign_edge_scalars_and_ragged_groups(engine, coracle):
+    """bls_sign_batch (lib.rs:179-187) on the batch sizes around the eight-lanes-per-signature groups of sign_wide.hip (1, 7, 8, 9, 63 ... 67:
+    ragged last wavefront, ragged last group) with planted edge scalars -- 0, 1, r - 1, r, r + 1 (the scalar is an Fp value and acts mod r:
+    r gives the identity signature), p - 1, a value >= p (reduced like Fp::new), 2^128 +- 1 (GLV halves of extreme size) -- and message
+    lengths on both sides of the Keccak rate (0, 1, 135, 136, 137, 300 bytes).  Every row against the oracle; under SYLOW_HIP_WIDE_TAIL=0
+    (tests/test_gpu_routes.py) the same rows go through the one-lane kernel."""
+    from helpers import P as PMOD
+    R_ORDER = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    edge = [0, 1, R_ORDER - 1, R_ORDER, R_ORDER + 1, PMOD - 1, PMOD + 5, (1 << 256) - 1, (1 << 128) - 1, (1 << 128) + 1, 2]
+    lens = [0, 1, 135, 136, 137, 300, 32, 4]
+    rng = Xoshiro(SEED + 41)
+    for n in (1, 7, 8, 9, 63, 64, 65, 67):
+        sk_int = [edge[i % len(edge)] if i % 3 == 0 else rng.fp() for i in range(n)]
+        msgs = [bytes((7 * i + j) & 255 for j in range(lens[(i + n) % len(lens)])) for i in range(n)]
+        sk = limbs(sk_int)
+        sig_xy, sig_inf = engine.bls_sign(sk, msgs)
+        exp_xy, exp_inf = coracle.g1_to_affine(coracle.sign(sk, msgs))
+        assert np.array_equal(sig_xy, exp_xy) and np.array_equal(sig_inf, exp_inf), n
+        zero_rows = [i for i, k in enumerate(sk_int) if k % PMOD % R_ORDER == 0]
+        assert all(sig_inf[i] == 1 for i in zero_rows)

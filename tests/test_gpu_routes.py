@@ -4,9 +4,10 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
   SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
                              shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
-                             above 2048 / 1024 elements reach them)
+                             above 2048 / 1024 elements reach them), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
+                             default only batches above 8192 reach it; below, sign_wide.hip's eight lanes per signature)
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
-(sylow_amd/csrc/plk_multi.hip; nothing else in the library reads the environment.)"""
+(sylow_amd/csrc/plk_multi.hip; besides these the library reads only SYLOW_HIP_SIGN_WIDE_MAX, the signing threshold, in sign.hip.)"""
 import os
 import subprocess
 import sys
@@ -16,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
-         "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py"]
+         "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py"]
 ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"},
           {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
 
