@@ -31,6 +31,7 @@ int32_t g1_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base t
 int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base table of the G2 generator (plk_group.hip), built on first use
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 size_t scratch_limit();                                         // sylow_hip_set_scratch_limit: 0 = default
+unsigned compute_units();                                       // CUs of the calling thread's current device (0 if unknown)
 }  // namespace host
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return host::fail(e_, #x); } while (0)

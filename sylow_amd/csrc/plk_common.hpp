@@ -19,6 +19,35 @@ BN_DEV void store_s12(u64* base, size_t n, size_t i, int odd, const S12& a) {
   store_s2(base, n, i, 0, odd, a.c0.c0); store_s2(base, n, i, 8, odd, a.c0.c1); store_s2(base, n, i, 16, odd, a.c0.c2);
   store_s2(base, n, i, 24, odd, a.c1.c0); store_s2(base, n, i, 32, odd, a.c1.c1); store_s2(base, n, i, 40, odd, a.c1.c2);
 }
+// ---- staggered launches (plk_pairing.hip: k_pairing; plk_verify.hip: k_bls_verify_fused) -------------------------------------------------
+// Blocks [first, first + count) run only the first half of their element's work (the Miller loop) and park the value; blocks >= nblk finish
+// the parked chunks (b - nblk + first).  See k_pairing for why.
+struct Stagger {
+  unsigned first, count, nblk;
+  u64* park;                        // [48][count * BLOCK / 2] raw Miller values
+  unsigned* done;                   // [count] set by a parking block when its values are visible
+};
+// role of this block -- 0: whole element, 1: Miller loop only (park), 2: final exponentiation only -- and the chunk of elements it works on
+BN_DEV int stagger_role(const Stagger& st, unsigned& chunk) {
+  chunk = blockIdx.x;
+  if (st.count) {
+    if (chunk >= st.first && chunk < st.first + st.count) return 1;
+    if (chunk >= st.nblk) { chunk = chunk - st.nblk + st.first; return 2; }
+  }
+  return 0;
+}
+BN_DEV void stagger_publish(const Stagger& st, unsigned chunk) {       // role 1, after the block's stores to st.park
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&st.done[chunk - st.first], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+BN_DEV void stagger_wait(const Stagger& st, unsigned chunk) {          // role 2, before the block's loads from st.park
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(&st.done[chunk - st.first], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+}
+
 BN_DEV S2 s2_g2gen_x() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1]))}; }
 BN_DEV S2 s2_g2gen_y() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[2]), fp_const(C_G2_GEN[3]))}; }
 BN_DEV W2 w2_select(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }     // c ? b : a
@@ -32,3 +61,8 @@ BN_DEV W2 w2_select(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b
 constexpr int LINE_TABLE_LINES = 87;
 constexpr int LINE_TABLE_WORDS = LINE_TABLE_LINES * 36 + LINE_TABLE_LINES;
 }  // namespace plk
+
+namespace plkh {
+// plk_pairing.hip: fills `sg` for a staggered launch of `nblk` blocks, `full` of them whole chunks (count = 0: plain launch)
+hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st);
+}  // namespace plkh

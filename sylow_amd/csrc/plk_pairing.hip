@@ -24,21 +24,44 @@ __global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
   store_s12(gout, n, i, odd, g);
 }
 // pairing.rs:870-893
-__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n) {
-  const size_t t = TID, i = pair_index(t);
+//
+// STAGGERED launch (round 5).  Left alone, the two wavefronts a SIMD holds start together and stay in the SAME phase -- both in the Miller
+// loop, then both in the final exponentiation -- for the first rounds of a launch; co-resident wavefronts in DIFFERENT phases run 11 % faster
+// (tools/dbg/mix_phases.py: half a round of Miller loops beside half a round of final exponentiations, 3.52 ms against 3.90 ms for the same
+// work phase by phase), because they stall on different things at different times.  So launches of two rounds or more are skewed by half a period: of the first
+// resident set of blocks (2 per CU; block b and b + 256 share a CU on this part) the second half only runs the Miller loop and parks the value
+// in a leased block (role M), the blocks that follow them into those slots therefore start their Miller loops while their SIMD partners are
+// in the final exponentiation, and the parked values are finished by extra blocks at the end of the grid (role F).  Same arithmetic, same
+// results; 1.6 % of a 2^20 batch takes the detour through 384 bytes of HBM per element.
+__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, Stagger st) {
+  unsigned chunk;
+  const int role = stagger_role(st, chunk);
+  const size_t t = (size_t)chunk * blockDim.x + threadIdx.x, i = pair_index(t);
   const int odd = pair_role(t);
+  const size_t np = (size_t)st.count * (BLOCK / 2), ip = (size_t)(chunk - st.first) * (BLOCK / 2) + (i & (BLOCK / 2 - 1));   // parked element index
+  if (role == 2) {                                               // chunks of role 1 / 2 are always whole (stagger_setup only skews full chunks)
+    stagger_wait(st, chunk);
+    S12 f, g;
+    load_s12(f, st.park, np, ip, odd);
+    final_exponentiation29(g, f);
+    store_s12(gout, n, i, odd, g);
+    return;
+  }
   if (i >= n) return;
   const bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
   S12 g;
   if (either_zero) {
     g = s12_one();                 // Miller value forced to one; final_exponentiation(1) == 1
+    if (role == 1) store_s12(st.park, np, ip, odd, g);
   } else {
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
     const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
     S12 f;
     miller_loop29g<true, true>(f, px, py, qx, qy);          // on the isomorphic curves: the value differs from the reference's raw Miller value by a factor in Fp*, gone after the next line
-    final_exponentiation29(g, f);
+    if (role == 1) store_s12(st.park, np, ip, odd, f);
+    else final_exponentiation29(g, f);
   }
+  if (role == 1) { stagger_publish(st, chunk); return; }
   store_s12(gout, n, i, odd, g);
 }
 
@@ -93,6 +116,28 @@ int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out,
 }
 }  // namespace plkh
 
+namespace plkh {
+// SYLOW_HIP_STAGGER=0: every block runs its whole element (A/B runs, tests/test_gpu_routes.py)
+static bool stagger_on() {
+  static const bool v = [] { const char* e = getenv("SYLOW_HIP_STAGGER"); return !(e && e[0] == '0'); }();
+  return v;
+}
+// Fills `sg` for a staggered launch of `nblk` blocks (`full` of them whole chunks) when the batch is at least two rounds of the resident
+// blocks (2 per CU): measured on k_pairing, 2^17 elements 14.46 -> 14.00 ms, 2^18 27.86 -> 27.33, 2^19 54.95 -> 54.3, 2^20 108.5 -> 108.0;
+// exactly one round (2^16) LOSES 2 % (the parked half runs its final exponentiations beside the other half's), so smaller batches stay plain.
+// Leaves sg.count = 0 (plain launch) when the lease fails.  The caller releases `ws` after the launch.
+hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st) {
+  sg = plk::Stagger{0, 0, (unsigned)nblk, nullptr, nullptr};
+  const unsigned cus = host::compute_units();
+  if (!stagger_on() || !cus || full < 4 * (size_t)cus || nblk >= 0x7fffffffu) return hipSuccess;
+  const size_t park_bytes = (size_t)cus * (BLOCK / 2) * 48 * sizeof(u64), flag_bytes = ((size_t)cus * sizeof(unsigned) + 255) & ~(size_t)255;
+  if (ws.acquire(park_bytes + flag_bytes, st) != SYLOW_HIP_OK) { (void)hipGetLastError(); return hipSuccess; }
+  sg.first = cus; sg.count = cus;
+  sg.park = (u64*)ws.p; sg.done = (unsigned*)((uint8_t*)ws.p + park_bytes);
+  return hipMemsetAsync(sg.done, 0, flag_bytes, st);
+}
+}  // namespace plkh
+
 extern "C" {
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
@@ -114,7 +159,16 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
     const int32_t r2 = ws.release();
     return rc != SYLOW_HIP_OK ? rc : r2;
   }
-  plk::k_pairing<<<GRID(2 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
+  // staggered launch (see k_pairing): needs one full resident set of blocks (2 per CU) made of whole chunks
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
+  plk::Stagger sg;
+  host::Lease ws;
+  HIPCHK(plkh::stagger_setup(sg, ws, nblk, full, st));
+  plk::k_pairing<<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, st>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, sg);
+  const hipError_t e = hipGetLastError();
+  const int32_t rc = ws.release();
+  return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 // test hook: raw Fp12 selector.  0..11: the one-element-per-lane layer (tower.hip: 8 product on the carry-free core, 9 cyclotomic square on
 // it, 10 / 11 exp_by_neg_z on the carry-free / saturated core); 16..29: the lane-pair Fp12 layer (plk::k_w12_op)

@@ -145,14 +145,27 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
 template <bool PK_TABLE>
 __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
                                                 const u64* hneg, const uint8_t* hneg_inf,
-                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
+                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, Stagger st) {
   __shared__ i32 tabA[LINE_TABLE_WORDS];
   __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
+  // staggered launch (k_pairing, plk_pairing.hip): role 1 parks the two-pair Miller value, role 2 finishes a parked chunk
+  unsigned chunk;
+  const int role = stagger_role(st, chunk);
+  const size_t t = (size_t)chunk * blockDim.x + threadIdx.x, i = pair_index(t);
+  const int odd = pair_role(t);
+  const size_t np = (size_t)st.count * (BLOCK / 2), ip = (size_t)(chunk - st.first) * (BLOCK / 2) + (i & (BLOCK / 2 - 1));
+  if (role == 2) {
+    stagger_wait(st, chunk);
+    S12 fs, g;
+    load_s12(fs, st.park, np, ip, odd);
+    final_exponentiation29(g, fs);
+    const bool one = s12_is_one(g);
+    if (!odd) okout[i] = one ? 1 : 0;
+    return;
+  }
   stage_table(tabA, gen_table);
   if (PK_TABLE) stage_table(tabB, pk_table);
   __syncthreads();
-  const size_t t = TID, i = pair_index(t);
-  const int odd = pair_role(t);
   const bool active = i < n;
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
   const Fp hxs = load_fp(hneg, n, ii, 0), hys = load_fp(hneg, n, ii, 4);     // pair B is (-H, pk)
@@ -240,6 +253,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   lineB();
   S12 fs, g;
   w12_to_s12(fs, f);
+  if (role == 1) {                                         // whole chunks only: every lane is active
+    store_s12(st.park, np, ip, odd, fs);
+    stagger_publish(st, chunk);
+    return;
+  }
   final_exponentiation29(g, fs);
   const bool one = s12_is_one(g);
   if (active && !odd) okout[i] = one ? 1 : 0;
@@ -264,12 +282,20 @@ static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const 
   u64* hneg = (u64*)ws.p;
   uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
   rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
+  plk::Stagger sg{0, 0, 0, nullptr, nullptr};
+  host::Lease wp;
+  const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
+  if (rc == SYLOW_HIP_OK) {
+    const hipError_t es = plkh::stagger_setup(sg, wp, nblk, full, (hipStream_t)stream);
+    if (es != hipSuccess) rc = host::fail(es, "stagger flags");
+  }
   if (rc == SYLOW_HIP_OK)
-    plk::k_bls_verify_fused<PK_TABLE><<<GRID(2 * n)>>>(pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n);
+    plk::k_bls_verify_fused<PK_TABLE><<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, (hipStream_t)stream>>>(pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n, sg);
   const hipError_t e = hipGetLastError();
+  const int32_t r3 = wp.release();
   const int32_t r2 = ws.release();
   if (rc != SYLOW_HIP_OK) return rc;
-  return e != hipSuccess ? host::fail(e, "kernel launch") : r2;
+  return e != hipSuccess ? host::fail(e, "kernel launch") : (r2 != SYLOW_HIP_OK ? r2 : r3);
 }
 
 extern "C" {

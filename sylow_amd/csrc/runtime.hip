@@ -190,6 +190,19 @@ int32_t fail(hipError_t e, const char* what) {
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
 static std::atomic<size_t> g_scratch_limit{0};
 size_t scratch_limit() { return g_scratch_limit.load(std::memory_order_relaxed); }
+unsigned compute_units() {
+  static std::atomic<unsigned> cache[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 0;
+  unsigned v = cache[d].load(std::memory_order_relaxed);
+  if (!v) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cu <= 0) return 0;
+    v = (unsigned)cu;
+    cache[d].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len) {
   if (!dst) { dst = SYLOW_DST; len = 30; }
   make_dst_prime(dp, dst, len);

@@ -166,3 +166,40 @@ def test_c2c_g2_scalar_mul_2_18_split_equals_generic(engine, coracle):
     aq, _ = engine.g2_scalar_mul(q, a, subgroup=True)
     sum_xy, sum_inf = engine.g2_add(aq, s1)
     assert np.array_equal(sum_xy, ab) and not sum_inf.any()
+
+
+def test_staggered_launch_every_row(engine, coracle):
+    """The skewed launch of k_pairing / k_bls_verify_fused (plk_pairing.hip: from 2^17 elements on, blocks 256..511 park their Miller values
+    and extra blocks at the end of the grid finish them) on a batch with a ragged last block: 2^17 + 77 pairings built from 64 distinct pairs,
+    so that EVERY row has an oracle value -- incl. identity flags planted inside the parked range and in the ragged tail -- and the same
+    for verify with wrong signatures planted inside the parked range."""
+    n, d = (1 << 17) + 77, 64
+    rng = np.random.default_rng(515)
+    a = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    b = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    p64, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), d, 0), a)
+    q64, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), d, 0), b)
+    one4 = np.zeros((d, 4), dtype=np.uint64); one4[:, 0] = 1
+    gt64 = coracle.pairing(np.concatenate([p64, one4], axis=1), np.concatenate([q64, one4, np.zeros((d, 4), dtype=np.uint64)], axis=1))
+    idx = np.arange(n) % d
+    pinf, qinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    pinf[[5, 32768, 40000, 65535, n - 1]] = 1                     # elements 32768 .. 65535 are the parked chunks
+    qinf[[6, 33333, 65000, 1 << 17]] = 1
+    got = engine.pairing(p64[idx], q64[idx], p_inf=pinf, q_inf=qinf, pipelined=False)
+    exp = gt64[idx]
+    ident = np.zeros(48, dtype=np.uint64); ident[0] = 1
+    exp[(pinf | qinf).astype(bool)] = ident
+    assert np.array_equal(got, exp)
+    # verify: 64 distinct (key, message, signature) triples, wrong signatures planted in and around the parked range
+    sk = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    msgs64 = [bytes([i, 255 - i, 7]) * (1 + i % 5) for i in range(d)]
+    sig64, _ = engine.bls_sign(sk, msgs64)
+    exp_sig, _ = coracle.g1_to_affine(coracle.sign(sk, msgs64))
+    assert np.array_equal(sig64, exp_sig)
+    pk64, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), d, 0), sk)
+    sig = sig64[idx].copy()
+    bad = np.array([0, 32767, 32768, 32769, 50001, 65535, 65536, 100000, n - 1])
+    sig[bad] = sig64[(idx[bad] + 1) % d]
+    ok = engine.bls_verify(pk64[idx], [msgs64[i] for i in idx], sig, pipelined=False)        # one launch of n elements (the pipeline would cut it)
+    want = np.ones(n, dtype=np.uint8); want[bad] = 0
+    assert np.array_equal(ok, want)
