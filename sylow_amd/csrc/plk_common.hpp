@@ -24,6 +24,7 @@ BN_DEV void store_s12(u64* base, size_t n, size_t i, int odd, const S12& a) {
 // the parked chunks (b - nblk + first).  See k_pairing for why.
 struct Stagger {
   unsigned first, count, nblk;
+  unsigned mute;                    // test mode (SYLOW_HIP_STAGGER=2): parking blocks never publish, so every finishing block takes the recompute fallback
   u64* park;                        // [48][count * BLOCK / 2] raw Miller values
   unsigned* done;                   // [count] set by a parking block when its values are visible
 };
@@ -39,13 +40,25 @@ BN_DEV int stagger_role(const Stagger& st, unsigned& chunk) {
 BN_DEV void stagger_publish(const Stagger& st, unsigned chunk) {       // role 1, after the block's stores to st.park
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&st.done[chunk - st.first], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && !st.mute) __hip_atomic_store(&st.done[chunk - st.first], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-BN_DEV void stagger_wait(const Stagger& st, unsigned chunk) {          // role 2, before the block's loads from st.park
+// role 2, before the block's loads from st.park: true when the parked values are visible.  The parking block was dispatched long before this
+// one (in-order dispatch; it has normally finished whole rounds ago), so the flag is set on the first look; the wait is BOUNDED (~2 ms) all the
+// same, and on false the caller recomputes the chunk from its inputs (role 0 on the same elements) -- no schedule of the dispatcher, no other
+// grid sharing the GPU can turn the skew into a deadlock.
+BN_DEV bool stagger_wait(const Stagger& st, unsigned chunk) {
+  __shared__ int ready;
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load(&st.done[chunk - st.first], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+    int r = 0;
+#pragma unroll 1
+    for (int it = 0; it < 4096 && !r; ++it) {
+      r = __hip_atomic_load(&st.done[chunk - st.first], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      if (!r) __builtin_amdgcn_s_sleep(16);
+    }
+    ready = r;
   }
   __syncthreads();
+  return ready != 0;
 }
 
 BN_DEV S2 s2_g2gen_x() { return S2{sel(lane_odd(), fp_const(C_G2_GEN[0]), fp_const(C_G2_GEN[1]))}; }

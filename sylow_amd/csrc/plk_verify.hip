@@ -150,12 +150,12 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
   // staggered launch (k_pairing, plk_pairing.hip): role 1 parks the two-pair Miller value, role 2 finishes a parked chunk
   unsigned chunk;
-  const int role = stagger_role(st, chunk);
+  int role = stagger_role(st, chunk);
   const size_t t = (size_t)chunk * blockDim.x + threadIdx.x, i = pair_index(t);
   const int odd = pair_role(t);
   const size_t np = (size_t)st.count * (BLOCK / 2), ip = (size_t)(chunk - st.first) * (BLOCK / 2) + (i & (BLOCK / 2 - 1));
+  if (role == 2 && !stagger_wait(st, chunk)) role = 0;           // parked values not visible within the bound: recompute the chunk whole
   if (role == 2) {
-    stagger_wait(st, chunk);
     S12 fs, g;
     load_s12(fs, st.park, np, ip, odd);
     final_exponentiation29(g, fs);
@@ -282,7 +282,7 @@ static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const 
   u64* hneg = (u64*)ws.p;
   uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
   rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
-  plk::Stagger sg{0, 0, 0, nullptr, nullptr};
+  plk::Stagger sg{0, 0, 0, 0, nullptr, nullptr};
   host::Lease wp;
   const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
   if (rc == SYLOW_HIP_OK) {

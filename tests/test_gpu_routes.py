@@ -9,6 +9,9 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
   SYLOW_HIP_STAGGER=0        k_pairing / k_bls_verify_fused launched plain (default from 2^17 elements: the launch is skewed by half a
                              period, plk_pairing.hip) -- the full-size C3 test is added to the files for this switch
+  SYLOW_HIP_STAGGER=2        the skewed launch with the parking blocks' flags muted: every finishing block waits out its bound and
+                             recomputes its chunk (the fallback that makes the skew independent of dispatch order); the every-row
+                             test of the skewed launch is added to the files for this switch
 (sylow_amd/csrc/plk_multi.hip; besides these the library reads only SYLOW_HIP_SIGN_WIDE_MAX, the signing threshold, in sign.hip.)"""
 import os
 import subprocess
@@ -21,6 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
          "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py"]
 ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"}, {"SYLOW_HIP_STAGGER": "0"},
+          {"SYLOW_HIP_STAGGER": "2"},
           {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
 
 
@@ -31,6 +35,7 @@ def test_forced_route_passes_the_same_tests(route):
     env = dict(os.environ, **route)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--deselect",
                         "tests/test_gpu_aggregate.py::test_rccl_entry_points_one_rank_communicator"] + FILES
-                       + (["tests/test_gpu_full_size.py::test_c3_pairings_2_18_bilinearity"] if "SYLOW_HIP_STAGGER" in route else []),
+                       + (["tests/test_gpu_full_size.py::test_c3_pairings_2_18_bilinearity", "tests/test_gpu_full_size.py::test_staggered_launch_every_row"]
+                          if "SYLOW_HIP_STAGGER" in route else []),
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-2500:]
