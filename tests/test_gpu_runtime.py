@@ -90,6 +90,60 @@ def test_two_threads_two_streams_workspace_users(engine, coracle):
     assert not errors, errors[:5]
 
 
+def test_two_threads_staggered_launches(engine, coracle):
+    """Two host threads on two non-default streams, each launching the skewed kernels (k_pairing / k_bls_verify_fused from 2^17 elements on:
+    parked Miller values, per-block flags and finishing blocks in a leased block per call) at the same time -- two skewed grids share the GPU, so
+    finishing blocks of one wait while the other holds slots.  Every row of every call against oracle values (64 distinct pairs / triples tiled)."""
+    import torch
+
+    import sylow_amd
+    n, d = (1 << 17) + 40, 64
+    rng = np.random.default_rng(616)
+    p64, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), d, 0), limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)]))
+    q64, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), d, 0), limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)]))
+    gt64 = coracle.pairing(proj1(p64), proj2(q64))
+    sk = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    msgs64 = [bytes([i, 3 * i & 255]) * (1 + i % 4) for i in range(d)]
+    sig64, _ = engine.bls_sign(sk, msgs64)
+    pk64, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), d, 0), sk)
+    idx = np.arange(n) % d
+    bad = np.array([1, 32768, 50000, 65535, 70000, n - 1])
+    sig = sig64[idx].copy(); sig[bad] = sig64[(idx[bad] + 1) % d]
+    want = np.ones(n, dtype=np.uint8); want[bad] = 0
+    blob = np.frombuffer(b"".join(msgs64[i] for i in idx), dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(msgs64[i]) for i in idx])
+    errors = []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream()
+            eng = sylow_amd.Engine(0, stream=st.cuda_stream)
+            dp, dq = eng.to_device_soa(p64[idx], 8), eng.to_device_soa(q64[idx], 16)
+            dpk, dsig = eng.to_device_soa(pk64[idx], 16), eng.to_device_soa(sig, 8)
+            dm, doff = eng.to_device(blob), eng.to_device(off)
+            gt, ok = eng.empty((48, n)), eng.empty((n,), np.uint8)
+            for it in range(3):
+                if (it + tid) % 2:
+                    eng._call("sylow_hip_pairing_batch", dp.ptr, None, dq.ptr, None, gt.ptr, n)
+                    eng._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n)
+                else:
+                    eng._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n)
+                    eng._call("sylow_hip_pairing_batch", dp.ptr, None, dq.ptr, None, gt.ptr, n)
+                if not np.array_equal(eng.from_device_soa(gt), gt64[idx]):
+                    errors.append(("pairing", tid, it))
+                if not np.array_equal(ok.download(), want):
+                    errors.append(("verify", tid, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", tid, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_shutdown_then_reuse(engine, coracle):
     p, q = _inputs(engine, 20, SEED + 102)
     before, _ = engine.pairing_product(p, q)
