@@ -1,5 +1,6 @@
-"""The multi-pair routes over job counts and job sizes for the route the environment selects (SYLOW_HIP_MULTI_PIPE=0 / 1): multi_pairing_batch
-(SoA points), the byte-level ecPairing adapter, the batch-wide product and the aggregate verifier."""
+"""The multi-pair routes over job counts and job sizes: multi_pairing_batch (SoA points), the byte-level ecPairing adapter and the batch-wide
+product, with a checksum of the Gt values (A/B runs of route variants must agree on it).  Round 5 used it for the two-chain slicing experiment
+(profiles/r05_ab/multi_two_chains.log; the switch it toggled, SYLOW_HIP_MULTI_PIPE, was removed with the variant)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, sylow_amd
