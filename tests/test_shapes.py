@@ -36,6 +36,17 @@ def test_every_array_entry_point_is_annotated():
                 assert sh.nbytes({k: 3 for k in ints}) > 0
 
 
+def test_header_is_what_the_generator_writes():
+    """include/sylow_hip.h carries exactly the @shape lines tools/gen_shape_annotations.py renders (nobody edited one by hand, none is stale)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_shapes", os.path.join(ROOT, "tools", "gen_shape_annotations.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(gen.HDR).read()
+    again, n = gen.render(text)
+    assert again == text and n == len(_shapes.parse())
+
+
 def test_checker_accepts_and_rejects():
     live = {0x1000: 8 * 8 * 5, 0x2000: 16 * 8 * 5, 0x3000: 48 * 8 * 5, 0x4000: 5}
     ok = [0x1000, 0x4000, 0x2000, None, 0x3000, 5]

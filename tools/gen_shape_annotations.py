@@ -111,8 +111,8 @@ S["pairing_host_bytes"] = "p_be=u8[64*n] q_be=u8[128*n] gt_aos=u64[48*n] status_
 S["bls_verify_host_bytes"] = "pk_be=u8[128*n] msgs=u8[*]? msg_offsets=u64[n+1] sig_be=u8[64*n] ok=u8[n] status_pk=u8[n] status_sig=u8[n]"
 
 
-def main():
-    text = open(HDR).read()
+def render(text):
+    """header text -> header text with exactly one @shape line in front of every prototype listed in S (idempotent)"""
     text = re.sub(r"/\* @shape [^\n]*? \*/\n", "", text)
     done = set()
 
@@ -125,8 +125,13 @@ def main():
     text = re.sub(r"^(int32_t)\s+(sylow_hip_\w+)\s*\(", repl, text, flags=re.M)
     missing = set(S) - done
     assert not missing, missing
+    return text, len(done)
+
+
+def main():
+    text, n = render(open(HDR).read())
     open(HDR, "w").write(text)
-    print(f"{len(done)} prototypes annotated")
+    print(f"{n} prototypes annotated")
 
 
 if __name__ == "__main__":
