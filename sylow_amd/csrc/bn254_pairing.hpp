@@ -292,6 +292,15 @@ struct OpsF29 {
   static BN_DEV F norm_sub3(const F& a, const F& b) { return f29_norm_sub3(a, b); }
   static BN_DEV F mul_b3_lazy(const F& a) { return mul_b3(a); }            // a reduce pass over 64-bit terms: any 32-bit limbs
 };
+// OpsF29 with the product / squaring INLINED at their call sites (no 18 + 9 argument / result moves, no call): for loops small enough to stay in
+// the instruction cache with 22 inlined leaves (the G1 window loop: 8 per doubling, 14 per addition).  BN_G1_INL selects it (A/B: 0).
+struct OpsF29I : OpsF29 {
+  static BN_DEV F mul(const F& a, const F& b) { return f29_mul(a, b); }
+  static BN_DEV F sqr(const F& a) { return f29_sqr(a); }
+};
+#ifndef BN_G1_INL
+#define BN_G1_INL 1
+#endif
 typedef Proj<F29> G1W;
 BN_DEV F29 f29_from_fp_reduced(const Fp& a) {
   const F29 t = f29_from_fp(a);
@@ -464,8 +473,13 @@ BN_DEV G1P g1_scalar_mul_t(G1P p, const u32 (&k)[8], TAB& tab) {
   glv_digits(d2, m2);
   // beta 2^261 mod p
   const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};
+#if BN_G1_INL
+  auto dbl = [](const G1W& a) { return proj_double_lazy<OpsF29I>(a); };
+  auto add = [](const G1W& a, const G1W& b) { return proj_add_lazy<OpsF29I>(a, b); };
+#else
   auto dbl = [](const G1W& a) { return proj_double_lazy<OpsF29>(a); };
   auto add = [](const G1W& a, const G1W& b) { return proj_add_lazy<OpsF29>(a, b); };
+#endif
   {
     G1W t1{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
     // an identity handed over as (x : y : 0) becomes the canonical (0 : 1 : 0): the complete formulas keep Z = 0 only
