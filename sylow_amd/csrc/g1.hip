@@ -145,7 +145,7 @@ __global__ void HEAVY_BOUNDS k_g1_generator_mul(const u64* ks, const i32* __rest
     q1.x = OpsF29::select(OpsF29::zero(), ex, nz);
     q1.y = OpsF29::select(OpsF29::one(), OpsF29::select(ey, OpsF29::neg(ey), d < 0), nz);
     q1.z = OpsF29::select(OpsF29::zero(), OpsF29::one(), nz);
-    res = proj_add_lazy<OpsF29>(res, q1);
+    res = proj_add_lazy<OpsF29>(res, q1);                        // leaves out of line: inlined (OpsF29I) this loop measured 3.25 against 3.14 ms per 2^20
   }
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, G1P{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)});

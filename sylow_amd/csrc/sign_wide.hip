@@ -48,15 +48,16 @@ BN_DEV F29 xq_f29(const F29& a) {
 }
 
 // proj_double_lazy<OpsF29> (bn254_pairing.hpp) with its eight products on the four lanes of a quad, two levels.  p replicated, N-class.
+// The products are INLINED (OpsF29I): a lone wavefront pays for every instruction, the 27 argument / result moves and the call included.
 // No identity select: the accumulators and table entries here only ever hold the CANONICAL identity (0 : 1 : 0), which the formulas map to itself.
 BN_DEV G1W qdouble(const G1W& p, int j) {
-  const F29 m1 = OpsF29::mul(qsel(j, p.y, p.y, p.z, p.x), qsel(j, p.y, p.z, p.z, p.y));
+  const F29 m1 = OpsF29I::mul(qsel(j, p.y, p.y, p.z, p.x), qsel(j, p.y, p.z, p.z, p.y));
   const F29 t0 = qb<0>(m1), t1 = qb<1>(m1), zz = qb<2>(m1), xy = qb<3>(m1);      // y^2, y z, z^2, x y
   const F29 z8 = f29_norm_x8(t0);
   const F29 t2 = OpsF29::mul_b3(zz);
   const F29 s = f29_norm(f29_add(t0, t2));
   const F29 d = f29_norm_sub3(t0, t2);
-  const F29 m2 = OpsF29::mul(qsel(j, t2, t1, d, d), qsel(j, z8, z8, s, xy));
+  const F29 m2 = OpsF29I::mul(qsel(j, t2, t1, d, d), qsel(j, z8, z8, s, xy));
   const F29 x3a = qb<0>(m2), z3 = qb<1>(m2), y3a = qb<2>(m2), x3b = qb<3>(m2);
   return G1W{f29_norm(f29_add(x3b, x3b)), f29_norm(f29_add(x3a, y3a)), z3};
 }
@@ -64,10 +65,10 @@ BN_DEV G1W qdouble(const G1W& p, int j) {
 BN_DEV G1W qadd(const G1W& p, const G1W& q, int j) {
   const F29 pxy = f29_sub(p.x, p.y), qxy = f29_sub(q.x, q.y), pyz = f29_sub(p.y, p.z), qyz = f29_sub(q.y, q.z),
             pxz = f29_sub(p.x, p.z), qxz = f29_sub(q.x, q.z);
-  const F29 m1 = OpsF29::mul(qsel(j, p.x, p.y, p.z, pxy), qsel(j, q.x, q.y, q.z, qxy));
+  const F29 m1 = OpsF29I::mul(qsel(j, p.x, p.y, p.z, pxy), qsel(j, q.x, q.y, q.z, qxy));
   F29 t0 = qb<0>(m1), t1 = qb<1>(m1), t2 = qb<2>(m1);
   const F29 c3 = qb<3>(m1);
-  const F29 m2 = OpsF29::mul(qsel(j, pyz, pxz, pyz, pxz), qsel(j, qyz, qxz, qyz, qxz));
+  const F29 m2 = OpsF29I::mul(qsel(j, pyz, pxz, pyz, pxz), qsel(j, qyz, qxz, qyz, qxz));
   const F29 c4 = qb<0>(m2), c5 = qb<1>(m2);
   const F29 t3 = f29_norm(f29_sub(f29_add(t0, t1), c3));            // x1 y2 + x2 y1
   const F29 t4 = f29_norm(f29_sub(f29_add(t1, t2), c4));            // y1 z2 + y2 z1
@@ -77,9 +78,9 @@ BN_DEV G1W qadd(const G1W& p, const G1W& q, int j) {
   const F29 z3 = f29_norm(f29_add(t1, t2));
   t1 = f29_sub(t1, t2);                                             // product operand only
   y3 = OpsF29::mul_b3_lazy(y3);
-  const F29 m3 = OpsF29::mul(qsel(j, t3, t4, t1, y3), qsel(j, t1, y3, z3, t0));
+  const F29 m3 = OpsF29I::mul(qsel(j, t3, t4, t1, y3), qsel(j, t1, y3, z3, t0));
   const F29 a = qb<0>(m3), b = qb<1>(m3), c = qb<2>(m3), d = qb<3>(m3);
-  const F29 m4 = OpsF29::mul(qsel(j, z3, t0, z3, t0), qsel(j, t4, t3, t4, t3));
+  const F29 m4 = OpsF29I::mul(qsel(j, z3, t0, z3, t0), qsel(j, t4, t3, t4, t3));
   const F29 e = qb<0>(m4), f = qb<1>(m4);
   return G1W{f29_norm(f29_sub(a, b)), f29_norm(f29_add(c, d)), f29_norm(f29_add(e, f))};
 }
