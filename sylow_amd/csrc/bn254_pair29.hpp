@@ -725,6 +725,14 @@ BN_NOINLINE void final_exponentiation29(S12& out, const S12& fin) {
 }
 
 
+// The product of the one-wavefront-per-element routines below is INLINED: they run one wavefront per SIMD by nature, and a lone wavefront pays
+// for every instruction -- the 27 argument / result moves and the call of the out-of-line leaf included (wide signing: 1.05 -> 1.01 ms).
+// BN_WIDE_LEAF_CALL restores the call (A/B runs).
+#ifdef BN_WIDE_LEAF_CALL
+BN_DEV W2 w2_mul_w(const W2& a, const W2& b) { return w2_mul(a, b); }
+#else
+BN_DEV W2 w2_mul_w(const W2& a, const W2& b) { return w2_mul_inl(a, b); }
+#endif
 // ---- ONE final exponentiation on a whole wavefront ("wide"): the tail of every one-boolean shape -----------------------------------
 // A single element on one lane pair is pure latency: the wavefront issues a multiply-add every ~8 cycles and 62 of its 64 lanes idle
 // (2.4-2.9 ms per final exponentiation).  Here ALL 32 lane pairs of a one-wavefront block hold the SAME element (replicated: same code,
@@ -754,7 +762,7 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
   {
     const W2 a = w2_sel3(k, z0, z2, z4), b = w2_sel3(k, z1, z3, z5);
     const W2 xs = w2_pick(a, w2_norm(w2_add(a, b)), s), ys = w2_pick(b, w2_xi_norm(b, a), s);
-    const W2 pr = w2_mul(xs, ys);
+    const W2 pr = w2_mul_w(xs, ys);
     if (j < 6) wide_put(x, p, odd, pr);
   }
   __syncthreads();
@@ -811,7 +819,7 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
     const W2 xa = wide_get(x, ba + i0, odd), xb = wide_get(x, ba + i1, odd);
     const W2 ya = wide_get(x, bb + i0, odd), yb = wide_get(x, bb + i1, odd);
     const W2 xs = w2_pick(xa, w2_norm(w2_add(xa, xb)), h >= 3), ys = w2_pick(ya, w2_norm(w2_add(ya, yb)), h >= 3);
-    const W2 pr = w2_mul(xs, ys);
+    const W2 pr = w2_mul_w(xs, ys);
     if (j < 18) wide_put(x, WL_P + w, odd, pr);
   }
   __syncthreads();
@@ -918,7 +926,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
     const int p = j < 5 ? j : 0;
     const W2 a = w2_pick(w2_pick(w2_pick(r.x, r.y, p == 2), r.z, p == 3), yz, p == 4);        // 0, 1: x   2: y   3: z   4: y + z
     const W2 b = w2_pick(a, r.y, p == 0);                                                       // 0: y, else the same operand (a square)
-    const W2 pr = w2_mul(a, b);
+    const W2 pr = w2_mul_w(a, b);
     if (j < 5) wide_put(x, WL_P + p, odd, pr);
   }
   __syncthreads();
@@ -927,7 +935,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
   const W2 a = w2_halve(xy);
   l2 = w2_norm(w2_triple(xx));
   const W2 h = w2_norm(w2_sub(s, w2_add(b, c)));
-  const W2 e = ISO ? w2_mul_27m3u(c) : w2_mul(w2_twist_b(), w2_norm(w2_triple(c)));      // E'': (9 - u) * 3c in one reduce pass
+  const W2 e = ISO ? w2_mul_27m3u(c) : w2_mul_w(w2_twist_b(), w2_norm(w2_triple(c)));      // E'': (9 - u) * 3c in one reduce pass
   l1 = w2_neg(h);
   l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);
   const W2 f = w2_norm(w2_triple(e));
@@ -936,7 +944,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
     const int p = j < 4 ? j : 0;
     const W2 u = w2_pick(w2_pick(w2_pick(b, a, p == 1), g, p == 2), e, p == 3);                 // 0: b   1: a   2: g   3: e
     const W2 v = w2_pick(w2_pick(w2_pick(h, w2_sub(b, f), p == 1), g, p == 2), e, p == 3);     // 0: h   1: b - f   2: g   3: e
-    const W2 pr = w2_mul(u, v);
+    const W2 pr = w2_mul_w(u, v);
     if (j < 4) wide_put(x, WL_T + p, odd, pr);
   }
   __syncthreads();
@@ -949,7 +957,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
 BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
   {   // level 1: z bx, z by
-    const W2 pr = w2_mul(r.z, w2_pick(bx, by, j == 1));
+    const W2 pr = w2_mul_w(r.z, w2_pick(bx, by, j == 1));
     if (j < 2) wide_put(x, WL_P + j, odd, pr);
   }
   __syncthreads();
@@ -961,7 +969,7 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
     const int p = j < 4 ? j : 0;
     const W2 u = w2_pick(w2_pick(w2_pick(e, d, p == 1), dn, p == 2), en, p == 3);
     const W2 v = w2_pick(w2_pick(w2_pick(bx, by, p == 1), dn, p == 2), en, p == 3);
-    const W2 pr = w2_mul(u, v);
+    const W2 pr = w2_mul_w(u, v);
     if (j < 4) wide_put(x, WL_T + p, odd, pr);
   }
   __syncthreads();
@@ -971,7 +979,7 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
     const int p = j < 3 ? j : 0;
     const W2 u = w2_pick(w2_pick(dn, r.x, p == 1), r.z, p == 2);
     const W2 v = w2_pick(f, e2, p == 2);
-    const W2 pr = w2_mul(u, v);
+    const W2 pr = w2_mul_w(u, v);
     if (j < 3) wide_put(x, WL_P + p, odd, pr);
   }
   __syncthreads();
@@ -981,7 +989,7 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
     const int p = j < 4 ? j : 0;
     const W2 u = w2_pick(w2_pick(w2_pick(r.z, dn, p == 1), en, p == 2), h, p == 3);
     const W2 v = w2_pick(w2_pick(w2_pick(h, jj, p == 1), w2_sub(i, jj), p == 2), r.y, p == 3);
-    const W2 pr = w2_mul(u, v);
+    const W2 pr = w2_mul_w(u, v);
     if (j < 4) wide_put(x, WL_T + 4 + p, odd, pr);
   }
   __syncthreads();
