@@ -69,6 +69,23 @@ def test_driver_bench_command_n_ranks_rccl():
         assert bad["config"]["bls_all_valid"] == 0 and bad["aux"]["aggregate_all_valid"] == 0 and bad["aux"]["strong"]["bls_all_valid"] == 0
 
 
+@needs_two
+def test_bare_bench_command_spawns_n_ranks_rccl():
+    """`python bench.py --gpus N` with no launcher (round 5: the parent starts its own ranks through torch.distributed.run): backend nccl, one
+    rank per GPU, one JSON line, the native communicator on every rank."""
+    for n in rank_counts():
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "SYLOW_BENCH_BACKEND", "SYLOW_BENCH_SINGLE_DEVICE"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--log2n", "16", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-aux"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["collective_backend"] == "nccl" and out["config"]["bls_all_valid"] == 1
+
+
 def test_preflight_is_armed():
     """Runs everywhere: the rank script parses, and the skip condition is the device count, nothing else."""
     import ast
