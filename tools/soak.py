@@ -58,6 +58,14 @@ while time.time() - t0 < budget:
     sk = base_k[s:s + nv]
     msgs = [bytes([(i * 7 + rounds) & 255] * (1 + (i % 40))) for i in range(nv)]
     sig, sinf = eng.bls_sign(sk, msgs)
+    sig2, _ = eng.bls_sign(sk, msgs)
+    assert np.array_equal(sig, sig2), ("sign nondeterministic", nv)
+    ks = [int(rng.next() % nv) for _ in range(3)]          # a slice of the signatures and hashes against the oracle (eight-lane routes below 8192)
+    es, _ = C.g1_to_affine(C.sign(sk[ks], [msgs[i] for i in ks]))
+    assert np.array_equal(sig[ks], es), ("sign parity", nv, ks)
+    hx, _ = eng.hash_to_g1([msgs[i] for i in ks])
+    eh, _ = C.g1_to_affine(C.hash_to_curve([msgs[i] for i in ks]))
+    assert np.array_equal(hx, eh), ("hash_to_g1 parity", nv, ks)
     pk, _ = eng.g2_scalar_mul(np.repeat(pack(G2, 16), nv, 0), sk)
     badi = set(int(rng.next() % nv) for _ in range(3))
     sigb = sig.copy()
@@ -79,5 +87,5 @@ while time.time() - t0 < budget:
     assert ok_all == 1 and ok_bad == (1 if same_multiset else 0), ("aggregate", n, ok_all, ok_bad, same_multiset)
     gt_a, _ = eng.bls_aggregate_verify(pk, msgs, sigb); gt_b, _ = eng.bls_aggregate_verify(pk, msgs, sigb)
     assert np.array_equal(gt_a, gt_b), ("aggregate nondeterministic", n)
-    rounds += 1; checks += 12
+    rounds += 1; checks += 15
 print(f"soak ok: {rounds} rounds, {checks} cross-checks, {time.time() - t0:.0f} s")
