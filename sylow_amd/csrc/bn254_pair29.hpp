@@ -741,6 +741,10 @@ BN_DEV W2 w2_mul_w(const W2& a, const W2& b) { return w2_mul_inl(a, b); }
 // every lane pair holds the square again.  Same formulas, same operand classes and therefore the same digits as w12_cyclotomic_sqr.
 struct WideLds { i32 v[63][9][2]; };               // [slot][limb][lane parity]; squaring: 6 products + 6 outputs; product: slots 12 .. 62
 typedef __attribute__((address_space(3))) WideLds* WideLdsPtr;
+// EPW = elements per wavefront.  1: all 32 lane pairs hold the same element.  2: lanes 0-31 and 32-63 hold one element each (16 lane pairs,
+// each half with its own WideLds): batches of 1025 .. 4096 elements then still run one or two wavefronts per SIMD.  The only level with more
+// than 16 products (the 18 of the dense Fp12 product) takes a second pass on two lane pairs.
+template <int EPW> BN_DEV int wide_j(int lane) { return (int)pair_index((u32)lane) & (32 / EPW - 1); }
 BN_DEV void wide_put(WideLdsPtr x, int slot, int odd, const W2& a) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) x->v[slot][i][odd] = a.c.v[i];
@@ -753,8 +757,9 @@ BN_DEV W2 wide_get(WideLdsPtr x, int slot, int odd) {
 }
 BN_DEV W2 w2_pick(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }                // c ? b : a
 BN_DEV W2 w2_sel3(int k, const W2& a, const W2& b, const W2& c) { return w2_pick(w2_pick(a, b, k == 1), c, k == 2); }
+template <int EPW = 1>
 BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   const int p = j < 6 ? j : 0, k = p >> 1;
   const bool s = (p & 1) != 0;
   const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
@@ -794,45 +799,88 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
 // Slots: the operands' coefficients IA / IB (lane pair c < 6 writes coefficient c of each), the coefficient sums of the third Fp6 product
 // SA / SB, the products P[6 g + h] (g: which Fp6 product, h: v0 v1 v2 and the three cross products), the nine Fp6 coefficients T[3 g + c],
 // the six outputs.  Every value goes through exactly the operations of w12_mul, so the digits are the same.
+// KIND (what a wavefront half of 16 lane pairs needs to stay at ONE product level):
+//   WK_DENSE   any a, b: 18 products (EPW = 2: 16 + 2 in two passes)
+//   WK_LINE    b = (l0, 0, l2; 0, l4, 0), a line of the Miller loop: four of the 18 products have a zero factor -- 14 products, zeros stored
+//   WK_SQUARE  a^2 (b ignored) as the complex squaring of fp12.rs:536-550, c1 = 2 t, c0 = (a0 + a1)(a0 + v a1) - t - v t with t = a0 a1:
+//              two Fp6 products, 12 products; t takes the place of the first Fp6 product, the other one that of the third
 constexpr int WL_IA = 12, WL_IB = 18, WL_SA = 24, WL_SB = 27, WL_P = 30, WL_T = 48, WL_OUT = 57;
+constexpr int WK_DENSE = 0, WK_LINE = 1, WK_SQUARE = 2;
+#ifndef BN_WIDE_KINDS
+#define BN_WIDE_KINDS 1      // 0: the Miller loop of the wide routines with dense products only (A/B runs)
+#endif
 BN_DEV W2 w12_coef(const W12& a, int c) {      // c = 3 * half + i
   const W2 lo = w2_sel3(c % 3, a.c0.c0, a.c0.c1, a.c0.c2), hi = w2_sel3(c % 3, a.c1.c0, a.c1.c1, a.c1.c2);
   return w2_pick(lo, hi, c >= 3);
 }
+template <int EPW = 1, int KIND = WK_DENSE>
 BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
+  const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   {   // stage 0: coefficients and the sums a.c0 + a.c1, b.c0 + b.c1 into LDS
     const int c = j < 6 ? j : 0;
-    const W2 ac = w12_coef(a, c), bc = w12_coef(b, c);
     const int i = c % 3;
-    const W2 sa = w2_norm(w2_add(w2_sel3(i, a.c0.c0, a.c0.c1, a.c0.c2), w2_sel3(i, a.c1.c0, a.c1.c1, a.c1.c2)));
-    const W2 sb = w2_norm(w2_add(w2_sel3(i, b.c0.c0, b.c0.c1, b.c0.c2), w2_sel3(i, b.c1.c0, b.c1.c1, b.c1.c2)));
-    if (j < 6) { wide_put(x, WL_IA + c, odd, ac); wide_put(x, WL_IB + c, odd, bc); }
-    if (j < 3) wide_put(x, WL_SA + i, odd, sa);
-    if (j >= 3 && j < 6) wide_put(x, WL_SB + i, odd, sb);
+    const W2 a0i = w2_sel3(i, a.c0.c0, a.c0.c1, a.c0.c2), a1i = w2_sel3(i, a.c1.c0, a.c1.c1, a.c1.c2);
+    const W2 sa = w2_norm(w2_add(a0i, a1i));
+    if (KIND == WK_SQUARE) {
+      // a0 + v a1 = (a0.c0 + xi a1.c2, a0.c1 + a1.c0, a0.c2 + a1.c1)
+      const W2 sb0 = w2_xi_lin(a.c1.c2, 1, a.c0.c0, 1);
+      const W2 sb12 = w2_norm(w2_add(a0i, w2_pick(a.c1.c0, a.c1.c1, i == 2)));
+      if (j < 3) { wide_put(x, WL_IA + i, odd, a0i); wide_put(x, WL_IB + i, odd, a1i); wide_put(x, WL_SA + i, odd, sa); }
+      if (j >= 3 && j < 6) wide_put(x, WL_SB + i, odd, w2_pick(sb12, sb0, i == 0));
+    } else {
+      const W2 ac = w2_pick(a0i, a1i, c >= 3), bc = w12_coef(b, c);
+      const W2 sb = w2_norm(w2_add(w2_sel3(i, b.c0.c0, b.c0.c1, b.c0.c2), w2_sel3(i, b.c1.c0, b.c1.c1, b.c1.c2)));
+      if (j < 6) { wide_put(x, WL_IA + c, odd, ac); wide_put(x, WL_IB + c, odd, bc); }
+      if (j < 3) wide_put(x, WL_SA + i, odd, sa);
+      if (j >= 3 && j < 6) wide_put(x, WL_SB + i, odd, sb);
+    }
   }
   __syncthreads();
-  {   // stage 1: product w = 6 g + h
-    const int w = j < 18 ? j : 0, g = w / 6, h = w % 6;
+#pragma unroll
+  for (int pass = 0; pass < (KIND == WK_DENSE ? EPW : 1); ++pass) {   // stage 1: product w = 6 g + h
+    int w;
+    bool live;
+    if (KIND == WK_DENSE) {
+      const int jw = j + 16 * pass;                                   // EPW = 2: products 16, 17 in a second pass
+      live = jw < 18;
+      w = live ? jw : 0;
+    } else if (KIND == WK_LINE) {                                     // products 1, 6, 8, 11 have a zero factor (h = 3, 4, 5: pairs 12, 01, 02)
+      live = j < 14;
+      w = live ? j + (j >= 1) + (j >= 5) + (j >= 6) + (j >= 8) : 0;   // 0 2 3 4 5 7 9 10 12 .. 17
+    } else {                                                          // t = a0 a1 (g = 0), (a0 + a1)(a0 + v a1) (g = 2)
+      live = j < 12;
+      w = j < 6 ? j : live ? j + 6 : 0;
+    }
+    const int g = w / 6, h = w % 6;
     const int i0 = h < 3 ? h : h == 3 ? 1 : 0, i1 = h < 3 ? h : h == 4 ? 1 : 2;
     const int ba = g == 0 ? WL_IA : g == 1 ? WL_IA + 3 : WL_SA, bb = g == 0 ? WL_IB : g == 1 ? WL_IB + 3 : WL_SB;
     const W2 xa = wide_get(x, ba + i0, odd), xb = wide_get(x, ba + i1, odd);
     const W2 ya = wide_get(x, bb + i0, odd), yb = wide_get(x, bb + i1, odd);
     const W2 xs = w2_pick(xa, w2_norm(w2_add(xa, xb)), h >= 3), ys = w2_pick(ya, w2_norm(w2_add(ya, yb)), h >= 3);
     const W2 pr = w2_mul_w(xs, ys);
-    if (j < 18) wide_put(x, WL_P + w, odd, pr);
+    if (live) wide_put(x, WL_P + w, odd, pr);
+    if (KIND == WK_LINE && j < 4) wide_put(x, WL_P + (j == 0 ? 1 : j == 1 ? 6 : j == 2 ? 8 : 11), odd, zero);
   }
   __syncthreads();
-  {   // stage 2: Fp6 coefficient u = 3 g + c of the three Fp6 products (w6_mul)
-    const int u = j < 9 ? j : 0, g = u / 3, c = u % 3, base = WL_P + 6 * g;
+  {   // stage 2: Fp6 coefficient u = 3 g + c of the three Fp6 products (w6_mul); WK_SQUARE: of the first and the third
+    const int nu = KIND == WK_SQUARE ? 6 : 9;
+    const int u = j >= nu ? 0 : (KIND == WK_SQUARE && j >= 3) ? j + 3 : j, g = u / 3, c = u % 3, base = WL_P + 6 * g;
     const W2 v0 = wide_get(x, base, odd), v1 = wide_get(x, base + 1, odd), v2 = wide_get(x, base + 2, odd), q = wide_get(x, base + 3 + c, odd);
     const W2 r0 = w2_xi_lin(w2_sub(w2_sub(q, v1), v2), 1, v0, 1);               // v0 + xi (q0 - v1 - v2)
     const W2 r1 = w2_xi_lin(v2, 1, w2_sub(w2_sub(q, v0), v1), 1);               // (q1 - v0 - v1) + xi v2
     const W2 r2 = w2_reduce(w2_add(w2_sub(w2_sub(q, v0), v2), v1));             // q2 - v0 - v2 + v1
-    if (j < 9) wide_put(x, WL_T + u, odd, w2_sel3(c, r0, r1, r2));
+    if (j < nu) wide_put(x, WL_T + u, odd, w2_sel3(c, r0, r1, r2));
   }
   __syncthreads();
-  {   // stage 3: output o (w12_mul): c1.ci = T2.ci - T0.ci - T1.ci;  c0.c0 = T0.c0 + xi T1.c2;  c0.c1 = T0.c1 + T1.c0;  c0.c2 = T0.c2 + T1.c1
+  if (KIND == WK_SQUARE) {   // stage 3: c1.ci = 2 t.ci;  c0.c0 = m.c0 - t.c0 - xi t.c2;  c0.c1 = m.c1 - t.c1 - t.c0;  c0.c2 = m.c2 - t.c2 - t.c1
+    const int o = j < 6 ? j : 0, i = o % 3;
+    const W2 ti = wide_get(x, WL_T + i, odd), tp = wide_get(x, WL_T + (i + 2) % 3, odd), mi = wide_get(x, WL_T + 6 + i, odd);
+    const W2 ra = w2_norm(w2_add(ti, ti));
+    const W2 rb = w2_xi_lin(tp, -1, w2_sub(mi, ti), 1);
+    const W2 rc = w2_lin2(w2_sub(mi, ti), 1, tp, -1);
+    if (j < 6) wide_put(x, WL_OUT + o, odd, o >= 3 ? ra : o == 0 ? rb : rc);
+  } else {   // stage 3: output o (w12_mul): c1.ci = T2.ci - T0.ci - T1.ci;  c0.c0 = T0.c0 + xi T1.c2;  c0.c1 = T0.c1 + T1.c0;  c0.c2 = T0.c2 + T1.c1
     const int o = j < 6 ? j : 0, i = o % 3;
     const int pa = o >= 3 ? i : o, pb = o >= 3 ? 3 + i : o == 0 ? 5 : o == 1 ? 3 : 4, pc = o >= 3 ? 6 + i : 0;
     const W2 ta = wide_get(x, WL_T + pa, odd), tb = wide_get(x, WL_T + pb, odd), tc = wide_get(x, WL_T + pc, odd);
@@ -847,12 +895,14 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
   r.c1.c0 = wide_get(x, WL_OUT + 3, odd); r.c1.c1 = wide_get(x, WL_OUT + 4, odd); r.c1.c2 = wide_get(x, WL_OUT + 5, odd);
   return r;
 }
+template <int EPW = 1, int KIND = WK_DENSE>
 BN_NOINLINE void w12_mul_wide_nl(W12& r, const W12& a, const W12& b, WideLds* xg) {
   W12 p = a, q = b;
   w12_pin(p); w12_pin(q);
-  r = w12_mul_wide(p, q, (WideLdsPtr)xg);
+  r = w12_mul_wide<EPW, KIND>(p, q, (WideLdsPtr)xg);
 }
 // exp_by_neg_z29 with the loop's squarings and products spread over the wavefront
+template <int EPW = 1>
 BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
   const WideLdsPtr x = (WideLdsPtr)xg;
   W12 tab[2];                                     // f^17, f^35: the chain of exp_by_neg_z29
@@ -862,65 +912,66 @@ BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
     w12_cyclotomic_sqr_nl(u, t);
     w12_cyclotomic_sqr_nl(t, u);
     w12_cyclotomic_sqr_nl(u, t);
-    w12_mul_wide_nl(tab[0], u, f, xg);
+    w12_mul_wide_nl<EPW>(tab[0], u, f, xg);
     w12_cyclotomic_sqr_nl(t, tab[0]);
-    w12_mul_wide_nl(tab[1], t, f, xg);
+    w12_mul_wide_nl<EPW>(tab[1], t, f, xg);
   }
   W12 res = tab[1];
   const u64 nz = BN_X_C_NZ, ng = BN_X_C_NEG, i17 = BN_X_C_17;
 #pragma unroll 1
   for (int i = 56; i >= 0; --i) {
-    res = w12_cyclotomic_sqr_wide(res, x);
+    res = w12_cyclotomic_sqr_wide<EPW>(res, x);
     if ((nz >> i) & 1) {
       W12 m = tab[((i17 >> i) & 1) ? 0 : 1];
       if ((ng >> i) & 1) m = w12_conj(m);
-      res = w12_mul_wide(res, m, x);
+      res = w12_mul_wide<EPW>(res, m, x);
     }
   }
   r = w12_conj(res);
 }
 // final_exponentiation29 for a one-wavefront block whose 32 lane pairs all hold the same element
+template <int EPW = 1>
 BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* x) {
   W12 in, t, a, b, d, e, g;
   {
     w12_from_s12(t, fin);
     w12_inv_nl(b, t);
     a = w12_conj(t);
-    w12_mul_wide_nl(d, a, b, x);
+    w12_mul_wide_nl<EPW>(d, a, b, x);
     w12_frobenius_nl<2>(a, d);
-    w12_mul_wide_nl(in, a, d, x);
+    w12_mul_wide_nl<EPW>(in, a, d, x);
   }
-  exp_by_neg_z29_wide(a, in, x);
+  exp_by_neg_z29_wide<EPW>(a, in, x);
   w12_cyclotomic_sqr_nl(b, a);
   w12_cyclotomic_sqr_nl(t, b);
-  w12_mul_wide_nl(d, t, b, x);
-  exp_by_neg_z29_wide(e, d, x);
+  w12_mul_wide_nl<EPW>(d, t, b, x);
+  exp_by_neg_z29_wide<EPW>(e, d, x);
   w12_cyclotomic_sqr_nl(t, e);
-  exp_by_neg_z29_wide(g, t, x);
+  exp_by_neg_z29_wide<EPW>(g, t, x);
   d = w12_conj(d);
   g = w12_conj(g);
-  w12_mul_wide_nl(t, g, e, x);
-  w12_mul_wide_nl(a, t, d, x);
-  w12_mul_wide_nl(d, a, b, x);
-  w12_mul_wide_nl(t, a, e, x);
-  w12_mul_wide_nl(e, in, t, x);
+  w12_mul_wide_nl<EPW>(t, g, e, x);
+  w12_mul_wide_nl<EPW>(a, t, d, x);
+  w12_mul_wide_nl<EPW>(d, a, b, x);
+  w12_mul_wide_nl<EPW>(t, a, e, x);
+  w12_mul_wide_nl<EPW>(e, in, t, x);
   w12_frobenius_nl<1>(t, d);
-  w12_mul_wide_nl(b, t, e, x);
+  w12_mul_wide_nl<EPW>(b, t, e, x);
   w12_frobenius_nl<2>(t, a);
-  w12_mul_wide_nl(e, t, b, x);
+  w12_mul_wide_nl<EPW>(e, t, b, x);
   t = w12_conj(in);
-  w12_mul_wide_nl(a, t, d, x);
+  w12_mul_wide_nl<EPW>(a, t, d, x);
   w12_frobenius_nl<3>(t, a);
-  w12_mul_wide_nl(g, t, e, x);
+  w12_mul_wide_nl<EPW>(g, t, e, x);
   w12_to_s12(out, g);
 }
 
 // g2_doubling_step29 with its ten products in three levels: five on five lane pairs (x y, x^2, y^2, z^2, (y + z)^2), the twist-constant
 // product replicated (one product: nothing to spread), four on four lane pairs (b h, a (b - f), g^2, e^2).  Inputs and outputs replicated;
 // the squares are taken with the product leaf (same values).  Products of level 1 meet in the P slots, those of level 3 in the T slots.
-template <bool ISO = false>
+template <bool ISO = false, int EPW = 1>
 BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   {
     const W2 yz = w2_norm(w2_add(r.y, r.z));
     const int p = j < 5 ? j : 0;
@@ -954,8 +1005,9 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
 }
 // g2_addition_step29 with its thirteen products in four levels (2 + 4 + 3 + 4 lane pairs); inputs and outputs replicated.  Levels 1 and 3
 // meet in the P slots, levels 2 and 4 in the T slots (a barrier separates every reuse).
+template <int EPW = 1>
 BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
-  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = (int)pair_index((u32)lane);
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   {   // level 1: z bx, z by
     const W2 pr = w2_mul_w(r.z, w2_pick(bx, by, j == 1));
     if (j < 2) wide_put(x, WL_P + j, odd, pr);
@@ -1003,7 +1055,7 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
 // sparse form on one.  With ISO = false: same field values step by step, so the raw Miller value (canonical at the exit) is the reference's.
 // ISO: on (phi P, phi Q) with the twist constant 9 - u (g2_doubling_step29): the value is the reference's Miller value times a factor in Fp* --
 // every caller feeds it to a final exponentiation (the raw-value entry points use the lane-pair kernels with ISO = false)
-template <bool ISO>
+template <bool ISO, int EPW = 1>
 BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, const S2& qxs_in, const S2& qys_in, WideLds* xg) {
   F29 px = f29_reduce(f29_from_fp(pxs)), py = f29_reduce(f29_from_fp(pys));
   W2 qx = w2_from_s2(qxs_in), qy = w2_from_s2(qys_in);
@@ -1025,25 +1077,25 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
     W12 ln;
     ln.c0.c0 = l0; ln.c0.c1 = zero; ln.c0.c2 = w2_scale(l2, px);
     ln.c1.c0 = zero; ln.c1.c1 = w2_scale(l1, py); ln.c1.c2 = zero;
-    w12_mul_wide_nl(f, f, ln, xg);
+    w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, f, ln, xg);
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
-    w12_mul_wide_nl(f, f, f, xg);
-    g2_doubling_step29_wide<ISO>(r, l0, l1, l2, (WideLdsPtr)xg);
+    w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, f, xg);
+    g2_doubling_step29_wide<ISO, EPW>(r, l0, l1, l2, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
-      g2_addition_step29_wide(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, (WideLdsPtr)xg);
+      g2_addition_step29_wide<EPW>(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, (WideLdsPtr)xg);
       line();
     }
   }
   S2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qxs, qys);
   g2_psi_affine(q2x, q2y, q1x, q1y);
-  g2_addition_step29_wide(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2, (WideLdsPtr)xg);
+  g2_addition_step29_wide<EPW>(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2, (WideLdsPtr)xg);
   line();
-  g2_addition_step29_wide(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2, (WideLdsPtr)xg);
+  g2_addition_step29_wide<EPW>(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2, (WideLdsPtr)xg);
   line();
   w12_to_s12(fout, f);
 }

@@ -572,32 +572,52 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
   }
   if (pair_index(t) == 0) store_s12(fout, 1, 0, odd, f);
 }
-// Small batches, one WAVEFRONT per element (grid = n blocks of 64): block b takes pair b of set A, block n + b pair b of set B (B optional).
-// qxy NULL = the G2 generator for every pair of that set.  An identity on either side gives 1.  Miller values up to factors in Fp*
-// (isomorphic curves), SoA stride n: input of the k_final_exp_wide_* kernels only.
+// Small batches, one WAVEFRONT per EPW elements (EPW = 1: grid = n blocks of 64; EPW = 2: lanes 0-31 / 32-63 of a block hold one element
+// each): element e < n is pair e of set A, element n + e pair e of set B (B optional).  qxy NULL = the G2 generator for every pair of that
+// set.  An identity on either side gives 1.  Miller values up to factors in Fp* (isomorphic curves), SoA stride n: input of the
+// k_final_exp_wide_* kernels only.  The loop runs on whatever the rows hold and the identity is selected afterwards, so that both halves of
+// a wavefront reach every barrier together.
+template <int EPW>
 __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
                                                  const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n) {
-  __shared__ WideLds lds;
-  const bool second = blockIdx.x >= n;
-  const size_t i = second ? blockIdx.x - n : blockIdx.x;
+  __shared__ WideLds lds[EPW];
+  const size_t total = pb ? 2 * n : n;
+  const int half = EPW == 2 ? (int)(threadIdx.x >> 5) : 0;
+  const size_t e0 = (size_t)EPW * blockIdx.x + (size_t)half;
+  const bool live = e0 < total;
+  const size_t e = live ? e0 : total - 1;
+  const bool second = e >= n;
+  const size_t i = second ? e - n : e;
   const u64 *pxy = second ? pb : pa, *qxy = second ? qb : qa;
   const uint8_t *pinf = second ? pb_inf : pa_inf, *qinf = second ? qb_inf : qa_inf;
   u64* fout = second ? fb : fa;
   const int odd = pair_role(threadIdx.x);
+  const bool ident = (pinf && pinf[i]) || (qinf && qinf[i]);
   S12 f;
-  if ((pinf && pinf[i]) || (qinf && qinf[i])) {
-    f = s12_one();
+  if (EPW == 1) {
+    if (ident) {
+      f = s12_one();
+    } else {
+      const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+      const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
+      miller_loop29_wide<true, 1>(f, px, py, qx, qy, &lds[0]);
+    }
   } else {
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
     const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
-    miller_loop29_wide<true>(f, px, py, qx, qy, &lds);
+    miller_loop29_wide<true, EPW>(f, px, py, qx, qy, &lds[half]);
+    if (ident) f = s12_one();
   }
-  if (pair_index(threadIdx.x) == 0) store_s12(fout, n, i, odd, f);
+  if (live && wide_j<EPW>((int)(threadIdx.x & 63u)) == 0) store_s12(fout, n, i, odd, f);
 }
-// final_exponentiation(fa_b * fb_b) (fb optional), one wavefront per element: Gt values (SoA stride n) and / or "== identity" flags
+// final_exponentiation(fa_b * fb_b) (fb optional), one wavefront per EPW elements: Gt values (SoA stride n) and / or "== identity" flags
+template <int EPW>
 __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb, size_t n, u64* gout, uint8_t* is_one) {
-  __shared__ WideLds lds;
-  const size_t i = blockIdx.x;
+  __shared__ WideLds lds[EPW];
+  const int half = EPW == 2 ? (int)(threadIdx.x >> 5) : 0;
+  const size_t e0 = (size_t)EPW * blockIdx.x + (size_t)half;
+  const bool live = e0 < n;
+  const size_t i = live ? e0 : n - 1;
   const int odd = pair_role(threadIdx.x);
   S12 f, g;
   load_s12(f, fa, n, i, odd);
@@ -607,11 +627,11 @@ __global__ void HEAVY_BOUNDS k_final_exp_wide_batch(const u64* fa, const u64* fb
     W12 x, y, r;
     w12_from_s12(x, f);
     w12_from_s12(y, h);
-    w12_mul_wide_nl(r, x, y, &lds);
+    w12_mul_wide_nl<EPW>(r, x, y, &lds[half]);
     w12_to_s12(f, r);
   }
-  final_exponentiation29_wide(g, f, &lds);
-  if (pair_index(threadIdx.x) != 0) return;
+  final_exponentiation29_wide<EPW>(g, f, &lds[half]);
+  if (!live || wide_j<EPW>((int)(threadIdx.x & 63u)) != 0) return;
   if (gout) store_s12(gout, n, i, odd, g);
   const bool one = s12_is_one(g);
   if (is_one && !odd) is_one[i] = one ? 1 : 0;
@@ -767,15 +787,43 @@ static int wide_tail() {
   static const int v = [] { const char* e = getenv("SYLOW_HIP_WIDE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
   return v;
 }
+// SYLOW_HIP_WIDE_PACK=t: the small-batch kernels put two elements on a wavefront above t elements (0 = never, 1 = always: A/B runs and
+// tests/test_gpu_routes.py).  Default: the number of compute units -- one wavefront per CU is the fastest shape (1.72 ms per pairing up
+// to 256), a second wavefront on a CU already costs more (1.9 ms) than a wavefront of two elements (1.76 ms), and from there on the
+// packed form has half the wavefronts: 1024 pairings 1.91 against 2.11 ms, 2048 2.15 against 3.74 ms, 4096 3.8 against 4.25 ms.
+static size_t wide_pack() {
+  static const size_t v = [] {
+    const char* e = getenv("SYLOW_HIP_WIDE_PACK");
+    if (e) return (size_t)strtoull(e, nullptr, 10);
+    const unsigned cus = host::compute_units();
+    return (size_t)(cus ? cus : 256);
+  }();
+  return v;
+}
+// Two elements per wavefront (16 lane pairs each) cost a second product pass in the dense Fp12 products of the final exponentiation only.
+static void launch_miller_wide(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
+                               const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n, hipStream_t st) {
+  const size_t units = pb ? 2 * n : n;
+  if (wide_pack() && units > wide_pack())
+    plk::k_miller_wide_batch<2><<<dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n);
+  else
+    plk::k_miller_wide_batch<1><<<dim3((unsigned)units), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n);
+}
+static void launch_final_exp_wide(const u64* fa, const u64* fb, size_t n, u64* gout, uint8_t* is_one, hipStream_t st) {
+  if (wide_pack() && n > wide_pack())
+    plk::k_final_exp_wide_batch<2><<<dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st>>>(fa, fb, n, gout, is_one);
+  else
+    plk::k_final_exp_wide_batch<1><<<dim3((unsigned)n), dim3(64), 0, st>>>(fa, fb, n, gout, is_one);
+}
 namespace plkh {
-// Small batches on one wavefront per element (k_miller_wide_batch / k_final_exp_wide_batch): up to this many elements the latency route
-// beats the one-lane-pair kernels (2 n + n blocks against 2048 resident wavefronts; measured crossover ~ 3 k verifications)
-size_t wide_batch_max() { return wide_tail() ? 2048 : 0; }
+// Small batches on one wavefront per one or two elements (k_miller_wide_batch / k_final_exp_wide_batch): up to this many pairings the
+// latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each)
+size_t wide_batch_max() { return wide_tail() ? (wide_pack() ? 4096 : 2048) : 0; }
 // pairing(P_i, Q_i), i < n: raw values through `scratch` (48 n words), Gt values to gt_out (SoA stride n)
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  plk::k_miller_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(p_xy, p_inf, q_xy, q_inf, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, n);
-  plk::k_final_exp_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(scratch, nullptr, n, gt_out, nullptr);
+  launch_miller_wide(p_xy, p_inf, q_xy, q_inf, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, n, st);
+  launch_final_exp_wide(scratch, nullptr, n, gt_out, nullptr, st);
   LAUNCHED();
 }
 // ok_i = [ e(sig_i, G2gen) e(hneg_i, pk_i) == 1 ], i < n; scratch: 96 n words
@@ -783,8 +831,8 @@ int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const ui
                           uint64_t* scratch, uint8_t* ok, size_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   u64 *fa = scratch, *fb = scratch + 48 * n;
-  plk::k_miller_wide_batch<<<dim3((unsigned)(2 * n)), dim3(64), 0, st>>>(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n);
-  plk::k_final_exp_wide_batch<<<dim3((unsigned)n), dim3(64), 0, st>>>(fa, fb, n, nullptr, ok);
+  launch_miller_wide(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n, st);
+  launch_final_exp_wide(fa, fb, n, nullptr, ok, st);
   LAUNCHED();
 }
 }  // namespace plkh
@@ -930,7 +978,7 @@ static int32_t finish(host::Lease& ws) {
 // stay on the device.  EIP-197 reading of identities only (skip_infinity).
 static bool single_job_route(size_t n_jobs, size_t n_pairs, int32_t skip_infinity) {
   const size_t cap = plkh::wide_batch_max();
-  return cap != 0 && n_pairs >= 1 && n_pairs <= cap && n_jobs <= cap / 2 && skip_infinity;
+  return cap != 0 && n_pairs >= 1 && n_pairs <= cap && n_jobs <= 1024 && skip_infinity;
 }
 static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, const uint64_t* pair_offsets,
                                   size_t n_jobs, size_t n_pairs, uint64_t* gt_out, uint8_t* is_one, void* stream) {
@@ -946,7 +994,7 @@ static int32_t single_job_product(const uint64_t* p_xy, const uint8_t* p_inf, co
   int32_t rc = ws.acquire(48 * n_pairs * sizeof(u64), st);
   if (rc != SYLOW_HIP_OK) return rc;
   u64* raw = (u64*)ws.p;
-  plk::k_miller_wide_batch<<<dim3((unsigned)n_pairs), dim3(64), 0, st>>>(p_xy, p_inf, q_xy, q_inf, raw, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs);
+  launch_miller_wide(p_xy, p_inf, q_xy, q_inf, raw, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs, st);
   plk::k_final_exp_wide_jobs<<<dim3((unsigned)n_jobs), dim3(64), 0, st>>>(raw, n_pairs, pair_offsets, n_jobs, gt_out, is_one);
   return finish(ws);
 }
@@ -962,7 +1010,7 @@ int32_t sylow_hip_pairing_product_batch(const uint64_t* p_xy, const uint8_t* p_i
     if (rc != SYLOW_HIP_OK) return rc;
     u64 *off = (u64*)ws.p, *raw = off + 2;
     plk::k_chunk_offsets<<<1, 64, 0, st>>>(off, 1, n_pairs, n_pairs, nullptr);
-    plk::k_miller_wide_batch<<<dim3((unsigned)n_pairs), dim3(64), 0, st>>>(p_xy, p_inf, q_xy, q_inf, raw, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs);
+    launch_miller_wide(p_xy, p_inf, q_xy, q_inf, raw, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs, st);
     plk::k_final_exp_wide_jobs<<<1, 64, 0, st>>>(raw, n_pairs, off, 1, gt_out, is_one);
     return finish(ws);
   }

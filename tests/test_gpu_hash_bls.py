@@ -103,6 +103,36 @@ def test_verify_batch_planted_pattern_large(engine):
     assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1
 
 
+@pytest.mark.parametrize("n", [513, 1500, 2047])
+def test_verify_two_elements_per_wavefront_route(engine, coracle, n):
+    """512 < n <= 2048 verifications: 2 n Miller loops and n final exponentiations, two per wavefront.  Planted corruption and identity
+    flags in both halves; flags equal the planted pattern, the literal two-pairing form, and (a sample) the oracle."""
+    g = np.random.default_rng(1234 + n)
+    msgs = [g.integers(0, 256, size=int(g.integers(0, 70)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sk = g.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sk[:, 3] &= np.uint64((1 << 60) - 1)
+    sig_xy, _ = engine.bls_sign(sk, msgs)
+    pk_xy, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), n, 0), sk)
+    plant = g.random(n) < 1 / 16
+    plant[[0, 1, n - 1]] = [True, False, True]
+    bad_sig, _ = engine.g1_add(sig_xy, np.repeat(pack([1, 2], 8), n, 0))
+    mixed = np.where(plant[:, None], bad_sig, sig_xy)
+    pinf, sinf = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    pinf[[7, 40, n - 2]] = 1
+    sinf[[8, 40, n - 3]] = 1
+    expect = (~plant).astype(np.uint8)
+    expect[[7, 8, n - 2, n - 3]] = 0                                                  # one side the identity, the other not
+    expect[40] = 1                                                                     # both sides the identity
+    got = engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf, pipelined=False)
+    assert np.array_equal(got, expect)
+    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf))
+    assert np.array_equal(got, engine.bls_verify(pk_xy, msgs, mixed, pk_inf=pinf, sig_inf=sinf, two_pairings=True))
+    idx = [0, 1, 2, 31, 32, 33, n - 1]
+    pk_proj = np.concatenate([pk_xy[idx], np.repeat(pack([1, 0], 8), len(idx), 0)], axis=1)
+    sig_proj = np.concatenate([mixed[idx], np.repeat(limbs([1]), len(idx), 0)], axis=1)
+    assert got[idx].tolist() == list(coracle.verify(pk_proj, [msgs[i] for i in idx], sig_proj))
+
+
 def test_one_final_exponentiation_verify_equals_the_two_pairing_form(engine, coracle):
     """sylow_hip_bls_verify_batch (= _fused_: e(sig, G2gen) * e(-H, pk) == 1, one final exponentiation) gives the booleans of
     lib.rs:223-236 evaluated literally (sylow_hip_bls_verify_two_pairings_batch): planted corruption, identity inputs, and keys

@@ -4,8 +4,10 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
   SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
                              shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
-                             above 2048 / 1024 elements reach them), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
+                             above 4096 / 2048 elements reach them), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
                              default only batches above 8192 reach it; below, sign_wide.hip's eight lanes per signature)
+  SYLOW_HIP_WIDE_PACK=0 / 1  the one-wavefront kernels of small batches with one element per wavefront at every size / two elements per
+                             wavefront from two elements on (default: two above one wavefront per compute unit, up to 4096 pairings)
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
   SYLOW_HIP_STAGGER=0        k_pairing / k_bls_verify_fused launched plain (default from 2^17 elements: the launch is skewed by half a
                              period, plk_pairing.hip) -- the full-size C3 test is added to the files for this switch
@@ -24,13 +26,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
          "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py"]
 ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"}, {"SYLOW_HIP_STAGGER": "0"},
-          {"SYLOW_HIP_STAGGER": "2"},
+          {"SYLOW_HIP_STAGGER": "2"}, {"SYLOW_HIP_WIDE_PACK": "0"}, {"SYLOW_HIP_WIDE_PACK": "1"},
           {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
 
 
 @pytest.mark.parametrize("route", ROUTES, ids=lambda r: ",".join(f"{k[10:]}={v}" for k, v in r.items()))
 def test_forced_route_passes_the_same_tests(route):
-    if any(k.startswith("SYLOW_HIP_") and k in ("SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER") for k in os.environ):
+    if any(k.startswith("SYLOW_HIP_") and k in ("SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER") for k in os.environ):
         pytest.skip("already inside a forced-route run")
     env = dict(os.environ, **route)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--deselect",

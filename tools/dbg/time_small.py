@@ -1,4 +1,5 @@
-"""Latency of the one-wavefront-per-element route: pairing and verify at n = 1, 64, 1024 for the library SYLOW_HIP_LIB names."""
+"""Latency of the one-wavefront-per-element route: pairing and verify at n = 1, 64, 1024 (or the sizes on the command line) for the
+library SYLOW_HIP_LIB names."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, sylow_amd
@@ -12,7 +13,7 @@ def timed(fn, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 name = os.path.basename(os.environ.get("SYLOW_HIP_LIB", "current"))
-for n in (1, 64, 1024):
+for n in ([int(a) for a in sys.argv[1:]] or (1, 64, 1024)):
     p, q, ka, kb = make_points(eng, n, 5)
     gt = eng.empty((48, n))
     tp = timed(lambda: eng._call("sylow_hip_pairing_batch", p.ptr, None, q.ptr, None, gt.ptr, n))
