@@ -82,3 +82,21 @@ def test_host_xoshiro_matches_the_test_stream():
         assert np.array_equal(out[:, :n].T, limbs([r.fp() for _ in range(n)]))
         assert not out[:, n:].any()                                    # the stride tail is left alone
     assert lib.sylow_hip_host_xoshiro_fp(1, None, 4, 4) == -2
+
+
+def test_environment_switches_are_the_documented_ones():
+    """Every variable the library reads is a route selector named in INTEGRATION.md and forced by tests/test_gpu_routes.py (or a
+    threshold named there); nothing undocumented changes what the library computes with."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for f in glob.glob(os.path.join(root, "sylow_amd", "csrc", "*.h*")):
+        read |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert read == {"SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER",
+                    "SYLOW_HIP_SIGN_WIDE_MAX"}
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    routes = open(os.path.join(root, "tests", "test_gpu_routes.py")).read()
+    for name in read:
+        assert name in doc, name
+        assert name in routes, name
