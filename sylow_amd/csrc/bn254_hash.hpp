@@ -191,6 +191,82 @@ __device__ inline void expand_message_xmd96(uint8_t out[96], const uint8_t* msg,
   }
 }
 
+// The same 96 bytes as twelve little-endian words (w[4 (i - 1) + k] = word k of b_i), every index a constant: for callers that keep the
+// bytes in registers and pick a half per LANE (sign_wide.hip) -- a byte array written under a loop counter and read at a lane-dependent
+// offset costs ~100 compare-and-select instructions per byte there.
+__device__ inline void expand_message_xmd96_words(u64 (&w)[12], const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
+  if (!dp.tail_ok) {                                  // long tags: the byte-wise route, packed afterwards
+    uint8_t em[96];
+    expand_message_xmd96(em, msg, msg_len, dp);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      u64 v = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v |= (u64)em[8 * k + j] << (8 * j);
+      w[k] = v;
+    }
+    return;
+  }
+  Keccak256 k;
+  k.init();
+  {
+    const u64 z[25] = {0xf1258f7940e1dde7ull, 0x84d5ccf933c0478aull, 0xd598261ea65aa9eeull, 0xbd1547306f80494dull, 0x8b284e056253d057ull,
+                       0xff97a42d7f8e6fd4ull, 0x90fee5a0a44647c4ull, 0x8c5bda0cd6192e76ull, 0xad30a6f71b19059cull, 0x30935ab7d08ffc64ull,
+                       0xeb5aa93f2317d635ull, 0xa9a6e6260d712103ull, 0x81a57c16dbcf555full, 0x43b831cd0347c826ull, 0x01f22f1a11a5569full,
+                       0x05e5635a21d9ae61ull, 0x64befef28cc970f2ull, 0x613670957bc46611ull, 0xb87c5a554fd00ecbull, 0x8c3ee88a1ccf32c8ull,
+                       0x940c7922ae3a2614ull, 0x1841f924a2c509e4ull, 0x16f53526e70465c2ull, 0x75f644e97f30a13bull, 0xeaf1ff7b5ceca249ull};
+#pragma unroll
+    for (int i = 0; i < 25; ++i) k.s[i] = z[i];           // Z_pad absorbed (expand_message_xmd96)
+  }
+  k.update(msg, msg_len);
+  k.put(0); k.put(96);
+  k.put(0);
+  k.update(dp.bytes, dp.len);
+  // finish() without the byte output: b_0 stays in the state's first four words
+  k.cur |= (u64)0x01 << (8 * (k.fill & 7));
+  k.flush_word(k.fill >> 3);
+  k.s[16] ^= 0x8000000000000000ull;
+  keccak_f1600(k.s);
+  const u64 x0[4] = {k.s[0], k.s[1], k.s[2], k.s[3]};
+  u64 xp[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int blk = 1; blk <= 3; ++blk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k.s[i] = x0[i] ^ xp[i];
+#pragma unroll
+    for (int i = 4; i < 17; ++i) k.s[i] = dp.tail[i];
+    k.s[4] |= (u64)blk;
+#pragma unroll
+    for (int i = 17; i < 25; ++i) k.s[i] = 0;
+    keccak_f1600(k.s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xp[i] = k.s[i]; w[4 * (blk - 1) + i] = k.s[i]; }
+  }
+}
+
+// value = hi * 2^256 + lo (plain limbs, hi < 2^128) reduced mod p, in Montgomery form
+__device__ inline Fp fp_from_wide_limbs(const Fp& lo, const Fp& hi) {
+  // mont(hi) * R^2 / R = mont(hi * R)
+  Fp h = fp_mul(fp_to_mont(hi), fp_r2());
+  return fp_add(h, fp_to_mont(lo));
+}
+// fp_from_be48 on six little-endian words holding the 48 bytes
+__device__ inline Fp fp_from_be48_words(const u64 (&w)[6]) {
+  Fp lo, hi;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int o = 44 - 4 * i;                         // byte offset of the big-endian 32-bit group
+    lo.v[i] = __builtin_bswap32((u32)(w[o >> 3] >> (8 * (o & 4))));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = 12 - 4 * i;
+    hi.v[i] = __builtin_bswap32((u32)(w[o >> 3] >> (8 * (o & 4))));
+  }
+  hi.v[4] = hi.v[5] = hi.v[6] = hi.v[7] = 0;
+  return fp_from_wide_limbs(lo, hi);
+}
+
 // hasher.rs:84-128: a 48-byte big-endian integer reduced mod p, in Montgomery form
 __device__ inline Fp fp_from_be48(const uint8_t* b) {
   Fp lo, hi;
@@ -205,9 +281,7 @@ __device__ inline Fp fp_from_be48(const uint8_t* b) {
     hi.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
   }
   hi.v[4] = hi.v[5] = hi.v[6] = hi.v[7] = 0;
-  // value = hi * 2^256 + lo:  mont(hi) * R^2 / R = mont(hi * R)
-  Fp h = fp_mul(fp_to_mont(hi), fp_r2());
-  return fp_add(h, fp_to_mont(lo));
+  return fp_from_wide_limbs(lo, hi);
 }
 
 // is_square (fp.rs:625-631: a^((p-1)/2) in {0, 1}) as a Jacobi symbol: the binary algorithm with a FIXED trip count and no

@@ -776,7 +776,7 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
   {
     const int ko = p >> 1;
     const W2 m = wide_get(x, 2 * ko, odd), w = wide_get(x, 2 * ko + 1, odd);
-    const W2 z = p == 0 ? z0 : p == 1 ? z1 : p == 2 ? z4 : p == 3 ? z5 : p == 4 ? z2 : z3;
+    const W2 z = w2_pick(w2_pick(w2_pick(w2_pick(w2_pick(z3, z2, p == 4), z5, p == 3), z4, p == 2), z1, p == 1), z0, p == 0);   // a chain of selects: the nested ?: form is lowered as a divergent switch
     W2 ra;                                                            // 3 (w - m - xi m) - 2 z in one pass, as w_fp4_square_fold
     {
       const F29 mo = xchg9(m.c);
@@ -786,7 +786,7 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
     }
     const W2 rb = w2_lin2(m, 6, z, 2);
     const W2 rc = w2_xi_lin(m, 6, z, 2);
-    const W2 r = (p == 1 || p == 3) ? rb : p == 4 ? rc : ra;
+    const W2 r = w2_pick(w2_pick(ra, rc, p == 4), rb, p == 1 || p == 3);
     if (j < 6) wide_put(x, 6 + p, odd, r);
   }
   __syncthreads();
@@ -860,7 +860,7 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
     const W2 xs = w2_pick(xa, w2_norm(w2_add(xa, xb)), h >= 3), ys = w2_pick(ya, w2_norm(w2_add(ya, yb)), h >= 3);
     const W2 pr = w2_mul_w(xs, ys);
     if (live) wide_put(x, WL_P + w, odd, pr);
-    if (KIND == WK_LINE && j < 4) wide_put(x, WL_P + (j == 0 ? 1 : j == 1 ? 6 : j == 2 ? 8 : 11), odd, zero);
+    if (KIND == WK_LINE && j < 4) wide_put(x, WL_P + (int)((0x0B080601u >> (8 * j)) & 255u), odd, zero);      // slots 1, 6, 8, 11
   }
   __syncthreads();
   {   // stage 2: Fp6 coefficient u = 3 g + c of the three Fp6 products (w6_mul); WK_SQUARE: of the first and the third
@@ -879,7 +879,7 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
     const W2 ra = w2_norm(w2_add(ti, ti));
     const W2 rb = w2_xi_lin(tp, -1, w2_sub(mi, ti), 1);
     const W2 rc = w2_lin2(w2_sub(mi, ti), 1, tp, -1);
-    if (j < 6) wide_put(x, WL_OUT + o, odd, o >= 3 ? ra : o == 0 ? rb : rc);
+    if (j < 6) wide_put(x, WL_OUT + o, odd, w2_pick(w2_pick(rc, rb, o == 0), ra, o >= 3));
   } else {   // stage 3: output o (w12_mul): c1.ci = T2.ci - T0.ci - T1.ci;  c0.c0 = T0.c0 + xi T1.c2;  c0.c1 = T0.c1 + T1.c0;  c0.c2 = T0.c2 + T1.c1
     const int o = j < 6 ? j : 0, i = o % 3;
     const int pa = o >= 3 ? i : o, pb = o >= 3 ? 3 + i : o == 0 ? 5 : o == 1 ? 3 : 4, pc = o >= 3 ? 6 + i : 0;
@@ -887,7 +887,7 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
     const W2 ra = w2_lin2(w2_sub(tc, ta), 1, tb, -1);
     const W2 rb = w2_xi_lin(tb, 1, ta, 1);
     const W2 rc = w2_norm(w2_add(ta, tb));
-    if (j < 6) wide_put(x, WL_OUT + o, odd, o >= 3 ? ra : o == 0 ? rb : rc);
+    if (j < 6) wide_put(x, WL_OUT + o, odd, w2_pick(w2_pick(rc, rb, o == 0), ra, o >= 3));
   }
   __syncthreads();
   W12 r;

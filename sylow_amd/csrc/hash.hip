@@ -27,10 +27,10 @@ k_hash_to_g1(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t
 }
 
 namespace g1h {
-constexpr size_t HASH_WIDE_MAX = 8192;        // 8 messages per wavefront: one wavefront per SIMD
+constexpr size_t HASH_WIDE_MAX = 16384;       // 8 messages per wavefront: up to two wavefronts per SIMD
 int32_t hash_to_g1_dst(const uint8_t* msgs, const uint64_t* msg_offsets, const DstPrime& dp, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
   if (!n) return SYLOW_HIP_OK;
-  // single calls and small batches: eight lanes per message (sign_wide.hip) -- one hash ~1.0 -> ~0.4 ms, the head of every single verification
+  // single calls and small batches: eight lanes per message (sign_wide.hip) -- one hash ~1.0 -> 0.36 ms, the head of every single verification
   if (plkh::wide_batch_max() != 0 && n <= HASH_WIDE_MAX) return hash_to_g1_wide(msgs, msg_offsets, dp, out_xy, out_inf, n, negate, stream);
   k_hash_to_g1<<<GRID(n)>>>(msgs, msg_offsets, dp, out_xy, out_inf, nullptr, n, negate, nullptr); LAUNCHED();
 }

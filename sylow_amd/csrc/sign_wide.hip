@@ -28,11 +28,31 @@ template <int S> BN_DEV F29 qb(const F29& a) {
   for (int i = 0; i < 9; ++i) r.v[i] = qbi<S>(a.v[i]);
   return r;
 }
-BN_DEV F29 qsel(int j, const F29& a0, const F29& a1, const F29& a2, const F29& a3) {
+// Operand of lane j: three conditional moves per limb.  Written as a CHAIN of two-way selects whose intermediate values the compiler
+// cannot see through (inline v_cndmask_b32 on ballot masks) -- left alone it lowers the nested form j == 0 ? a0 : j == 1 ? a1 : ... as a switch with divergent control
+// flow (53 exec-mask regions and ~570 instructions per doubling where 108 conditional moves do), and the plain chain as a table in the
+// stack frame read back at a lane-dependent address (127 scratch accesses per addition).
+BN_DEV i32 qcsel(i32 a, i32 b, u64 m) {          // lanes of mask m take b, the others a: one v_cndmask_b32, whatever the optimizer thinks of it
+  i32 r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+BN_DEV F29 qcsel9(const F29& a, const F29& b, u64 m) {
   F29 r;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.v[i] = j == 0 ? a0.v[i] : (j == 1 ? a1.v[i] : (j == 2 ? a2.v[i] : a3.v[i]));
+  for (int i = 0; i < 9; ++i) r.v[i] = qcsel(a.v[i], b.v[i], m);
   return r;
+}
+// Call sites pass the same object for equal candidates (the address comparisons fold at compile time): one or two selects then
+BN_DEV F29 qsel(int j, const F29& a0, const F29& a1, const F29& a2, const F29& a3) {
+  const bool e01 = &a0 == &a1, e23 = &a2 == &a3, e02 = &a0 == &a2, e13 = &a1 == &a3, e12 = &a1 == &a2, e03 = &a0 == &a3;
+  if (e02 && e13) return qcsel9(a0, a1, __builtin_amdgcn_ballot_w64((j & 1) != 0));                     // a b a b
+  if (e01 && e23) return qcsel9(a2, a0, __builtin_amdgcn_ballot_w64(j < 2));                            // a a b b
+  if (e12 && e03) return qcsel9(a0, a1, __builtin_amdgcn_ballot_w64(j == 1 || j == 2));                 // a b b a
+  if (e01) return qcsel9(qcsel9(a3, a2, __builtin_amdgcn_ballot_w64(j == 2)), a0, __builtin_amdgcn_ballot_w64(j < 2));   // a a b c
+  if (e23) return qcsel9(qcsel9(a2, a1, __builtin_amdgcn_ballot_w64(j == 1)), a0, __builtin_amdgcn_ballot_w64(j == 0));  // a b c c
+  const u64 m0 = __builtin_amdgcn_ballot_w64(j == 0), m1 = __builtin_amdgcn_ballot_w64(j == 1), m2 = __builtin_amdgcn_ballot_w64(j == 2);
+  return qcsel9(qcsel9(qcsel9(a3, a2, m2), a1, m1), a0, m0);
 }
 BN_DEV Fp xq_fp(const Fp& a) {               // the other quad's value
   Fp r;
@@ -118,10 +138,13 @@ BN_DEV bool svdw_back_quad(Fp& xo, Fp& yo, const Fp& u, const Fp& tv1, const Fp&
 template <bool STAMPS>
 BN_DEV G1P hash_to_g1_group(const uint8_t* msg, size_t len, const DstPrime& dp, int q, int j, u64* stamps) {
   auto stamp = [&](int k) { if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (u64)clock64(); };
-  uint8_t em[96];
-  expand_message_xmd96(em, msg, len, dp);
+  u64 em[12];
+  expand_message_xmd96_words(em, msg, len, dp);
   stamp(1);
-  const Fp u = fp_from_be48(em + 48 * q);
+  u64 half[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) half[k] = q ? em[6 + k] : em[k];
+  const Fp u = fp_from_be48_words(half);
   const SvdwHalf me = svdw_front(u);
   const bool zme = fp_is_zero(me.d);
   const Fp one = fp_one(), zero = fp_zero();

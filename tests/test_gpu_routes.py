@@ -5,7 +5,7 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
                              shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
                              above 4096 / 2048 elements reach them), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
-                             default only batches above 8192 reach it; below, sign_wide.hip's eight lanes per signature)
+                             default only batches above 16384 reach it; below, sign_wide.hip's eight lanes per signature)
   SYLOW_HIP_WIDE_PACK=0 / 1  the one-wavefront kernels of small batches with one element per wavefront at every size / two elements per
                              wavefront from two elements on (default: two above one wavefront per compute unit, up to 4096 pairings)
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream

@@ -11,7 +11,7 @@ def timed(fn, reps=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 rng = np.random.default_rng(7)
-for n in (1, 64, 1024, 4096, 8192, 16384, 65536):
+for n in (1, 64, 1024, 4096, 8192, 12288, 16384, 20480, 65536):
     msgs = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     dm, doff = eng.to_device(msgs.reshape(-1)), eng.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(32))
     hx, hi = eng.empty((8, n)), eng.empty((n,), np.uint8)
