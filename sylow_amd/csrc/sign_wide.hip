@@ -2,8 +2,9 @@
 //
 // One signature on one lane (sign.hip) is a chain of ~2 900 dependent field multiplications: 2.1 ms whatever the batch size, because a lone
 // lane issues a multiply-add every ~8 cycles.  What is independent inside one signature is spread over the 8 lanes of a group here:
-//   * the two SvdW maps of hash_to_curve (g1.rs:307-331) run side by side, one per QUAD (4 lanes); inside a map the two Jacobi symbols
-//     (is_square(gx1), is_square(gx2): svdw.rs:218-232) run on two lanes at once; the maps' inversions stay shared (Montgomery's trick);
+//   * the two SvdW maps of hash_to_curve (g1.rs:307-331) run side by side, one per QUAD (4 lanes); inside a map the three square-root
+//     candidates run on three lanes at once and replace the Jacobi symbols (is_square(gx1), is_square(gx2): svdw.rs:218-232 -- read off
+//     as "candidate^2 == gx"); the maps' inversions stay shared (Montgomery's trick);
 //   * the scalar multiplication is GLV-split (k = k1 + k2 lambda, bn254_pairing.hpp) with k1 * (+-P) on quad 0 and k2 * (+-phi P) on quad 1,
 //     each with its own accumulator and window table (LDS), added once at the end;
 //   * inside a quad every point is REPLICATED on the four lanes and each lane computes one of the independent products of a formula level:
@@ -105,26 +106,35 @@ BN_DEV G1W qadd(const G1W& p, const G1W& q, int j) {
   return G1W{f29_norm(f29_sub(a, b)), f29_norm(f29_add(c, d)), f29_norm(f29_add(e, f))};
 }
 
-// svdw_back (bn254_hash.hpp; svdw.rs:180-262) with the two Jacobi symbols on two lanes of the quad at once
+template <int S> BN_DEV Fp qb_fp(const Fp& a) {          // lane S of this lane's quad
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (u32)qbi<S>((int)a.v[i]);
+  return r;
+}
+// svdw_back (bn254_hash.hpp; svdw.rs:180-262) without Jacobi symbols: the quad has a lane for each of the THREE candidates, so lane 0 takes
+// the square-root candidate gx1^((p+1)/4), lane 1 that of gx2, lanes 2 and 3 that of gx3 -- one power chain, the same instruction stream
+// on every lane -- and is_square(gx_i) (fp.rs:625-631: gx_i^((p-1)/2) in {0, 1}) is read off as "candidate^2 == gx_i" (true for 0 as
+// well, like the reference).  The selected x and the root are the reference's: e1 ? x1 : e2 ? x2 : x3 and its gx^((p+1)/4).
 BN_DEV bool svdw_back_quad(Fp& xo, Fp& yo, const Fp& u, const Fp& tv1, const Fp& tv2, const Fp& tv3, int j) {
   const Fp c2 = fp_const(C_SVDW[1]), c3 = fp_const(C_SVDW[2]), c4 = fp_const(C_SVDW[3]), z = fp_const(C_SVDW[4]);
   const Fp b = fp_small(3);
   const Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
   const Fp x1 = fp_sub(c2, tv4);
-  const Fp gx1 = fp_add(fp_mul(fp_mul(x1, x1), x1), b);
   const Fp x2 = fp_add(c2, tv4);
-  const Fp gx2 = fp_add(fp_mul(fp_mul(x2, x2), x2), b);
-  const int sq = fp_is_square(fp_select(gx1, gx2, (j & 1) != 0)) ? 1 : 0;       // even lanes: gx1, odd lanes: gx2
-  const bool e1 = qbi<0>(sq) != 0;
-  const bool e2 = qbi<1>(sq) != 0 && !e1;
   Fp x3 = fp_mul(fp_mul(tv2, tv2), tv3);
   x3 = fp_mul(fp_mul(x3, x3), c4);
   x3 = fp_add(x3, z);
+  const Fp xc = fp_select(fp_select(x3, x2, j == 1), x1, j == 0);              // this lane's candidate
+  const Fp gx = fp_add(fp_mul(fp_mul(xc, xc), xc), b);
+  const Fp yc = fp_mul(gx, fp_pow_pm3_quarter(gx));
+  const int sq = fp_eq(fp_mul(yc, yc), gx) ? 1 : 0;
+  const bool e1 = qbi<0>(sq) != 0;
+  const bool e2 = qbi<1>(sq) != 0 && !e1;
+  const bool ok = e1 || e2 || qbi<2>(sq) != 0;
   Fp x = fp_select(x3, x1, e1);
   x = fp_select(x, x2, e2);
-  const Fp gx = fp_add(fp_mul(fp_mul(x, x), x), b);
-  Fp y = fp_mul(gx, fp_pow_pm3_quarter(gx));
-  const bool ok = fp_eq(fp_mul(y, y), gx);
+  Fp y = fp_select(fp_select(qb_fp<2>(yc), qb_fp<1>(yc), e2), qb_fp<0>(yc), e1);
   const bool e3 = fp_sgn0(u) == fp_sgn0(y);
   y = fp_select(fp_neg(y), y, e3);
   xo = x;
@@ -132,8 +142,8 @@ BN_DEV bool svdw_back_quad(Fp& xo, Fp& yo, const Fp& u, const Fp& tv1, const Fp&
   return ok;
 }
 
-// hash_to_curve (g1.rs:307-331) on the eight lanes of a group: every lane expands the message, quad q maps field element u_q (the two Jacobi
-// symbols of a map on two lanes at once, the maps' inversions shared), the two points meet through the quad exchange and every lane adds them.
+// hash_to_curve (g1.rs:307-331) on the eight lanes of a group: every lane expands the message, quad q maps field element u_q (the three
+// square-root candidates of a map on three lanes at once, the maps' inversions shared), the two points meet through the quad exchange and every lane adds them.
 // Returns H(m) projective, the same on all eight lanes.
 template <bool STAMPS>
 BN_DEV G1P hash_to_g1_group(const uint8_t* msg, size_t len, const DstPrime& dp, int q, int j, u64* stamps) {

@@ -12,7 +12,7 @@ int main() {
   (void)hipMalloc(&sk, 32); (void)hipMalloc(&off, 16); (void)hipMalloc(&oxy, 64); (void)hipMalloc(&stamps, 64); (void)hipMalloc(&msg, 32); (void)hipMalloc(&oinf, 1);
   (void)hipMemcpy(sk, hsk, 32, hipMemcpyHostToDevice); (void)hipMemcpy(off, hoff, 16, hipMemcpyHostToDevice); (void)hipMemcpy(msg, hmsg, 32, hipMemcpyHostToDevice);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
-  const char* names[7] = {"expand_message", "front + shared inversion", "svdw_back (Jacobi, sqrt)", "exchange + add", "GLV + table", "window loop", "combine + affine + store"};
+  const char* names[7] = {"expand_message", "front + shared inversion", "svdw_back (3 root candidates)", "exchange + add", "GLV + table", "window loop", "combine + affine + store"};
   for (int rep = 0; rep < 3; ++rep) {
     wsign::k_bls_sign_wide<true><<<1, 64>>>(sk, msg, off, dp, oxy, oinf, n, stamps);
     u64 h[8]; (void)hipMemcpy(h, stamps, 64, hipMemcpyDeviceToHost);
