@@ -63,13 +63,15 @@ BN_DEV int wave_max(int v) {
 }
 
 // ---- 32-byte big-endian field elements (Fp::from_be_bytes / to_be_bytes, fp.rs:686-737) ----------
-BN_DEV bool read_be_fp(Fp& out, const uint8_t* b) {         // returns false when the value is >= p
+// Two 16-byte loads whatever the alignment of b (the fixed-size copy compiles to global_load_dwordx4), then byte swaps.  clear_flag drops
+// bit 7 of byte 0 (the identity flag of the point encodings) before the range check.
+BN_DEV bool read_be_fp(Fp& out, const uint8_t* b, bool clear_flag = false) {         // returns false when the value is >= p
+  u32 w[8];
+  __builtin_memcpy(w, b, 32);
   Fp x;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint8_t* q = b + 28 - 4 * j;
-    x.v[j] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
-  }
+  for (int j = 0; j < 8; ++j) x.v[j] = __builtin_bswap32(w[7 - j]);
+  if (clear_flag) x.v[7] &= 0x7fffffffu;
   const u32 pl[8] = {BN_P0, BN_P1, BN_P2, BN_P3, BN_P4, BN_P5, BN_P6, BN_P7};
   bool lt = false, decided = false;
 #pragma unroll

@@ -262,10 +262,11 @@ __global__ void __launch_bounds__(BLOCK) k_compute_naf(const u64* k, u64* onp, u
 __global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, const u64* off, DstPrime dp, u64* out, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  uint8_t em[96];
-  expand_message_xmd96(em, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
-  store_fp(out, n, i, 0, fp_from_be48(em));
-  store_fp(out, n, i, 4, fp_from_be48(em + 48));
+  u64 em[12];
+  expand_message_xmd96_words(em, msgs + off[i], (size_t)(off[i + 1] - off[i]), dp);
+  const u64 a[6] = {em[0], em[1], em[2], em[3], em[4], em[5]}, b[6] = {em[6], em[7], em[8], em[9], em[10], em[11]};
+  store_fp(out, n, i, 0, fp_from_be48_words(a));
+  store_fp(out, n, i, 4, fp_from_be48_words(b));
 }
 // ------------------------------------------------------------------ EVM alt_bn128 adapter -------
 // Byte-level batches of the three precompile shapes of examples/reth_bn128.rs:99-217 (EIP-196/197):
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t*
   uint8_t sa = evm_read_g1(a, in + 128 * i), sb = evm_read_g1(b, in + 128 * i + 64);
   uint8_t st = sa ? sa : sb;
   status[i] = st;
-  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  if (st) { __builtin_memset(out + 64 * i, 0, 64); return; }
   evm_write_g1(out + 64 * i, g1_add(a, b));
 }
 __global__ void HEAVY_BOUNDS k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
@@ -307,7 +308,7 @@ __global__ void HEAVY_BOUNDS k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_
   G1P a;
   uint8_t st = evm_read_g1(a, in + 96 * i);
   status[i] = st;
-  if (st) { for (int k = 0; k < 64; ++k) out[64 * i + k] = 0; return; }
+  if (st) { __builtin_memset(out + 64 * i, 0, 64); return; }
   Fp kx;
   read_be_fp(kx, in + 96 * i + 64);
   // EIP-196 accepts any 256-bit scalar; G1 has prime order r, so reduce mod r (2^256 < 6r).  (The reference
@@ -337,12 +338,10 @@ __global__ void __launch_bounds__(BLOCK) k_g1_to_bytes(const u64* xy, const uint
 __global__ void __launch_bounds__(BLOCK) k_g1_from_bytes(const uint8_t* in, u64* xy, uint8_t* inf, uint8_t* status, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  uint8_t b[64];
-  for (int k = 0; k < 64; ++k) b[k] = in[64 * i + k];
-  bool flag = (b[0] >> 7) & 1;
-  b[0] &= 0x7f;
+  const uint8_t* b = in + 64 * i;
+  const bool flag = (b[0] >> 7) & 1;
   Fp x, y;
-  bool ok = read_be_fp(x, b);
+  bool ok = read_be_fp(x, b, true);
   ok = read_be_fp(y, b + 32) && ok;
   uint8_t st = SYLOW_HIP_ST_OK;
   bool is01 = fp_is_zero(x) && fp_eq(y, fp_from_limbs(1, 0, 0, 0, 0, 0, 0, 0));

@@ -552,12 +552,10 @@ __global__ void HEAVY_BOUNDS k_g2_from_bytes(const uint8_t* in, u64* xy, uint8_t
   const size_t t = TID, i = bn254::pl::pair_index(t);
   const bool odd = bn254::pl::pair_role(t) != 0;
   if (i >= n) return;
-  uint8_t b[128];
-  for (int k = 0; k < 128; ++k) b[k] = in[128 * i + k];
-  bool flag = (b[0] >> 7) & 1;
-  b[0] &= 0x7f;
+  const uint8_t* b = in + 128 * i;
+  const bool flag = (b[0] >> 7) & 1;
   Fp xc1, xc0, yc1, yc0;
-  bool ok = read_be_fp(xc1, b);
+  bool ok = read_be_fp(xc1, b, true);
   ok = read_be_fp(xc0, b + 32) && ok;
   ok = read_be_fp(yc1, b + 64) && ok;
   ok = read_be_fp(yc0, b + 96) && ok;

@@ -9,9 +9,11 @@ namespace plk {
 // are exchanged and both lanes finish with the same complete addition and affine normalisation.
 BN_DEV bool hash_to_g1_pair(Fp& hx, Fp& hy, bool& hinf, const uint8_t* msg, size_t msg_len, const DstPrime& dp) {
   const bool odd = lane_odd();
-  uint8_t em[96];
-  expand_message_xmd96(em, msg, msg_len, dp);
-  const Fp u = fp_from_be48(em + (odd ? 48 : 0));
+  u64 em[12], half[6];
+  expand_message_xmd96_words(em, msg, msg_len, dp);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) half[k] = odd ? em[6 + k] : em[k];
+  const Fp u = fp_from_be48_words(half);
   Fp x, y;
   u32 ok = svdw_map(x, y, u) ? 1u : 0u;
   ok &= swap_u32(ok);
