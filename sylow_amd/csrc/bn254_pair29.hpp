@@ -739,20 +739,29 @@ BN_DEV W2 w2_mul_w(const W2& a, const W2& b) { return w2_mul_inl(a, b); }
 // same inputs), and the cyclotomic squarings of the three f^x chains -- 189 of them, six independent Fp2 products each -- are spread:
 // lane pair j < 6 forms product j, the products meet in LDS, lane pair j forms output coefficient j, the coefficients meet in LDS and
 // every lane pair holds the square again.  Same formulas, same operand classes and therefore the same digits as w12_cyclotomic_sqr.
-struct WideLds { i32 v[63][9][2]; };               // [slot][limb][lane parity]; squaring: 6 products + 6 outputs; product: slots 12 .. 62
+// [slot][lane parity][limb, padded to 12]: a value is 48 contiguous bytes at a 16-byte boundary, so that a put / get is two 16-byte LDS
+// accesses and one of 4 bytes instead of nine of 4 (a third of the LDS instructions of a wide product).  Squaring: 6 products + 6 outputs; product: slots 12 .. 62
+struct alignas(16) WideLds { i32 v[63][2][12]; };
 typedef __attribute__((address_space(3))) WideLds* WideLdsPtr;
 // EPW = elements per wavefront.  1: all 32 lane pairs hold the same element.  2: lanes 0-31 and 32-63 hold one element each (16 lane pairs,
 // each half with its own WideLds): batches of 1025 .. 4096 elements then still run one or two wavefronts per SIMD.  The only level with more
 // than 16 products (the 18 of the dense Fp12 product) takes a second pass on two lane pairs.
 template <int EPW> BN_DEV int wide_j(int lane) { return (int)pair_index((u32)lane) & (32 / EPW - 1); }
+typedef i32 __attribute__((ext_vector_type(4))) WideVec4;
+typedef __attribute__((address_space(3))) WideVec4* WideVec4Ptr;
 BN_DEV void wide_put(WideLdsPtr x, int slot, int odd, const W2& a) {
-#pragma unroll
-  for (int i = 0; i < 9; ++i) x->v[slot][i][odd] = a.c.v[i];
+  const WideVec4Ptr p = (WideVec4Ptr)&x->v[slot][odd][0];
+  p[0] = WideVec4{a.c.v[0], a.c.v[1], a.c.v[2], a.c.v[3]};
+  p[1] = WideVec4{a.c.v[4], a.c.v[5], a.c.v[6], a.c.v[7]};
+  x->v[slot][odd][8] = a.c.v[8];
 }
 BN_DEV W2 wide_get(WideLdsPtr x, int slot, int odd) {
+  const WideVec4Ptr p = (WideVec4Ptr)&x->v[slot][odd][0];
+  const WideVec4 lo = p[0], hi = p[1];
   W2 r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) r.c.v[i] = x->v[slot][i][odd];
+  r.c.v[0] = lo.x; r.c.v[1] = lo.y; r.c.v[2] = lo.z; r.c.v[3] = lo.w;
+  r.c.v[4] = hi.x; r.c.v[5] = hi.y; r.c.v[6] = hi.z; r.c.v[7] = hi.w;
+  r.c.v[8] = x->v[slot][odd][8];
   return r;
 }
 BN_DEV W2 w2_pick(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }                // c ? b : a
