@@ -815,6 +815,9 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
 //              two Fp6 products, 12 products; t takes the place of the first Fp6 product, the other one that of the third
 constexpr int WL_IA = 12, WL_IB = 18, WL_SA = 24, WL_SB = 27, WL_P = 30, WL_T = 48, WL_OUT = 57;
 constexpr int WK_DENSE = 0, WK_LINE = 1, WK_SQUARE = 2;
+#ifndef BN_WIDE_MILLER_INL
+#define BN_WIDE_MILLER_INL 2  // the wide Miller loop's Fp12 products inlined: 0 none, 1 the squaring, 2 the squaring and the line products (A/B runs)
+#endif
 #ifndef BN_WIDE_KINDS
 #define BN_WIDE_KINDS 1      // 0: the Miller loop of the wide routines with dense products only (A/B runs)
 #endif
@@ -822,10 +825,12 @@ BN_DEV W2 w12_coef(const W12& a, int c) {      // c = 3 * half + i
   const W2 lo = w2_sel3(c % 3, a.c0.c0, a.c0.c1, a.c0.c2), hi = w2_sel3(c % 3, a.c1.c0, a.c1.c1, a.c1.c2);
   return w2_pick(lo, hi, c >= 3);
 }
+// The product in three pieces: stage 0 (operands from registers into LDS), the core (LDS to LDS: callable out of line with nothing but the
+// LDS pointer -- an out-of-line call that takes Fp12 values by reference sends them through the stack frame, ~2 us for a lone wavefront)
+// and the read of the six output coefficients.
 template <int EPW = 1, int KIND = WK_DENSE>
-BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
+BN_DEV void w12_mul_wide_stage0(const W12& a, const W12& b, WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
-  const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   {   // stage 0: coefficients and the sums a.c0 + a.c1, b.c0 + b.c1 into LDS
     const int c = j < 6 ? j : 0;
     const int i = c % 3;
@@ -845,6 +850,11 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
       if (j >= 3 && j < 6) wide_put(x, WL_SB + i, odd, sb);
     }
   }
+}
+template <int EPW = 1, int KIND = WK_DENSE>
+BN_DEV void w12_mul_wide_core(WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
+  const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
   __syncthreads();
 #pragma unroll
   for (int pass = 0; pass < (KIND == WK_DENSE ? EPW : 1); ++pass) {   // stage 1: product w = 6 g + h
@@ -899,16 +909,27 @@ BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
     if (j < 6) wide_put(x, WL_OUT + o, odd, w2_pick(w2_pick(rc, rb, o == 0), ra, o >= 3));
   }
   __syncthreads();
+}
+BN_DEV W12 w12_wide_result(WideLdsPtr x) {
+  const int odd = pair_role((u32)(threadIdx.x & 63u));
   W12 r;
   r.c0.c0 = wide_get(x, WL_OUT, odd); r.c0.c1 = wide_get(x, WL_OUT + 1, odd); r.c0.c2 = wide_get(x, WL_OUT + 2, odd);
   r.c1.c0 = wide_get(x, WL_OUT + 3, odd); r.c1.c1 = wide_get(x, WL_OUT + 4, odd); r.c1.c2 = wide_get(x, WL_OUT + 5, odd);
   return r;
 }
 template <int EPW = 1, int KIND = WK_DENSE>
-BN_NOINLINE void w12_mul_wide_nl(W12& r, const W12& a, const W12& b, WideLds* xg) {
-  W12 p = a, q = b;
-  w12_pin(p); w12_pin(q);
-  r = w12_mul_wide<EPW, KIND>(p, q, (WideLdsPtr)xg);
+BN_DEV W12 w12_mul_wide(const W12& a, const W12& b, WideLdsPtr x) {
+  w12_mul_wide_stage0<EPW, KIND>(a, b, x);
+  w12_mul_wide_core<EPW, KIND>(x);
+  return w12_wide_result(x);
+}
+template <int EPW = 1, int KIND = WK_DENSE>
+BN_NOINLINE void w12_mul_wide_core_nl(WideLds* xg) { w12_mul_wide_core<EPW, KIND>((WideLdsPtr)xg); }
+template <int EPW = 1, int KIND = WK_DENSE>
+BN_DEV void w12_mul_wide_nl(W12& r, const W12& a, const W12& b, WideLds* xg) {
+  w12_mul_wide_stage0<EPW, KIND>(a, b, (WideLdsPtr)xg);
+  w12_mul_wide_core_nl<EPW, KIND>(xg);
+  r = w12_wide_result((WideLdsPtr)xg);
 }
 // exp_by_neg_z29 with the loop's squarings and products spread over the wavefront
 template <int EPW = 1>
@@ -1086,12 +1107,14 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
     W12 ln;
     ln.c0.c0 = l0; ln.c0.c1 = zero; ln.c0.c2 = w2_scale(l2, px);
     ln.c1.c0 = zero; ln.c1.c1 = w2_scale(l1, py); ln.c1.c2 = zero;
-    w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, f, ln, xg);
+    if (BN_WIDE_MILLER_INL >= 2) f = w12_mul_wide<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, ln, (WideLdsPtr)xg);
+    else w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, f, ln, xg);
   };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
 #pragma unroll 1
   for (int i = 0; i < 64; ++i) {
-    w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, f, xg);
+    if (BN_WIDE_MILLER_INL >= 1) f = w12_mul_wide<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, (WideLdsPtr)xg);
+    else w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, f, xg);
     g2_doubling_step29_wide<ISO, EPW>(r, l0, l1, l2, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
