@@ -937,13 +937,17 @@ BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
   const WideLdsPtr x = (WideLdsPtr)xg;
   W12 tab[2];                                     // f^17, f^35: the chain of exp_by_neg_z29
   {
-    W12 t, u;
-    w12_cyclotomic_sqr_nl(t, f);
-    w12_cyclotomic_sqr_nl(u, t);
-    w12_cyclotomic_sqr_nl(t, u);
-    w12_cyclotomic_sqr_nl(u, t);
-    w12_mul_wide_nl<EPW>(tab[0], u, f, xg);
-    w12_cyclotomic_sqr_nl(t, tab[0]);
+    // f^16 by four squarings, f^17 = f^16 f, f^34, f^35 = f^34 f -- the squarings spread over the wavefront in ONE loop (no out-of-line
+    // call with values by reference: each costs a lone wavefront ~2 us through the stack frame)
+    W12 t = f;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+      t = w12_cyclotomic_sqr_wide<EPW>(t, x);
+      if (k == 3) {
+        w12_mul_wide_nl<EPW>(tab[0], t, f, xg);
+        t = tab[0];
+      }
+    }
     w12_mul_wide_nl<EPW>(tab[1], t, f, xg);
   }
   W12 res = tab[1];

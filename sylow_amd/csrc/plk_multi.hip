@@ -817,8 +817,19 @@ static void launch_final_exp_wide(const u64* fa, const u64* fb, size_t n, u64* g
 }
 namespace plkh {
 // Small batches on one wavefront per one or two elements (k_miller_wide_batch / k_final_exp_wide_batch): up to this many pairings the
-// latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each)
-size_t wide_batch_max() { return wide_tail() ? (wide_pack() ? 4096 : 2048) : 0; }
+// latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each, and one more half-round)
+// SYLOW_HIP_WIDE_MAX=n / SYLOW_HIP_WIDE_VERIFY_MAX=n move the two caps (crossover runs, tools/dbg/time_small.py)
+static size_t env_size(const char* name) { const char* e = getenv(name); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }
+size_t wide_batch_max() {
+  static const size_t v = env_size("SYLOW_HIP_WIDE_MAX");
+  return !wide_tail() ? 0 : v ? v : wide_pack() ? 6144 : 2048;      // 6144 pairings: three half-rounds of wavefronts, 3.6 against 4.2 ms; 7168: 4.6
+}
+// ... and up to this many verifications (2 n Miller loops + n final exponentiations; two rounds of wavefronts at the cap: 4096
+// verifications 3.8 against 5.4 ms on the lane-pair kernel, 6144: 5.7 against 5.4)
+size_t wide_verify_max() {
+  static const size_t v = env_size("SYLOW_HIP_WIDE_VERIFY_MAX");
+  return !wide_tail() ? 0 : v ? v : wide_pack() ? 4096 : 1024;
+}
 // pairing(P_i, Q_i), i < n: raw values through `scratch` (48 n words), Gt values to gt_out (SoA stride n)
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;

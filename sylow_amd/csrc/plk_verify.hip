@@ -310,7 +310,7 @@ static int32_t verify_one_final_exp(const uint64_t* pk_xy, const uint8_t* pk_inf
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   // a few verifications are pure latency on one lane pair each (6.8 ms): the same product e(sig, G2gen) e(-H, pk) with the same reading of
   // identities on one wavefront per Miller loop and per final exponentiation (3 ms)
-  if (n <= plkh::wide_batch_max() / 2) {  // small batches: -H(m_i), then a wavefront per Miller loop and per final exponentiation
+  if (n <= plkh::wide_verify_max()) {  // small batches: -H(m_i), then a wavefront per Miller loop and per final exponentiation
     host::Lease ws;
     int32_t rc = ws.acquire((8 + 96) * n * sizeof(u64) + n, (hipStream_t)stream);
     if (rc != SYLOW_HIP_OK) return rc;

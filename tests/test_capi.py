@@ -92,9 +92,10 @@ def test_environment_switches_are_the_documented_ones():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     read = set()
     for f in glob.glob(os.path.join(root, "sylow_amd", "csrc", "*.h*")):
-        read |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+        src = open(f).read()
+        read |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', src)) | set(re.findall(r'env_size\("([A-Z0-9_]+)"\)', src))
     assert read == {"SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER",
-                    "SYLOW_HIP_SIGN_WIDE_MAX"}
+                    "SYLOW_HIP_SIGN_WIDE_MAX", "SYLOW_HIP_WIDE_MAX", "SYLOW_HIP_WIDE_VERIFY_MAX"}
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     routes = open(os.path.join(root, "tests", "test_gpu_routes.py")).read()
     for name in read:

@@ -103,9 +103,9 @@ def test_verify_batch_planted_pattern_large(engine):
     assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1
 
 
-@pytest.mark.parametrize("n", [513, 1500, 2047])
+@pytest.mark.parametrize("n", [513, 1500, 2047, 3333])
 def test_verify_two_elements_per_wavefront_route(engine, coracle, n):
-    """512 < n <= 2048 verifications: 2 n Miller loops and n final exponentiations, two per wavefront.  Planted corruption and identity
+    """128 < n <= 4096 verifications: 2 n Miller loops and n final exponentiations, two per wavefront.  Planted corruption and identity
     flags in both halves; flags equal the planted pattern, the literal two-pairing form, and (a sample) the oracle."""
     g = np.random.default_rng(1234 + n)
     msgs = [g.integers(0, 256, size=int(g.integers(0, 70)), dtype=np.uint8).tobytes() for _ in range(n)]

@@ -52,10 +52,10 @@ def test_large_batch_kernel_equals_raw_miller_then_final_exp(engine, coracle):
     y^2 = x^3 + (9 - u): its Miller value differs from the reference's raw value by a factor in Fp*, its OUTPUT must not.
     The raw entry point keeps the reference's value bit for bit (oracle), and final_exp of it is the same Gt as the one-kernel route."""
     rng = Xoshiro(SEED + 33)
-    n = 4600
+    n = 6500
     _, _, p_xy, q_xy = random_points(engine, rng, n)
     raw = engine.miller_loop(p_xy, q_xy)
-    idx = np.arange(0, n, 383)
+    idx = np.arange(0, n, 541)
     assert np.array_equal(raw[idx], coracle.miller_loop(p_xy[idx], q_xy[idx]))
     gt = engine.pairing(p_xy, q_xy, pipelined=False)
     assert np.array_equal(gt, engine.final_exp(raw))
@@ -64,9 +64,9 @@ def test_large_batch_kernel_equals_raw_miller_then_final_exp(engine, coracle):
     assert np.array_equal(engine.pairing(p_xy[idx], q_xy[idx], pipelined=False), gt[idx])
 
 
-@pytest.mark.parametrize("n", [1025, 2050, 4095])
+@pytest.mark.parametrize("n", [1025, 2050, 4095, 6143])
 def test_two_elements_per_wavefront_route(engine, coracle, n):
-    """1024 < n <= 4096 (k_miller_wide_batch<2> / k_final_exp_wide_batch<2>): lanes 0-31 and 32-63 of a wavefront hold one pairing each.
+    """256 < n <= 6144 (k_miller_wide_batch<2> / k_final_exp_wide_batch<2>): lanes 0-31 and 32-63 of a wavefront hold one pairing each.
     An odd n leaves the last half without an element; identities are planted in either half, next to live neighbours.  Every row against
     the raw lane-pair Miller kernel + final exponentiation, a sample (both halves, first and last wavefront) against the oracle."""
     rng = Xoshiro(SEED + 91 + n)

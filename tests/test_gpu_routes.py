@@ -4,10 +4,10 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
   SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
                              shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
-                             above 4096 / 2048 elements reach them), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
+                             above 6144 / 4096 elements reach them; SYLOW_HIP_WIDE_MAX / SYLOW_HIP_WIDE_VERIFY_MAX move these two caps for crossover runs), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
                              default only batches above 16384 reach it; below, sign_wide.hip's eight lanes per signature)
   SYLOW_HIP_WIDE_PACK=0 / 1  the one-wavefront kernels of small batches with one element per wavefront at every size / two elements per
-                             wavefront from two elements on (default: two above one wavefront per compute unit, up to 4096 pairings)
+                             wavefront from two elements on (default: two above one wavefront per compute unit, up to 6144 pairings)
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
   SYLOW_HIP_STAGGER=0        k_pairing / k_bls_verify_fused launched plain (default from 2^17 elements: the launch is skewed by half a
                              period, plk_pairing.hip) -- the full-size C3 test is added to the files for this switch
