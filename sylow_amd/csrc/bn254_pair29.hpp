@@ -773,30 +773,30 @@ BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
   const bool s = (p & 1) != 0;
   const W2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
   // product p: pair k of (z0, z1), (z2, z3), (z4, z5);  s = 0: m = a b,  s = 1: w = (a + b)(a + xi b)   (w_fp4_square)
+  const W2 a = w2_sel3(k, z0, z2, z4), b = w2_sel3(k, z1, z3, z5);
   {
-    const W2 a = w2_sel3(k, z0, z2, z4), b = w2_sel3(k, z1, z3, z5);
     const W2 xs = w2_pick(a, w2_norm(w2_add(a, b)), s), ys = w2_pick(b, w2_xi_norm(b, a), s);
     const W2 pr = w2_mul_w(xs, ys);
     if (j < 6) wide_put(x, p, odd, pr);
   }
   __syncthreads();
-  // output p: 0: c0.c0 = 3 c0(0) - 2 z0   1: c1.c1 = 6 m(0) + 2 z1   2: c0.c1 = 3 c0(1) - 2 z4   3: c1.c2 = 6 m(1) + 2 z5
-  //           4: c1.c0 = 6 xi m(2) + 2 z2   5: c0.c2 = 3 c0(2) - 2 z3      with c0(k) = w(k) - m(k) - xi m(k)
+  // Outputs, with c0(k) = w(k) - m(k) - xi m(k).  Lane pair p forms the output whose z it already selected as a product operand (a for even
+  // p, b for odd p), from the products of pair ko:
+  //   p = 0: c0.c0 = 3 c0(0) - 2 z0   1: c1.c1 = 6 m(0) + 2 z1   2: c1.c0 = 6 xi m(2) + 2 z2   3: c0.c2 = 3 c0(2) - 2 z3
+  //       4: c0.c1 = 3 c0(1) - 2 z4   5: c1.c2 = 6 m(1) + 2 z5
+  // All three shapes are ONE pass c_w w + c_m m + c_mo (partner's m) + c_z z with lane-dependent coefficients (xi m on this lane is
+  // 9 m -/+ partner's m): 3 c0 - 2 z = 3 w - 30 m -/+ 3 mo - 2 z;  6 m + 2 z;  6 xi m + 2 z = 54 m -/+ 6 mo + 2 z.
   {
-    const int ko = p >> 1;
+    const int ko = p < 2 ? 0 : p < 4 ? 2 : 1;
+    const bool ta = p == 0 || p == 3 || p == 4, tc = p == 2;
     const W2 m = wide_get(x, 2 * ko, odd), w = wide_get(x, 2 * ko + 1, odd);
-    const W2 z = w2_pick(w2_pick(w2_pick(w2_pick(w2_pick(z3, z2, p == 4), z5, p == 3), z4, p == 2), z1, p == 1), z0, p == 0);   // a chain of selects: the nested ?: form is lowered as a divergent switch
-    W2 ra;                                                            // 3 (w - m - xi m) - 2 z in one pass, as w_fp4_square_fold
-    {
-      const F29 mo = xchg9(m.c);
-      const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
-      const i32 c[4] = {bn_keep(3), bn_keep(-30), bn_keep_v(lane_odd() ? -3 : 3), bn_keep(-2)};
-      ra = W2{f29_reduce_terms(t, c)};
-    }
-    const W2 rb = w2_lin2(m, 6, z, 2);
-    const W2 rc = w2_xi_lin(m, 6, z, 2);
-    const W2 r = w2_pick(w2_pick(ra, rc, p == 4), rb, p == 1 || p == 3);
-    if (j < 6) wide_put(x, 6 + p, odd, r);
+    const W2 z = w2_pick(a, b, s);
+    const F29 mo = xchg9(m.c);
+    const bool lo = lane_odd();
+    const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
+    const i32 c[4] = {bn_keep_v(ta ? 3 : 0), bn_keep_v(ta ? -30 : tc ? 54 : 6), bn_keep_v(ta ? (lo ? -3 : 3) : tc ? (lo ? 6 : -6) : 0), bn_keep_v(ta ? -2 : 2)};
+    const W2 r{f29_reduce_terms(t, c)};
+    if (j < 6) wide_put(x, 6 + (p < 2 ? p : p < 4 ? p + 2 : p - 2), odd, r);
   }
   __syncthreads();
   W12 r;
