@@ -765,6 +765,7 @@ BN_DEV W2 wide_get(WideLdsPtr x, int slot, int odd) {
   return r;
 }
 BN_DEV W2 w2_pick(const W2& a, const W2& b, bool c) { return W2{sel9(c, a.c, b.c)}; }                // c ? b : a
+BN_DEV W2 w2_real(const F29& k) { return W2{sel9(lane_odd(), k, F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}})}; }   // the Fp element k as (k, 0)
 BN_DEV W2 w2_sel3(int k, const W2& a, const W2& b, const W2& c) { return w2_pick(w2_pick(a, b, k == 1), c, k == 2); }
 template <int EPW = 1>
 BN_DEV W12 w12_cyclotomic_sqr_wide(const W12& f, WideLdsPtr x) {
@@ -1004,7 +1005,7 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
 // product replicated (one product: nothing to spread), four on four lane pairs (b h, a (b - f), g^2, e^2).  Inputs and outputs replicated;
 // the squares are taken with the product leaf (same values).  Products of level 1 meet in the P slots, those of level 3 in the T slots.
 template <bool ISO = false, int EPW = 1>
-BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
+BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, const F29& px, const F29& py, WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   {
     const W2 yz = w2_norm(w2_add(r.y, r.z));
@@ -1021,18 +1022,19 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
   l2 = w2_norm(w2_triple(xx));
   const W2 h = w2_norm(w2_sub(s, w2_add(b, c)));
   const W2 e = ISO ? w2_mul_27m3u(c) : w2_mul_w(w2_twist_b(), w2_norm(w2_triple(c)));      // E'': (9 - u) * 3c in one reduce pass
-  l1 = w2_neg(h);
   l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);
   const W2 f = w2_norm(w2_triple(e));
   const W2 g = w2_halve(w2_norm(w2_add(b, f)));
-  {
-    const int p = j < 4 ? j : 0;
-    const W2 u = w2_pick(w2_pick(w2_pick(b, a, p == 1), g, p == 2), e, p == 3);                 // 0: b   1: a   2: g   3: e
-    const W2 v = w2_pick(w2_pick(w2_pick(h, w2_sub(b, f), p == 1), g, p == 2), e, p == 3);     // 0: h   1: b - f   2: g   3: e
+  {   // two idle lane pairs scale the line: 4: l2 x_P, 5: l1 y_P (the real factor as the Fp2 element (k, 0))
+    const int p = j < 6 ? j : 0;
+    const W2 u = w2_pick(w2_pick(w2_pick(w2_pick(w2_pick(b, a, p == 1), g, p == 2), e, p == 3), l2, p == 4), w2_neg(h), p == 5);   // 0: b  1: a  2: g  3: e
+    const W2 v = w2_pick(w2_pick(w2_pick(w2_pick(h, w2_sub(b, f), p == 1), g, p == 2), e, p == 3), w2_real(sel9(p == 5, px, py)), p >= 4);   // 0: h  1: b - f  2: g  3: e
     const W2 pr = w2_mul_w(u, v);
-    if (j < 4) wide_put(x, WL_T + p, odd, pr);
+    if (j < 6) wide_put(x, WL_T + p, odd, pr);
   }
   __syncthreads();
+  l2 = wide_get(x, WL_T + 4, odd);
+  l1 = wide_get(x, WL_T + 5, odd);
   r.z = wide_get(x, WL_T, odd);
   r.x = wide_get(x, WL_T + 1, odd);
   r.y = w2_lin2(wide_get(x, WL_T + 2, odd), 1, wide_get(x, WL_T + 3, odd), -3);
@@ -1040,7 +1042,7 @@ BN_DEV void g2_doubling_step29_wide(G2W& r, W2& l0, W2& l1, W2& l2, WideLdsPtr x
 // g2_addition_step29 with its thirteen products in four levels (2 + 4 + 3 + 4 lane pairs); inputs and outputs replicated.  Levels 1 and 3
 // meet in the P slots, levels 2 and 4 in the T slots (a barrier separates every reuse).
 template <int EPW = 1>
-BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, WideLdsPtr x) {
+BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2, const F29& px, const F29& py, WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   {   // level 1: z bx, z by
     const W2 pr = w2_mul_w(r.z, w2_pick(bx, by, j == 1));
@@ -1048,17 +1050,17 @@ BN_DEV void g2_addition_step29_wide(G2W& r, const W2& bx, const W2& by, W2& l0, 
   }
   __syncthreads();
   const W2 d = w2_sub(r.x, wide_get(x, WL_P, odd)), e = w2_sub(r.y, wide_get(x, WL_P + 1, odd));      // D
-  l1 = d;
-  l2 = w2_neg(e);
   const W2 dn = w2_norm(d), en = w2_norm(e);
-  {   // level 2: e bx, d by, dn^2, en^2
-    const int p = j < 4 ? j : 0;
-    const W2 u = w2_pick(w2_pick(w2_pick(e, d, p == 1), dn, p == 2), en, p == 3);
-    const W2 v = w2_pick(w2_pick(w2_pick(bx, by, p == 1), dn, p == 2), en, p == 3);
+  {   // level 2: e bx, d by, dn^2, en^2 -- and the scaled line on two idle lane pairs: 4: l2 x_P = -e x_P, 5: l1 y_P = d y_P (slots P + 4, P + 5)
+    const int p = j < 6 ? j : 0;
+    const W2 u = w2_pick(w2_pick(w2_pick(w2_pick(w2_pick(e, d, p == 1), dn, p == 2), en, p == 3), w2_neg(e), p == 4), d, p == 5);
+    const W2 v = w2_pick(w2_pick(w2_pick(w2_pick(bx, by, p == 1), dn, p == 2), en, p == 3), w2_real(sel9(p == 5, px, py)), p >= 4);
     const W2 pr = w2_mul_w(u, v);
-    if (j < 4) wide_put(x, WL_T + p, odd, pr);
+    if (j < 6) wide_put(x, p < 4 ? WL_T + p : WL_P + p, odd, pr);
   }
   __syncthreads();
+  l2 = wide_get(x, WL_P + 4, odd);
+  l1 = wide_get(x, WL_P + 5, odd);
   l0 = w2_xi_lin(w2_sub(wide_get(x, WL_T, odd), wide_get(x, WL_T + 1, odd)), 1, bx, 0);               // xi (e bx - d by)
   const W2 f = wide_get(x, WL_T + 2, odd), e2 = wide_get(x, WL_T + 3, odd);
   {   // level 3: dn f, x f, z en^2
@@ -1109,8 +1111,8 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
   W2 l0, l1, l2;
   auto line = [&]() {
     W12 ln;
-    ln.c0.c0 = l0; ln.c0.c1 = zero; ln.c0.c2 = w2_scale(l2, px);
-    ln.c1.c0 = zero; ln.c1.c1 = w2_scale(l1, py); ln.c1.c2 = zero;
+    ln.c0.c0 = l0; ln.c0.c1 = zero; ln.c0.c2 = l2;             // l1, l2 come out of the steps already scaled by y_P, x_P
+    ln.c1.c0 = zero; ln.c1.c1 = l1; ln.c1.c2 = zero;
     if (BN_WIDE_MILLER_INL >= 2) f = w12_mul_wide<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, ln, (WideLdsPtr)xg);
     else w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_LINE : WK_DENSE>(f, f, ln, xg);
   };
@@ -1119,19 +1121,19 @@ BN_NOINLINE void miller_loop29_wide(S12& fout, const Fp& pxs, const Fp& pys, con
   for (int i = 0; i < 64; ++i) {
     if (BN_WIDE_MILLER_INL >= 1) f = w12_mul_wide<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, (WideLdsPtr)xg);
     else w12_mul_wide_nl<EPW, BN_WIDE_KINDS ? WK_SQUARE : WK_DENSE>(f, f, f, xg);
-    g2_doubling_step29_wide<ISO, EPW>(r, l0, l1, l2, (WideLdsPtr)xg);
+    g2_doubling_step29_wide<ISO, EPW>(r, l0, l1, l2, px, py, (WideLdsPtr)xg);
     line();
     if ((nz >> (63 - i)) & 1) {
-      g2_addition_step29_wide<EPW>(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, (WideLdsPtr)xg);
+      g2_addition_step29_wide<EPW>(r, qx, ((ng >> (63 - i)) & 1) ? w2_neg(qy) : qy, l0, l1, l2, px, py, (WideLdsPtr)xg);
       line();
     }
   }
   S2 q1x, q1y, q2x, q2y;
   g2_psi_affine(q1x, q1y, qxs, qys);
   g2_psi_affine(q2x, q2y, q1x, q1y);
-  g2_addition_step29_wide<EPW>(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2, (WideLdsPtr)xg);
+  g2_addition_step29_wide<EPW>(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2, px, py, (WideLdsPtr)xg);
   line();
-  g2_addition_step29_wide<EPW>(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2, (WideLdsPtr)xg);
+  g2_addition_step29_wide<EPW>(r, w2_from_s2(q2x), w2_from_s2(s2_neg(q2y)), l0, l1, l2, px, py, (WideLdsPtr)xg);
   line();
   w12_to_s12(fout, f);
 }
