@@ -887,27 +887,37 @@ BN_DEV void w12_mul_wide_core(WideLdsPtr x) {
     const int nu = KIND == WK_SQUARE ? 6 : 9;
     const int u = j >= nu ? 0 : (KIND == WK_SQUARE && j >= 3) ? j + 3 : j, g = u / 3, c = u % 3, base = WL_P + 6 * g;
     const W2 v0 = wide_get(x, base, odd), v1 = wide_get(x, base + 1, odd), v2 = wide_get(x, base + 2, odd), q = wide_get(x, base + 3 + c, odd);
-    const W2 r0 = w2_xi_lin(w2_sub(w2_sub(q, v1), v2), 1, v0, 1);               // v0 + xi (q0 - v1 - v2)
-    const W2 r1 = w2_xi_lin(v2, 1, w2_sub(w2_sub(q, v0), v1), 1);               // (q1 - v0 - v1) + xi v2
-    const W2 r2 = w2_reduce(w2_add(w2_sub(w2_sub(q, v0), v2), v1));             // q2 - v0 - v2 + v1
-    if (j < nu) wide_put(x, WL_T + u, odd, w2_sel3(c, r0, r1, r2));
+    // c = 0: v0 + xi (q - v1 - v2)   1: (q - v0 - v1) + xi v2   2: q - v0 - v2 + v1 -- ONE pass with lane-dependent coefficients over
+    // (X, partner's X, q, v0, v1, v2), X the value xi applies to (xi X on this lane is 9 X -/+ partner's X)
+    const W2 xv = w2_pick(v2, w2_sub(w2_sub(q, v1), v2), c == 0);
+    const F29 xo = xchg9(xv.c);
+    const bool lo = lane_odd();
+    const F29* const t[6] = {&xv.c, &xo, &q.c, &v0.c, &v1.c, &v2.c};
+    const i32 kx = c == 2 ? 0 : 1;
+    const i32 k[6] = {bn_keep_v(9 * kx), bn_keep_v(lo ? kx : -kx), bn_keep_v(c == 0 ? 0 : 1), bn_keep_v(c == 0 ? 1 : -1),
+                      bn_keep_v(c == 0 ? 0 : c == 1 ? -1 : 1), bn_keep_v(c == 2 ? -1 : 0)};
+    if (j < nu) wide_put(x, WL_T + u, odd, W2{f29_reduce_terms(t, k)});
   }
   __syncthreads();
   if (KIND == WK_SQUARE) {   // stage 3: c1.ci = 2 t.ci;  c0.c0 = m.c0 - t.c0 - xi t.c2;  c0.c1 = m.c1 - t.c1 - t.c0;  c0.c2 = m.c2 - t.c2 - t.c1
     const int o = j < 6 ? j : 0, i = o % 3;
     const W2 ti = wide_get(x, WL_T + i, odd), tp = wide_get(x, WL_T + (i + 2) % 3, odd), mi = wide_get(x, WL_T + 6 + i, odd);
-    const W2 ra = w2_norm(w2_add(ti, ti));
-    const W2 rb = w2_xi_lin(tp, -1, w2_sub(mi, ti), 1);
-    const W2 rc = w2_lin2(w2_sub(mi, ti), 1, tp, -1);
-    if (j < 6) wide_put(x, WL_OUT + o, odd, w2_pick(w2_pick(rc, rb, o == 0), ra, o >= 3));
+    // o >= 3: 2 t_i   o = 0: m_i - t_i - xi t_p   else: m_i - t_i - t_p -- one pass over (t_i, t_p, partner's t_p, m_i)
+    const F29 tpo = xchg9(tp.c);
+    const bool lo = lane_odd(), hi = o >= 3, o0 = o == 0;
+    const F29* const t[4] = {&ti.c, &tp.c, &tpo, &mi.c};
+    const i32 k[4] = {bn_keep_v(hi ? 2 : -1), bn_keep_v(hi ? 0 : o0 ? -9 : -1), bn_keep_v(o0 ? (lo ? -1 : 1) : 0), bn_keep_v(hi ? 0 : 1)};
+    if (j < 6) wide_put(x, WL_OUT + o, odd, W2{f29_reduce_terms(t, k)});
   } else {   // stage 3: output o (w12_mul): c1.ci = T2.ci - T0.ci - T1.ci;  c0.c0 = T0.c0 + xi T1.c2;  c0.c1 = T0.c1 + T1.c0;  c0.c2 = T0.c2 + T1.c1
     const int o = j < 6 ? j : 0, i = o % 3;
     const int pa = o >= 3 ? i : o, pb = o >= 3 ? 3 + i : o == 0 ? 5 : o == 1 ? 3 : 4, pc = o >= 3 ? 6 + i : 0;
     const W2 ta = wide_get(x, WL_T + pa, odd), tb = wide_get(x, WL_T + pb, odd), tc = wide_get(x, WL_T + pc, odd);
-    const W2 ra = w2_lin2(w2_sub(tc, ta), 1, tb, -1);
-    const W2 rb = w2_xi_lin(tb, 1, ta, 1);
-    const W2 rc = w2_norm(w2_add(ta, tb));
-    if (j < 6) wide_put(x, WL_OUT + o, odd, w2_pick(w2_pick(rc, rb, o == 0), ra, o >= 3));
+    // o >= 3: tc - ta - tb   o = 0: ta + xi tb   else: ta + tb -- one pass over (ta, tb, partner's tb, tc)
+    const F29 tbo = xchg9(tb.c);
+    const bool lo = lane_odd(), hi = o >= 3, o0 = o == 0;
+    const F29* const t[4] = {&ta.c, &tb.c, &tbo, &tc.c};
+    const i32 k[4] = {bn_keep_v(hi ? -1 : 1), bn_keep_v(hi ? -1 : o0 ? 9 : 1), bn_keep_v(o0 ? (lo ? 1 : -1) : 0), bn_keep_v(hi ? 1 : 0)};
+    if (j < 6) wide_put(x, WL_OUT + o, odd, W2{f29_reduce_terms(t, k)});
   }
   __syncthreads();
 }
