@@ -974,6 +974,37 @@ BN_NOINLINE void exp_by_neg_z29_wide(W12& r, const W12& f, WideLds* xg) {
   }
   r = w12_conj(res);
 }
+// w12_frobenius<E> on the wavefront: the five products by the Frobenius constants on five lane pairs (the conjugated coefficients c0.c1,
+// c0.c2, c1.c0, c1.c1, c1.c2 by k1, k2, kk, k1, k2), then the second factor kk of c1.c1 and c1.c2 on two -- two product levels instead
+// of seven products on one lane pair behind an out-of-line call by reference.  Same products in the same order: same values.
+template <int E, int EPW = 1>
+BN_DEV W12 w12_frobenius_wide(const W12& a, WideLdsPtr x) {
+  constexpr bool oddE = (E & 1) != 0;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
+  const W2 k1 = w2_const((E == 1) ? C_FROB6_C1_1 : (E == 2) ? C_FROB6_C1_2 : C_FROB6_C1_3);
+  const W2 k2 = w2_const((E == 1) ? C_FROB6_C2_1 : (E == 2) ? C_FROB6_C2_2 : C_FROB6_C2_3);
+  const W2 kk = w2_const((E == 1) ? C_FROB12_C1_1 : (E == 2) ? C_FROB12_C1_2 : C_FROB12_C1_3);
+  {
+    const int p = j < 5 ? j : 0;
+    const W2 c = w2_pick(w2_pick(w2_pick(w2_pick(a.c0.c1, a.c0.c2, p == 1), a.c1.c0, p == 2), a.c1.c1, p == 3), a.c1.c2, p == 4);
+    const W2 u = oddE ? w2_conj(c) : c;
+    const W2 v = w2_pick(w2_pick(k1, k2, p == 1 || p == 4), kk, p == 2);
+    const W2 pr = w2_mul_w(u, v);
+    if (j < 5) wide_put(x, WL_P + p, odd, pr);
+  }
+  __syncthreads();
+  {
+    const W2 u = wide_get(x, WL_P + 3 + (j == 1 ? 1 : 0), odd);
+    const W2 pr = w2_mul_w(u, kk);
+    if (j < 2) wide_put(x, WL_T + j, odd, pr);
+  }
+  __syncthreads();
+  W12 r;
+  r.c0.c0 = oddE ? w2_conj(a.c0.c0) : a.c0.c0;
+  r.c0.c1 = wide_get(x, WL_P, odd); r.c0.c2 = wide_get(x, WL_P + 1, odd);
+  r.c1.c0 = wide_get(x, WL_P + 2, odd); r.c1.c1 = wide_get(x, WL_T, odd); r.c1.c2 = wide_get(x, WL_T + 1, odd);
+  return r;
+}
 // final_exponentiation29 for a one-wavefront block whose 32 lane pairs all hold the same element
 template <int EPW = 1>
 BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* x) {
@@ -983,15 +1014,15 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
     w12_inv_nl(b, t);
     a = w12_conj(t);
     w12_mul_wide_nl<EPW>(d, a, b, x);
-    w12_frobenius_nl<2>(a, d);
+    a = w12_frobenius_wide<2, EPW>(d, (WideLdsPtr)x);
     w12_mul_wide_nl<EPW>(in, a, d, x);
   }
   exp_by_neg_z29_wide<EPW>(a, in, x);
-  w12_cyclotomic_sqr_nl(b, a);
-  w12_cyclotomic_sqr_nl(t, b);
+  b = w12_cyclotomic_sqr_wide<EPW>(a, (WideLdsPtr)x);             // the wide squaring inline: no lane-pair routine by reference on a lone wavefront
+  t = w12_cyclotomic_sqr_wide<EPW>(b, (WideLdsPtr)x);
   w12_mul_wide_nl<EPW>(d, t, b, x);
   exp_by_neg_z29_wide<EPW>(e, d, x);
-  w12_cyclotomic_sqr_nl(t, e);
+  t = w12_cyclotomic_sqr_wide<EPW>(e, (WideLdsPtr)x);
   exp_by_neg_z29_wide<EPW>(g, t, x);
   d = w12_conj(d);
   g = w12_conj(g);
@@ -1000,13 +1031,13 @@ BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* 
   w12_mul_wide_nl<EPW>(d, a, b, x);
   w12_mul_wide_nl<EPW>(t, a, e, x);
   w12_mul_wide_nl<EPW>(e, in, t, x);
-  w12_frobenius_nl<1>(t, d);
+  t = w12_frobenius_wide<1, EPW>(d, (WideLdsPtr)x);
   w12_mul_wide_nl<EPW>(b, t, e, x);
-  w12_frobenius_nl<2>(t, a);
+  t = w12_frobenius_wide<2, EPW>(a, (WideLdsPtr)x);
   w12_mul_wide_nl<EPW>(e, t, b, x);
   t = w12_conj(in);
   w12_mul_wide_nl<EPW>(a, t, d, x);
-  w12_frobenius_nl<3>(t, a);
+  t = w12_frobenius_wide<3, EPW>(a, (WideLdsPtr)x);
   w12_mul_wide_nl<EPW>(g, t, e, x);
   w12_to_s12(out, g);
 }
