@@ -414,6 +414,8 @@ int32_t sylow_hip_g1_sum_batch(const uint64_t* p_xy, const uint8_t* p_inf, size_
 }
 int32_t sylow_hip_g1_scalar_mul_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   ARGCHK(p_xy && k && out_xy && out_inf); if (!n) return SYLOW_HIP_OK;
+  // single calls and small batches: eight lanes per product (sign_wide.hip) -- one product 1.0 -> ~0.35 ms
+  if (plkh::wide_batch_max() != 0 && n <= g1h::sign_wide_max()) return g1h::g1_scalar_mul_wide(p_xy, p_inf, k, out_xy, out_inf, n, stream);
   // window tables in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: G1TableGlobal); a failed
   // lease keeps them in the stack frame
   host::Lease ws;

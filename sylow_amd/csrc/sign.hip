@@ -23,9 +23,11 @@ k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64*
 
 
 constexpr size_t SIGN_WIDE_MAX = 16384;      // 8 signatures per wavefront: up to two wavefronts per SIMD (16 384: 1.36 against 1.74 ms; 24 576: 1.98 against 1.76)
-static size_t sign_wide_max() {               // SYLOW_HIP_SIGN_WIDE_MAX: crossover measurements (tools/dbg/time_sign.py)
+namespace g1h {
+size_t sign_wide_max() {                      // SYLOW_HIP_SIGN_WIDE_MAX: crossover measurements (tools/dbg/time_sign.py)
   static const size_t v = [] { const char* e = getenv("SYLOW_HIP_SIGN_WIDE_MAX"); return e ? (size_t)atoll(e) : SIGN_WIDE_MAX; }();
   return v;
+}
 }
 
 extern "C" {
@@ -34,7 +36,7 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
   ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
   // single calls and small batches: eight lanes per signature (sign_wide.hip) -- one signature 2.1 -> 0.67 ms; the one-lane kernel below wins
   // once the batch fills the chip's lanes (SYLOW_HIP_WIDE_TAIL=0 switches every one-wavefront-per-element route off, this one included)
-  if (plkh::wide_batch_max() != 0 && n <= sign_wide_max()) return g1h::sign_wide(sk, msgs, msg_offsets, sig_xy, sig_inf, n, stream);
+  if (plkh::wide_batch_max() != 0 && n <= g1h::sign_wide_max()) return g1h::sign_wide(sk, msgs, msg_offsets, sig_xy, sig_inf, n, stream);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   host::Lease ws;
   // window tables in a leased global block, one contiguous KB per lane (bn254_pairing.hpp: G1TableGlobal); a failed lease keeps them in the

@@ -170,23 +170,13 @@ BN_DEV G1P hash_to_g1_group(const uint8_t* msg, size_t len, const DstPrime& dp, 
   return g1_add(a, b);
 }
 
-// STAMPS (tools/ubench/sign_wide_phases.hip only): clock64() at the phase boundaries of the block's first group into stamps[0..7]
+// k * P on the eight lanes of a group (g1_scalar_mul's GLV split, bn254_pairing.hpp): k1 * (+-P) on quad 0, k2 * (+-phi P) on quad 1, each with
+// its own accumulator and window table `tab[slot]` (LDS, slot = quad of the block), added once at the end.  p is the same on all eight lanes
+// (any representative; Z = 0 is the identity); the affine result comes back on every lane.
+typedef i32 (*QuadTab)[9][28];                              // per quad: 0P .. 8P, 27 words each
 template <bool STAMPS>
-__global__ void __launch_bounds__(WBLOCK)
-k_bls_sign_wide(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, u64* stamps) {
-  auto stamp = [&](int k) { if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (u64)clock64(); };
-  stamp(0);
-  __shared__ i32 tab[2 * EPB][9][28];                       // per quad: 0P .. 8P, 27 words each
-  const int lane = threadIdx.x & (GROUP - 1), q = lane >> 2, j = lane & 3, slot = (int)(threadIdx.x >> 2);
-  size_t i = (size_t)blockIdx.x * EPB + (threadIdx.x >> 3);
-  const bool live = i < n;
-  if (!live) i = n - 1;                                     // tail groups repeat the last element and store nothing (no lane leaves early)
-  // ---- H(m): both quads expand the message; quad 0 maps u0, quad 1 maps u1
-  const G1P h = hash_to_g1_group<STAMPS>(msgs + off[i], (size_t)(off[i + 1] - off[i]), dp, q, j, stamps);
-  stamp(4);
-  // ---- sk * H: GLV halves on the two quads
-  u32 k[8];
-  load_scalar(k, sk, n, i);
+BN_DEV void group_scalar_mul(Fp& x, Fp& y, bool& inf, const G1P& p, const u32 (&k)[8], int q, int j, int slot, QuadTab tab, u64* stamps) {
+  auto stamp = [&](int s) { if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[s] = (u64)clock64(); };
   u32 m1[4], m2[4];
   bool n1, n2;
   glv_decompose(m1, n1, m2, n2, k);
@@ -211,7 +201,7 @@ k_bls_sign_wide(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp,
   };
   {
     const F29 beta{{0x18ccb791, 0x175b1c3a, 0x0b83d6e2, 0x0e8ed071, 0x1282bee2, 0x04220e84, 0x1fe4017f, 0x15084d4a, 0x00169119}};   // beta 2^261 mod p
-    G1W t1{f29_from_fp_reduced(h.x), f29_from_fp_reduced(h.y), f29_from_fp_reduced(h.z)};
+    G1W t1{f29_from_fp_reduced(p.x), f29_from_fp_reduced(p.y), f29_from_fp_reduced(p.z)};
     const bool pinf = OpsF29::is_zero(t1.z);                // canonical identity, as g1_scalar_mul_t
     t1.x = OpsF29::select(t1.x, OpsF29::zero(), pinf);
     t1.y = OpsF29::select(t1.y, OpsF29::one(), pinf);
@@ -247,20 +237,60 @@ k_bls_sign_wide(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp,
     res = qadd(res, e, j);
   }
   stamp(6);
-  // ---- k1 P + k2 phi(P), to affine, stored by the group's first lane
+  // ---- k1 P + k2 phi(P), to affine
   {
     const G1W o{xq_f29(res.x), xq_f29(res.y), xq_f29(res.z)};
     const G1W a{q ? o.x : res.x, q ? o.y : res.y, q ? o.z : res.z}, b{q ? res.x : o.x, q ? res.y : o.y, q ? res.z : o.z};
     res = qadd(a, b, j);
   }
   const G1P s{f29_to_fp(res.x), f29_to_fp(res.y), f29_to_fp(res.z)};
-  Fp x, y; bool inf;
   g1_to_affine(x, y, inf, s);
+}
+
+// STAMPS (tools/ubench/sign_wide_phases.hip only): clock64() at the phase boundaries of the block's first group into stamps[0..7]
+template <bool STAMPS>
+__global__ void __launch_bounds__(WBLOCK)
+k_bls_sign_wide(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, u64* stamps) {
+  auto stamp = [&](int k) { if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (u64)clock64(); };
+  stamp(0);
+  __shared__ i32 tab[2 * EPB][9][28];
+  const int lane = threadIdx.x & (GROUP - 1), q = lane >> 2, j = lane & 3, slot = (int)(threadIdx.x >> 2);
+  size_t i = (size_t)blockIdx.x * EPB + (threadIdx.x >> 3);
+  const bool live = i < n;
+  if (!live) i = n - 1;                                     // tail groups repeat the last element and store nothing (no lane leaves early)
+  // ---- H(m): both quads expand the message; quad 0 maps u0, quad 1 maps u1
+  const G1P h = hash_to_g1_group<STAMPS>(msgs + off[i], (size_t)(off[i + 1] - off[i]), dp, q, j, stamps);
+  stamp(4);
+  // ---- sk * H: GLV halves on the two quads
+  u32 k[8];
+  load_scalar(k, sk, n, i);
+  Fp x, y; bool inf;
+  group_scalar_mul<STAMPS>(x, y, inf, h, k, q, j, slot, tab, stamps);
   if (live && lane == 0) {
     store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
     oinf[i] = inf ? 1 : 0;
   }
   stamp(7);
+}
+// k_i * P_i for small batches (sylow_hip_g1_scalar_mul_batch: group.rs:619-650 through the GLV split), eight lanes per product: one product
+// ~0.35 ms against ~1.0 ms on one lane
+__global__ void __launch_bounds__(WBLOCK)
+k_g1_scalar_mul_wide(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n) {
+  __shared__ i32 tab[2 * EPB][9][28];
+  const int lane = threadIdx.x & (GROUP - 1), q = lane >> 2, j = lane & 3, slot = (int)(threadIdx.x >> 2);
+  size_t i = (size_t)blockIdx.x * EPB + (threadIdx.x >> 3);
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  const bool pi = pinf && pinf[i];
+  const G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), pi ? fp_zero() : fp_one()};
+  u32 k[8];
+  load_scalar(k, ks, n, i);
+  Fp x, y; bool inf;
+  group_scalar_mul<false>(x, y, inf, p, k, q, j, slot, tab, nullptr);
+  if (live && lane == 0) {
+    store_fp(oxy, n, i, 0, x); store_fp(oxy, n, i, 4, y);
+    oinf[i] = inf ? 1 : 0;
+  }
 }
 // H(m_i) (or -H(m_i)) affine for small batches: the hash part alone, eight lanes per message (one message: ~0.4 ms against ~1.0 ms on one lane)
 __global__ void __launch_bounds__(WBLOCK)
@@ -284,6 +314,12 @@ namespace g1h {
 int32_t hash_to_g1_wide(const uint8_t* msgs, const uint64_t* msg_offsets, const DstPrime& dp, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream) {
   if (!n) return SYLOW_HIP_OK;
   wsign::k_hash_to_g1_wide<<<dim3((unsigned)((n + wsign::EPB - 1) / wsign::EPB)), dim3(wsign::WBLOCK), 0, (hipStream_t)stream>>>(msgs, msg_offsets, dp, out_xy, out_inf, n, negate);
+  LAUNCHED();
+}
+// k_i * P_i, i < n <= sign_wide_max(), on eight lanes each
+int32_t g1_scalar_mul_wide(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
+  if (!n) return SYLOW_HIP_OK;
+  wsign::k_g1_scalar_mul_wide<<<dim3((unsigned)((n + wsign::EPB - 1) / wsign::EPB)), dim3(wsign::WBLOCK), 0, (hipStream_t)stream>>>(p_xy, p_inf, k, out_xy, out_inf, n);
   LAUNCHED();
 }
 // signatures of n <= sign_wide_max() messages on eight lanes each

@@ -4,7 +4,7 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
   SYLOW_HIP_WIDE_TAIL=0      no one-wavefront-per-element kernels: small batches and the single-element tails of the one-boolean
                              shapes run on the lane-pair kernels (k_pairing, k_bls_verify_fused, k_final_exp: by default only batches
-                             above 6144 / 4096 elements reach them; SYLOW_HIP_WIDE_MAX / SYLOW_HIP_WIDE_VERIFY_MAX move these two caps for crossover runs), and bls_sign_batch runs on one lane per signature (k_bls_sign: by
+                             above 6144 / 4096 elements reach them; SYLOW_HIP_WIDE_MAX / SYLOW_HIP_WIDE_VERIFY_MAX move these two caps for crossover runs), and bls_sign_batch / g1_scalar_mul_batch run on one lane per element (k_bls_sign: by
                              default only batches above 16384 reach it; below, sign_wide.hip's eight lanes per signature)
   SYLOW_HIP_WIDE_PACK=0 / 1  the one-wavefront kernels of small batches with one element per wavefront at every size / two elements per
                              wavefront from two elements on (default: two above one wavefront per compute unit, up to 6144 pairings)
@@ -24,7 +24,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
-         "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py"]
+         "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py", "tests/test_gpu_groups.py"]
 ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"}, {"SYLOW_HIP_STAGGER": "0"},
           {"SYLOW_HIP_STAGGER": "2"}, {"SYLOW_HIP_WIDE_PACK": "0"}, {"SYLOW_HIP_WIDE_PACK": "1"},
           {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
