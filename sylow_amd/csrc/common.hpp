@@ -89,3 +89,35 @@ BN_DEV void write_be_fp(uint8_t* b, const Fp& plain) {
     q[0] = (uint8_t)(w >> 24); q[1] = (uint8_t)(w >> 16); q[2] = (uint8_t)(w >> 8); q[3] = (uint8_t)w;
   }
 }
+
+// ---- EVM alt_bn128 point / scalar codecs (examples/reth_bn128.rs:99-217), shared by g1.hip and sign_wide.hip -----------------------
+// read_point + new_g1_point (reth_bn128.rs:107-128): Montgomery-form affine point or identity
+BN_DEV uint8_t evm_read_g1(G1P& out, const uint8_t* b) {
+  Fp x, y;
+  bool okx = read_be_fp(x, b), oky = read_be_fp(y, b + 32);
+  if (!(okx && oky)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_DECODE_ERROR; }
+  if (fp_is_zero(x) && fp_is_zero(y)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_OK; }
+  Fp xm = fp_to_mont(x), ym = fp_to_mont(y);
+  out = G1P{xm, ym, fp_one()};
+  return g1_on_curve_affine(xm, ym) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
+}
+// to_be_bytes_scrubbed (g1.rs:182-192): all-zero bytes for the identity
+BN_DEV void evm_write_g1(uint8_t* b, const G1P& p) {
+  Fp x, y; bool inf;
+  g1_to_affine(x, y, inf, p);
+  Fp zero = fp_zero();
+  write_be_fp(b, inf ? zero : fp_from_mont(x));
+  write_be_fp(b + 32, inf ? zero : fp_from_mont(y));
+}
+// EIP-196 accepts any 256-bit scalar; G1 has prime order r, so reduce mod r (2^256 < 6r).  (The reference adapter unwraps
+// Fr::from_be_bytes and would panic for k >= r, reth_bn128.rs:144.)
+BN_DEV void evm_read_scalar(u32 (&k)[8], const uint8_t* b) {
+  Fp kx;
+  read_be_fp(kx, b);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) k[w] = kx.v[w];
+  cond_sub_const(k, 0xc0000004u, 0x0f87d64fu, 0xe6e5c245u, 0xa0cfa121u, 0x06056174u, 0xe14116dau, 0x84c680a6u, 0xc19139cbu);  // 4r
+  cond_sub_const(k, 0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2r
+  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);  // r
+}
+

@@ -274,24 +274,6 @@ __global__ void __launch_bounds__(BLOCK) k_hash_to_field(const uint8_t* msgs, co
 // identity, G1 points must be on the curve (G1Affine::new, g1.rs:111-132), G2 points on the twist AND in
 // the r-torsion (G2Projective::new, g2.rs:460-525); G2 is encoded x.c1 | x.c0 | y.c1 | y.c0.
 // status: OK, DECODE_ERROR (= Bn128FieldPointNotAMember), NOT_ON_CURVE / NOT_IN_SUBGROUP (= Bn128AffineGFailedToCreate).
-// read_point + new_g1_point (reth_bn128.rs:107-128): Montgomery-form affine point or identity
-BN_DEV uint8_t evm_read_g1(G1P& out, const uint8_t* b) {
-  Fp x, y;
-  bool okx = read_be_fp(x, b), oky = read_be_fp(y, b + 32);
-  if (!(okx && oky)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_DECODE_ERROR; }
-  if (fp_is_zero(x) && fp_is_zero(y)) { out = proj_zero<OpsFp>(); return SYLOW_HIP_ST_OK; }
-  Fp xm = fp_to_mont(x), ym = fp_to_mont(y);
-  out = G1P{xm, ym, fp_one()};
-  return g1_on_curve_affine(xm, ym) ? SYLOW_HIP_ST_OK : SYLOW_HIP_ST_NOT_ON_CURVE;
-}
-// to_be_bytes_scrubbed (g1.rs:182-192): all-zero bytes for the identity
-BN_DEV void evm_write_g1(uint8_t* b, const G1P& p) {
-  Fp x, y; bool inf;
-  g1_to_affine(x, y, inf, p);
-  Fp zero = fp_zero();
-  write_be_fp(b, inf ? zero : fp_from_mont(x));
-  write_be_fp(b + 32, inf ? zero : fp_from_mont(y));
-}
 __global__ void __launch_bounds__(BLOCK) k_evm_ecadd(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
   size_t i = TID;
   if (i >= n) return;
@@ -309,14 +291,8 @@ __global__ void HEAVY_BOUNDS k_evm_ecmul(const uint8_t* in, uint8_t* out, uint8_
   uint8_t st = evm_read_g1(a, in + 96 * i);
   status[i] = st;
   if (st) { __builtin_memset(out + 64 * i, 0, 64); return; }
-  Fp kx;
-  read_be_fp(kx, in + 96 * i + 64);
-  // EIP-196 accepts any 256-bit scalar; G1 has prime order r, so reduce mod r (2^256 < 6r).  (The reference
-  // adapter unwraps Fr::from_be_bytes and would panic for k >= r, reth_bn128.rs:144.)
-  u32 k[8] = {kx.v[0], kx.v[1], kx.v[2], kx.v[3], kx.v[4], kx.v[5], kx.v[6], kx.v[7]};
-  cond_sub_const(k, 0xc0000004u, 0x0f87d64fu, 0xe6e5c245u, 0xa0cfa121u, 0x06056174u, 0xe14116dau, 0x84c680a6u, 0xc19139cbu);  // 4r
-  cond_sub_const(k, 0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u);  // 2r
-  cond_sub_const(k, 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u);  // r
+  u32 k[8];
+  evm_read_scalar(k, in + 96 * i + 64);
   evm_write_g1(out + 64 * i, g1_scalar_mul(a, k));
 }
 
@@ -483,6 +459,8 @@ int32_t sylow_hip_evm_ecadd_batch(const uint8_t* in, uint8_t* out, uint8_t* stat
 }
 int32_t sylow_hip_evm_ecmul_batch(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
   ARGCHK(in && out && status); if (!n) return SYLOW_HIP_OK;
+  // single calls and small batches: eight lanes per product (sign_wide.hip) -- one ecMul 1.1 -> ~0.36 ms
+  if (plkh::wide_batch_max() != 0 && n <= g1h::sign_wide_max()) return g1h::evm_ecmul_wide(in, out, status, n, stream);
   k_evm_ecmul<<<GRID(n)>>>(in, out, status, n); LAUNCHED();
 }
 int32_t sylow_hip_g1_to_be_bytes_batch(const uint64_t* p_xy, const uint8_t* p_inf, uint8_t* out, size_t n, void* stream) {

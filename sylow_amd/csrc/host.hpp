@@ -54,6 +54,7 @@ int32_t hash_to_g1_proj(const uint8_t* msgs, const uint64_t* msg_offsets, uint64
 int32_t sign_wide(const uint64_t* sk, const uint8_t* msgs, const uint64_t* msg_offsets, uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream);
 int32_t g1_scalar_mul_wide(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream);
 size_t sign_wide_max();
+int32_t evm_ecmul_wide(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream);
 // sign_wide.hip: the same on eight lanes per message (small batches)
 int32_t hash_to_g1_wide(const uint8_t* msgs, const uint64_t* msg_offsets, const DstPrime& dp, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream);
 int32_t hash_to_g1_dst(const uint8_t* msgs, const uint64_t* msg_offsets, const DstPrime& dp, uint64_t* out_xy, uint8_t* out_inf, size_t n, int negate, void* stream);

@@ -292,6 +292,32 @@ k_g1_scalar_mul_wide(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* ox
     oinf[i] = inf ? 1 : 0;
   }
 }
+// ecMul (EIP-196, examples/reth_bn128.rs:137-157) for single calls and small batches: every lane of the group decodes the 96 bytes, the
+// product runs on the group's eight lanes, its first lane writes the 64 bytes (zeros with an error status, like k_evm_ecmul)
+__global__ void __launch_bounds__(WBLOCK)
+k_evm_ecmul_wide(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n) {
+  __shared__ i32 tab[2 * EPB][9][28];
+  const int lane = threadIdx.x & (GROUP - 1), q = lane >> 2, j = lane & 3, slot = (int)(threadIdx.x >> 2);
+  size_t i = (size_t)blockIdx.x * EPB + (threadIdx.x >> 3);
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  G1P a;
+  const uint8_t st = evm_read_g1(a, in + 96 * i);
+  u32 k[8];
+  evm_read_scalar(k, in + 96 * i + 64);
+  Fp x, y; bool inf;
+  group_scalar_mul<false>(x, y, inf, a, k, q, j, slot, tab, nullptr);      // a is the identity when the point did not decode
+  if (live && lane == 0) {
+    status[i] = st;
+    if (st) {
+      __builtin_memset(out + 64 * i, 0, 64);
+    } else {
+      const Fp zero = fp_zero();
+      write_be_fp(out + 64 * i, inf ? zero : fp_from_mont(x));
+      write_be_fp(out + 64 * i + 32, inf ? zero : fp_from_mont(y));
+    }
+  }
+}
 // H(m_i) (or -H(m_i)) affine for small batches: the hash part alone, eight lanes per message (one message: ~0.4 ms against ~1.0 ms on one lane)
 __global__ void __launch_bounds__(WBLOCK)
 k_hash_to_g1_wide(const uint8_t* msgs, const u64* off, DstPrime dp, u64* oxy, uint8_t* oinf, size_t n, int negate) {
@@ -320,6 +346,11 @@ int32_t hash_to_g1_wide(const uint8_t* msgs, const uint64_t* msg_offsets, const 
 int32_t g1_scalar_mul_wide(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* k, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
   if (!n) return SYLOW_HIP_OK;
   wsign::k_g1_scalar_mul_wide<<<dim3((unsigned)((n + wsign::EPB - 1) / wsign::EPB)), dim3(wsign::WBLOCK), 0, (hipStream_t)stream>>>(p_xy, p_inf, k, out_xy, out_inf, n);
+  LAUNCHED();
+}
+int32_t evm_ecmul_wide(const uint8_t* in, uint8_t* out, uint8_t* status, size_t n, void* stream) {
+  if (!n) return SYLOW_HIP_OK;
+  wsign::k_evm_ecmul_wide<<<dim3((unsigned)((n + wsign::EPB - 1) / wsign::EPB)), dim3(wsign::WBLOCK), 0, (hipStream_t)stream>>>(in, out, status, n);
   LAUNCHED();
 }
 // signatures of n <= sign_wide_max() messages on eight lanes each
