@@ -79,6 +79,10 @@ int32_t build_g2_comb(bn254::i32* table, void* stream);                         
 // plk_multi.hip: small batches on one wavefront per element (0 from wide_batch_max = route disabled)
 size_t wide_batch_max();
 size_t wide_verify_max();
+int32_t miller_raw_wide_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
+int32_t final_exp_wide_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
+int32_t verify_two_pairings_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* h, const uint8_t* h_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
+                                       uint64_t* scratch, uint8_t* ok, size_t n, void* stream);
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream);
 int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* hneg, const uint8_t* hneg_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
                           uint64_t* scratch, uint8_t* ok, size_t n, void* stream);

@@ -574,10 +574,10 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
 }
 // Small batches, one WAVEFRONT per EPW elements (EPW = 1: grid = n blocks of 64; EPW = 2: lanes 0-31 / 32-63 of a block hold one element
 // each): element e < n is pair e of set A, element n + e pair e of set B (B optional).  qxy NULL = the G2 generator for every pair of that
-// set.  An identity on either side gives 1.  Miller values up to factors in Fp* (isomorphic curves), SoA stride n: input of the
-// k_final_exp_wide_* kernels only.  The loop runs on whatever the rows hold and the identity is selected afterwards, so that both halves of
+// set.  An identity on either side gives 1.  ISO: Miller values up to factors in Fp* (isomorphic curves), SoA stride n: input of the
+// k_final_exp_wide_* kernels only; ISO = false: the reference's raw Miller value (sylow_hip_miller_loop_batch at small sizes).  The loop runs on whatever the rows hold and the identity is selected afterwards, so that both halves of
 // a wavefront reach every barrier together.
-template <int EPW>
+template <int EPW, bool ISO = true>
 __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
                                                  const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n) {
   __shared__ WideLds lds[EPW];
@@ -600,12 +600,12 @@ __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* p
     } else {
       const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
       const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
-      miller_loop29_wide<true, 1>(f, px, py, qx, qy, &lds[0]);
+      miller_loop29_wide<ISO, 1>(f, px, py, qx, qy, &lds[0]);
     }
   } else {
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
     const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
-    miller_loop29_wide<true, EPW>(f, px, py, qx, qy, &lds[half]);
+    miller_loop29_wide<ISO, EPW>(f, px, py, qx, qy, &lds[half]);
     if (ident) f = s12_one();
   }
   if (live && wide_j<EPW>((int)(threadIdx.x & 63u)) == 0) store_s12(fout, n, i, odd, f);
@@ -815,6 +815,15 @@ static void launch_final_exp_wide(const u64* fa, const u64* fb, size_t n, u64* g
   else
     plk::k_final_exp_wide_batch<1><<<dim3((unsigned)n), dim3(64), 0, st>>>(fa, fb, n, gout, is_one);
 }
+// eq_i = [ a_i == b_i ] for Gt values (SoA stride n, canonical limbs)
+__global__ void __launch_bounds__(BLOCK) k_gt_eq_flags(const u64* a, const u64* b, size_t n, uint8_t* eq) {
+  const size_t i = TID;
+  if (i >= n) return;
+  u64 d = 0;
+#pragma unroll 8
+  for (int w = 0; w < 48; ++w) d |= a[(size_t)w * n + i] ^ b[(size_t)w * n + i];
+  eq[i] = d == 0 ? 1 : 0;
+}
 namespace plkh {
 // Small batches on one wavefront per one or two elements (k_miller_wide_batch / k_final_exp_wide_batch): up to this many pairings the
 // latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each, and one more half-round)
@@ -844,6 +853,32 @@ int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const ui
   u64 *fa = scratch, *fb = scratch + 48 * n;
   launch_miller_wide(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n, st);
   launch_final_exp_wide(fa, fb, n, nullptr, ok, st);
+  LAUNCHED();
+}
+// the reference's raw Miller values (no identity flags: the raw entry point has none), i < n <= wide_batch_max()
+int32_t miller_raw_wide_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (wide_pack() && n > wide_pack())
+    plk::k_miller_wide_batch<2, false><<<dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st>>>(p_xy, nullptr, q_xy, nullptr, f_out, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+  else
+    plk::k_miller_wide_batch<1, false><<<dim3((unsigned)n), dim3(64), 0, st>>>(p_xy, nullptr, q_xy, nullptr, f_out, nullptr, nullptr, nullptr, nullptr, nullptr, n);
+  LAUNCHED();
+}
+// final_exponentiation(f_i), i < n <= wide_batch_max()
+int32_t final_exp_wide_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
+  launch_final_exp_wide(f, nullptr, n, gt_out, nullptr, (hipStream_t)stream);
+  LAUNCHED();
+}
+// ok_i = [ pairing(sig_i, G2gen) == pairing(h_i, pk_i) ] evaluated literally (two final exponentiations, a comparison of Gt values);
+// scratch: 192 n words
+int32_t verify_two_pairings_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* h, const uint8_t* h_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
+                                       uint64_t* scratch, uint8_t* ok, size_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  u64 *fa = scratch, *fb = scratch + 48 * n, *ga = scratch + 96 * n, *gb = scratch + 144 * n;
+  launch_miller_wide(sig_xy, sig_inf, nullptr, nullptr, fa, h, h_inf, pk_xy, pk_inf, fb, n, st);
+  launch_final_exp_wide(fa, nullptr, n, ga, nullptr, st);
+  launch_final_exp_wide(fb, nullptr, n, gb, nullptr, st);
+  k_gt_eq_flags<<<GRID(n)>>>(ga, gb, n, ok);
   LAUNCHED();
 }
 }  // namespace plkh

@@ -142,10 +142,13 @@ hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t 
 extern "C" {
 int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
+  // small batches: one wavefront per one or two Miller loops on the reference's curves (same field values step by step: the raw value)
+  if (n <= plkh::wide_batch_max()) return plkh::miller_raw_wide_batch(p_xy, q_xy, f_out, n, stream);
   plk::k_miller_loop<<<GRID(2 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
 }
 int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
+  if (n <= plkh::wide_batch_max()) return plkh::final_exp_wide_batch(f, gt_out, n, stream);      // small batches: one wavefront per one or two elements
   plk::k_final_exp<<<GRID(2 * n)>>>(f, gt_out, n); LAUNCHED();
 }
 int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {

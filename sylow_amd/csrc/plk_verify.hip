@@ -339,6 +339,18 @@ int32_t sylow_hip_bls_verify_fused_batch(const uint64_t* pk_xy, const uint8_t* p
 int32_t sylow_hip_bls_verify_two_pairings_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint8_t* msgs, const uint64_t* msg_offsets,
                                                 const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
+  if (n <= plkh::wide_verify_max()) {  // small batches: H(m_i), a wavefront per one or two Miller loops / final exponentiations, Gt values compared
+    host::Lease ws;
+    int32_t rc = ws.acquire((8 + 192) * n * sizeof(u64) + n, (hipStream_t)stream);
+    if (rc != SYLOW_HIP_OK) return rc;
+    u64* h = (u64*)ws.p;
+    u64* scratch = h + 8 * n;
+    uint8_t* hinf = (uint8_t*)(scratch + 192 * n);
+    rc = g1h::hash_to_g1(msgs, msg_offsets, h, hinf, n, /*negate=*/0, stream);
+    if (rc == SYLOW_HIP_OK) rc = plkh::verify_two_pairings_wide_batch(pk_xy, pk_inf, h, hinf, sig_xy, sig_inf, scratch, ok, n, stream);
+    const int32_t r2 = ws.release();
+    return rc != SYLOW_HIP_OK ? rc : r2;
+  }
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, (hipStream_t)stream);
