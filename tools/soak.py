@@ -1,5 +1,5 @@
 """Soak / determinism harness: random batch sizes through every pairing-based entry point, each call issued twice (results must be
-bit-identical) and a slice checked against the oracle.  `python tools/soak.py [seconds]`"""
+bit-identical) and a slice checked against the oracle.  `python tools/soak.py [seconds [seed]]`"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,7 +10,7 @@ import sylow_amd
 from test_gpu_multi_pairing import proj1, proj2, G1, G2
 
 eng = sylow_amd.Engine(0)
-rng = Xoshiro(0xC0FFEE)
+rng = Xoshiro(int(sys.argv[2], 0) if len(sys.argv) > 2 else 0xC0FFEE)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0      # tests/test_gpu_runtime.py runs 20 s of it
 t0 = time.time()
 NMAX = 4096
