@@ -85,7 +85,7 @@ int32_t verify_two_pairings_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_
                                        uint64_t* scratch, uint8_t* ok, size_t n, void* stream);
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream);
 int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* hneg, const uint8_t* hneg_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
-                          uint64_t* scratch, uint8_t* ok, size_t n, void* stream);
+                          uint64_t* scratch, uint8_t* ok, size_t n, void* stream, int one_key = 0);
 // plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
 }  // namespace plkh

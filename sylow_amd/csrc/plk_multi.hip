@@ -579,8 +579,8 @@ __global__ void HEAVY_BOUNDS k_miller_single_wide(const u64* pxy, const uint8_t*
 // a wavefront reach every barrier together.
 template <int EPW, bool ISO = true>
 __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
-                                                 const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n) {
-  __shared__ WideLds lds[EPW];
+                                                 const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n, int bcast_b = 0) {
+  __shared__ WideLds lds[EPW];                      // bcast_b: set B's G2 point is ONE point (a 1-element array) for every pair -- the same signer
   const size_t total = pb ? 2 * n : n;
   const int half = EPW == 2 ? (int)(threadIdx.x >> 5) : 0;
   const size_t e0 = (size_t)EPW * blockIdx.x + (size_t)half;
@@ -592,19 +592,21 @@ __global__ void HEAVY_BOUNDS k_miller_wide_batch(const u64* pa, const uint8_t* p
   const uint8_t *pinf = second ? pb_inf : pa_inf, *qinf = second ? qb_inf : qa_inf;
   u64* fout = second ? fb : fa;
   const int odd = pair_role(threadIdx.x);
-  const bool ident = (pinf && pinf[i]) || (qinf && qinf[i]);
+  const bool one_q = second && bcast_b;
+  const size_t qn = one_q ? 1 : n, qi = one_q ? 0 : i;
+  const bool ident = (pinf && pinf[i]) || (qinf && qinf[qi]);
   S12 f;
   if (EPW == 1) {
     if (ident) {
       f = s12_one();
     } else {
       const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
-      const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
+      const S2 qx = qxy ? load_s2(qxy, qn, qi, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, qn, qi, 8, odd) : s2_g2gen_y();
       miller_loop29_wide<ISO, 1>(f, px, py, qx, qy, &lds[0]);
     }
   } else {
     const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
-    const S2 qx = qxy ? load_s2(qxy, n, i, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, n, i, 8, odd) : s2_g2gen_y();
+    const S2 qx = qxy ? load_s2(qxy, qn, qi, 0, odd) : s2_g2gen_x(), qy = qxy ? load_s2(qxy, qn, qi, 8, odd) : s2_g2gen_y();
     miller_loop29_wide<ISO, EPW>(f, px, py, qx, qy, &lds[half]);
     if (ident) f = s12_one();
   }
@@ -802,12 +804,12 @@ static size_t wide_pack() {
 }
 // Two elements per wavefront (16 lane pairs each) cost a second product pass in the dense Fp12 products of the final exponentiation only.
 static void launch_miller_wide(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
-                               const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n, hipStream_t st) {
+                               const u64* pb, const uint8_t* pb_inf, const u64* qb, const uint8_t* qb_inf, u64* fb, size_t n, hipStream_t st, int bcast_b = 0) {
   const size_t units = pb ? 2 * n : n;
   if (wide_pack() && units > wide_pack())
-    plk::k_miller_wide_batch<2><<<dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n);
+    plk::k_miller_wide_batch<2><<<dim3((unsigned)((units + 1) / 2)), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n, bcast_b);
   else
-    plk::k_miller_wide_batch<1><<<dim3((unsigned)units), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n);
+    plk::k_miller_wide_batch<1><<<dim3((unsigned)units), dim3(64), 0, st>>>(pa, pa_inf, qa, qa_inf, fa, pb, pb_inf, qb, qb_inf, fb, n, bcast_b);
 }
 static void launch_final_exp_wide(const u64* fa, const u64* fb, size_t n, u64* gout, uint8_t* is_one, hipStream_t st) {
   if (wide_pack() && n > wide_pack())
@@ -848,10 +850,10 @@ int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uin
 }
 // ok_i = [ e(sig_i, G2gen) e(hneg_i, pk_i) == 1 ], i < n; scratch: 96 n words
 int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* hneg, const uint8_t* hneg_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
-                          uint64_t* scratch, uint8_t* ok, size_t n, void* stream) {
+                          uint64_t* scratch, uint8_t* ok, size_t n, void* stream, int one_key) {
   hipStream_t st = (hipStream_t)stream;
   u64 *fa = scratch, *fb = scratch + 48 * n;
-  launch_miller_wide(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n, st);
+  launch_miller_wide(sig_xy, sig_inf, nullptr, nullptr, fa, hneg, hneg_inf, pk_xy, pk_inf, fb, n, st, one_key);
   launch_final_exp_wide(fa, fb, n, nullptr, ok, st);
   LAUNCHED();
 }
@@ -989,6 +991,11 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
     *result = bufa;
     return SYLOW_HIP_OK;
   }
+  // FEW pairs (small aggregate verifications, short products): one pair per lane pair would be one Miller loop deep on lone wavefronts
+  // (2.5 ms) -- a wavefront per one or two pairs instead (0.6 ms), then the same product tree over the n_pairs values
+  if (chunk == 1 && !range && skip_infinity && n_pairs <= plkh::wide_batch_max()) {
+    launch_miller_wide(p_xy, p_inf, q_xy, q_inf, bufa, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs, st);
+  } else {
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk, range);
   // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
   const size_t round_table = (size_t)65536 * chunk * plk::LT_LINES * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);     // one round of chunk-slot jobs
@@ -998,6 +1005,7 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
   }
   else if (chunk <= 2) plk::k_multi_pairing<plk::KMAXW><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
   else plk::k_multi_pairing<plk::KPROD><<<GRID(2 * n_jobs)>>>(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1);
+  }
   u64 *cur = bufa, *nxt = bufb;
   size_t m = n_jobs;
   while (m > (size_t)BLOCK) {

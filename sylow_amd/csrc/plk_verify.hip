@@ -361,6 +361,18 @@ int32_t sylow_hip_bls_verify_same_signer_batch(const uint64_t* pk_xy, const uint
                                                const uint64_t* sig_xy, const uint8_t* sig_inf, uint8_t* ok, size_t n, void* stream) {
   ARGCHK(pk_xy && msgs && msg_offsets && sig_xy && ok); if (!n) return SYLOW_HIP_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (n <= plkh::wide_verify_max()) {  // small batches: the one-wavefront route of bls_verify_batch with the one key read by every pair
+    host::Lease wsm;
+    int32_t rcs = wsm.acquire((8 + 96) * n * sizeof(u64) + n, st);
+    if (rcs != SYLOW_HIP_OK) return rcs;
+    u64* hneg = (u64*)wsm.p;
+    u64* scratch = hneg + 8 * n;
+    uint8_t* hinf = (uint8_t*)(scratch + 96 * n);
+    rcs = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
+    if (rcs == SYLOW_HIP_OK) rcs = plkh::verify_wide_batch(pk_xy, pk_inf, hneg, hinf, sig_xy, sig_inf, scratch, ok, n, stream, /*one_key=*/1);
+    const int32_t r2s = wsm.release();
+    return rcs != SYLOW_HIP_OK ? rcs : r2s;
+  }
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   const bn254::i32* gen = nullptr;
   int32_t rc = host::gen_lines29(&gen, st);
