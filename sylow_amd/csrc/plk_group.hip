@@ -493,6 +493,120 @@ __global__ void HEAVY_BOUNDS k_gt_pow(const u64* g, const u64* ks, u64* out, siz
   w12_to_s12(sr, res);
   if (active) store_s12(out, n, i, odd, sr);
 }
+// k_gt_pow for single calls and small batches: ONE element per wavefront (all 32 lane pairs hold it), the squarings and products of the
+// same window schedule spread over the wavefront (bn254_pair29.hpp: w12_mul_wide, w12_cyclotomic_sqr_wide), the eleven table entries
+// parked in LDS.  Same table, same digits, same sequence of field operations: the same canonical value.
+struct alignas(16) GtShelf { i32 v[66][2][12]; };
+typedef __attribute__((address_space(3))) GtShelf* GtShelfPtr;
+BN_DEV void gt_shelve(GtShelfPtr sh, int k, const W12& v, int odd, bool writer) {
+  const W2* const c[6] = {&v.c0.c0, &v.c0.c1, &v.c0.c2, &v.c1.c0, &v.c1.c1, &v.c1.c2};
+  if (writer) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sh->v[6 * k + t][odd][i] = c[t]->c.v[i];
+  }
+  __syncthreads();
+}
+BN_DEV W12 gt_fetch(GtShelfPtr sh, int k, int odd) {
+  W12 r;
+  W2* const c[6] = {&r.c0.c0, &r.c0.c1, &r.c0.c2, &r.c1.c0, &r.c1.c1, &r.c1.c2};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[t]->c.v[i] = sh->v[6 * k + t][odd][i];
+  return r;
+}
+__global__ void HEAVY_BOUNDS k_gt_pow_wide(const u64* g, const u64* ks, u64* out, size_t n) {
+  __shared__ WideLds lds;
+  __shared__ GtShelf shelf;
+  const WideLdsPtr x = (WideLdsPtr)&lds;
+  const GtShelfPtr sh = (GtShelfPtr)&shelf;
+  const size_t i = blockIdx.x;
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane);
+  const bool writer = pair_index((u32)lane) == 0;
+  auto sqr = [&](const W12& a) { return w12_mul_wide<1, WK_SQUARE>(a, a, x); };
+  auto mul = [&](const W12& a, const W12& b) { return w12_mul_wide<1, WK_DENSE>(a, b, x); };
+  W12 g1;
+  {
+    S12 sa, so = s12_one();
+    load_s12(sa, g, n, i, odd);
+    W12 one;
+    w12_from_s12(one, so);
+    w12_from_s12(g1, sa);
+    gt_shelve(sh, 0, one, odd, writer);
+    gt_shelve(sh, 1, g1, odd, writer);
+  }
+  {   // slots 2 .. 10: g^2, g^4, g^5, g^8, g^9, g^10, g^8 conj(g)^2, g^8 conj(g), g^4 conj(g)   (k_gt_pow's table)
+    const W12 g2 = sqr(g1);
+    gt_shelve(sh, 2, g2, odd, writer);
+    const W12 g4 = sqr(g2);
+    gt_shelve(sh, 3, g4, odd, writer);
+    gt_shelve(sh, 4, mul(g4, g1), odd, writer);
+    const W12 g8 = sqr(g4);
+    gt_shelve(sh, 5, g8, odd, writer);
+    gt_shelve(sh, 6, mul(g8, g1), odd, writer);
+    gt_shelve(sh, 7, mul(g8, g2), odd, writer);
+    gt_shelve(sh, 8, mul(g8, w12_conj(g2)), odd, writer);
+    gt_shelve(sh, 9, mul(g8, w12_conj(g1)), odd, writer);
+    gt_shelve(sh, 10, mul(g4, w12_conj(g1)), odd, writer);
+  }
+  // digits of fp.rs:653-662 on the raw 256-bit scalar (as k_gt_pow)
+  u32 k[8], xh[8], x3[8], np[8], nm[8];
+  {
+    const Fp kp = load_plain(ks, n, i, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = kp.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xh[j] = (k[j] >> 1) | (j < 7 ? (k[j + 1] << 31) : 0);
+  u64 c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c += (u64)k[j] + xh[j]; x3[j] = (u32)c; c >>= 32; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const u32 cc = xh[j] ^ x3[j]; np[j] = x3[j] & cc; nm[j] = xh[j] & cc; }
+  auto entry = [&](int w) {
+    u32 wp = 0, wm = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == (w >> 3)) { wp = (np[j] >> (4 * (w & 7))) & 15u; wm = (nm[j] >> (4 * (w & 7))) & 15u; }
+    bool cj;
+    const int slot = __builtin_amdgcn_readfirstlane(gt_window_slot(wp, wm, cj));      // the whole wavefront holds one scalar
+    const W12 m = gt_fetch(sh, slot, odd);
+    const W12 mc = w12_conj(m);
+    W12 r = m;
+    r.c1.c0 = w2_select(m.c1.c0, mc.c1.c0, cj); r.c1.c1 = w2_select(m.c1.c1, mc.c1.c1, cj); r.c1.c2 = w2_select(m.c1.c2, mc.c1.c2, cj);
+    return r;
+  };
+  // cyclotomic inputs take the Granger-Scott squaring (see k_gt_pow): frob^4(g) g == frob^2(g)
+  bool cyc;
+  {
+    const W12 f2 = w12_frobenius_wide<2, 1>(g1, x);
+    const W12 f4 = w12_frobenius_wide<2, 1>(f2, x);
+    const W12 lhs = mul(f4, g1);
+    S12 a, b;
+    w12_to_s12(a, lhs);
+    w12_to_s12(b, f2);
+    const bool eq = s2_eq(a.c0.c0, b.c0.c0) && s2_eq(a.c0.c1, b.c0.c1) && s2_eq(a.c0.c2, b.c0.c2) &&
+                    s2_eq(a.c1.c0, b.c1.c0) && s2_eq(a.c1.c1, b.c1.c1) && s2_eq(a.c1.c2, b.c1.c2);
+    const bool zero = s2_is_zero(b.c0.c0) && s2_is_zero(b.c0.c1) && s2_is_zero(b.c0.c2) && s2_is_zero(b.c1.c0) && s2_is_zero(b.c1.c1) && s2_is_zero(b.c1.c2);
+    cyc = wave_max((eq && !zero) ? 0 : 1) == 0;
+  }
+  W12 res = entry(63);
+#pragma unroll 1
+  for (int w = 62; w >= 0; --w) {
+    if (cyc) {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) res = w12_cyclotomic_sqr_wide<1>(res, x);
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) res = sqr(res);
+    }
+    res = mul(res, entry(w));
+  }
+  S12 sr;
+  w12_to_s12(sr, res);
+  if (writer) store_s12(out, n, i, odd, sr);
+}
 }  // namespace plk
 
 // one LANE PAIR per 192-byte pair: decode + validate into the SoA arrays the multi-pairing kernel consumes.  Both lanes decode
@@ -642,6 +756,8 @@ int32_t sylow_hip_g2_from_be_bytes_batch(const uint8_t* in, uint64_t* out_xy, ui
 }
 int32_t sylow_hip_gt_pow_batch(const uint64_t* gt, const uint64_t* k, uint64_t* out, size_t n, void* stream) {
   ARGCHK(gt && k && out); if (!n) return SYLOW_HIP_OK;
+  // single calls and small batches: one wavefront per element (one power 3.1 -> ~0.8 ms)
+  if (plkh::wide_batch_max() != 0 && n <= 2048) { plk::k_gt_pow_wide<<<dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream>>>(gt, k, out, n); LAUNCHED(); }
   plk::k_gt_pow<<<GRID(2 * n)>>>(gt, k, out, n); LAUNCHED();
 }
 int32_t sylow_hip_g2_add_batch(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, uint64_t* out_xy, uint8_t* out_inf, size_t n, void* stream) {
