@@ -1146,12 +1146,18 @@ static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, s
   uint8_t *hinf = (uint8_t*)(qb2 + 16), *p2inf = hinf + n, *q2inf = p2inf + 2, *swinf = q2inf + 2;
   host::Lease wa, wb;
   u64 *pa = nullptr, *pb = nullptr;
-  // The G2gen half -- e(sum_i sig_i, G2gen): a summation tree and ONE Miller loop on one lane pair, a few ms of pure latency -- depends on
-  // the signatures only: it runs on a side stream beside the hashing (with weights it needs w_i sig_i first and stays in line).
+  // The G2gen half -- e(sum_i sig_i, G2gen), or e(sum_i w_i sig_i, G2gen) with weights: a (scalar multiplication,) summation tree and ONE
+  // Miller loop, a few ms of pure latency -- depends on the signatures (and weights) only: it runs on a side stream beside the hashing.
   Fork fork;
-  hipStream_t sd = weights ? st : fork.open(st);
-  if (!weights) {
-    rc = g1h::sum(sig_xy, sig_inf, n, acc, pb2, p2inf + 1, 1, 0, 0, sd);
+  hipStream_t sd = fork.open(st);
+  {
+    const u64* sp = sig_xy;
+    const uint8_t* spi = sig_inf;
+    if (weights) {                                          // sig_i -> w_i sig_i (scratch)
+      rc = sylow_hip_g1_scalar_mul_batch(sig_xy, sig_inf, weights, sw, swinf, n, sd);
+      sp = sw; spi = swinf;
+    }
+    if (rc == SYLOW_HIP_OK) rc = g1h::sum(sp, spi, n, acc, pb2, p2inf + 1, 1, 0, 0, sd);
     if (rc == SYLOW_HIP_OK) {
       plk::k_g2_set_column<<<1, 64, 0, sd>>>(qb2, q2inf + 1, 1, 0, nullptr, nullptr);
       rc = miller_product_tree(pb2, p2inf + 1, qb2, q2inf + 1, 1, 1, wb, &pb, sd);
@@ -1161,15 +1167,7 @@ static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, s
   const bool hash_into_tree = one_key && !weights;
   if (rc == SYLOW_HIP_OK) rc = hash_into_tree ? g1h::hash_to_g1_proj(msgs, msg_offsets, acc2, n, stream)
                                               : g1h::hash_to_g1(msgs, msg_offsets, hxy, hinf, n, /*negate=*/one_key ? 0 : 1, stream);
-  if (rc == SYLOW_HIP_OK && weights) {                      // H_i <- w_i H_i (in place), sig_i -> w_i sig_i (scratch)
-    rc = sylow_hip_g1_scalar_mul_batch(hxy, hinf, weights, hxy, hinf, n, stream);
-    if (rc == SYLOW_HIP_OK) rc = sylow_hip_g1_scalar_mul_batch(sig_xy, sig_inf, weights, sw, swinf, n, stream);
-    if (rc == SYLOW_HIP_OK) rc = g1h::sum(sw, swinf, n, acc, pb2, p2inf + 1, 1, 0, 0, stream);
-    if (rc == SYLOW_HIP_OK) {
-      plk::k_g2_set_column<<<1, 64, 0, st>>>(qb2, q2inf + 1, 1, 0, nullptr, nullptr);
-      rc = miller_product_tree(pb2, p2inf + 1, qb2, q2inf + 1, 1, 1, wb, &pb, stream);
-    }
-  }
+  if (rc == SYLOW_HIP_OK && weights) rc = sylow_hip_g1_scalar_mul_batch(hxy, hinf, weights, hxy, hinf, n, stream);      // H_i <- w_i H_i (in place)
   if (rc == SYLOW_HIP_OK && !one_key) {
     // prod_i e(-H_i, pk_i) over the batch
     rc = miller_product_tree(hxy, hinf, pk_xy, pk_inf, n, 1, wa, &pa, stream);
