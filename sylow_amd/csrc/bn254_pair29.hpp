@@ -852,7 +852,7 @@ BN_DEV void w12_mul_wide_stage0(const W12& a, const W12& b, WideLdsPtr x) {
     }
   }
 }
-template <int EPW = 1, int KIND = WK_DENSE>
+template <int EPW = 1, int KIND = WK_DENSE, bool STAGE3 = true>      // STAGE3 = false: stop at the Fp6 coefficients in the T slots (w12_inv_wide)
 BN_DEV void w12_mul_wide_core(WideLdsPtr x) {
   const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
   const W2 zero{F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}};
@@ -899,6 +899,7 @@ BN_DEV void w12_mul_wide_core(WideLdsPtr x) {
     if (j < nu) wide_put(x, WL_T + u, odd, W2{f29_reduce_terms(t, k)});
   }
   __syncthreads();
+  if (!STAGE3) return;
   if (KIND == WK_SQUARE) {   // stage 3: c1.ci = 2 t.ci;  c0.c0 = m.c0 - t.c0 - xi t.c2;  c0.c1 = m.c1 - t.c1 - t.c0;  c0.c2 = m.c2 - t.c2 - t.c1
     const int o = j < 6 ? j : 0, i = o % 3;
     const W2 ti = wide_get(x, WL_T + i, odd), tp = wide_get(x, WL_T + (i + 2) % 3, odd), mi = wide_get(x, WL_T + 6 + i, odd);
@@ -1005,13 +1006,74 @@ BN_DEV W12 w12_frobenius_wide(const W12& a, WideLdsPtr x) {
   r.c1.c0 = wide_get(x, WL_P + 2, odd); r.c1.c1 = wide_get(x, WL_T, odd); r.c1.c2 = wide_get(x, WL_T + 1, odd);
   return r;
 }
+// Two independent Fp6 products A B and C D in ONE pass of the product machinery (the first and the third Fp6 product of the square form:
+// 12 lane pairs): the coefficients of A B land in T[0 .. 2], those of C D in T[6 .. 8].  Operands replicated, R / N.
+template <int EPW>
+BN_DEV void w6_mul2_wide(const W6& a, const W6& b, const W6& c, const W6& d, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
+  const int i = (j < 6 ? j : 0) % 3;
+  const bool hi = j >= 3;
+  const W2 u = w2_sel3(i, w2_pick(a.c0, c.c0, hi), w2_pick(a.c1, c.c1, hi), w2_pick(a.c2, c.c2, hi));
+  const W2 v = w2_sel3(i, w2_pick(b.c0, d.c0, hi), w2_pick(b.c1, d.c1, hi), w2_pick(b.c2, d.c2, hi));
+  if (j < 3) { wide_put(x, WL_IA + i, odd, u); wide_put(x, WL_IB + i, odd, v); }
+  if (j >= 3 && j < 6) { wide_put(x, WL_SA + i, odd, u); wide_put(x, WL_SB + i, odd, v); }
+  w12_mul_wide_core<EPW, WK_SQUARE, false>(x);
+}
+BN_DEV W6 w6_wide_t(WideLdsPtr x, int base) {
+  const int odd = pair_role((u32)(threadIdx.x & 63u));
+  return W6{wide_get(x, WL_T + base, odd), wide_get(x, WL_T + base + 1, odd), wide_get(x, WL_T + base + 2, odd)};
+}
+// w12_inv (fp12.rs:281-286, fp6.rs:415-423) on the wavefront: the two Fp6 squarings and the two final Fp6 products as double products,
+// the nine products of the Fp6 inversion in three levels of 6 / 3 / 3 lane pairs, the Fp2 inversion replicated.  Same formulas as
+// w12_inv_nl / w6_inv: same values.
+template <int EPW = 1>
+BN_DEV W12 w12_inv_wide(const W12& a, WideLdsPtr x) {
+  const int lane = (int)(threadIdx.x & 63u), odd = pair_role((u32)lane), j = wide_j<EPW>(lane);
+  w6_mul2_wide<EPW>(a.c0, a.c0, a.c1, a.c1, x);
+  const W6 s0 = w6_wide_t(x, 0), s1 = w6_wide_t(x, 6);
+  // d = c0^2 - v c1^2 with v (x0, x1, x2) = (xi x2, x0, x1)
+  const W2 d0 = w2_norm(w2_sub(s0.c0, w2_mul_xi(s1.c2))), d1 = w2_norm(w2_sub(s0.c1, s1.c0)), d2 = w2_norm(w2_sub(s0.c2, s1.c1));
+  {   // six products: d0 d0, d1 (xi d2), d2 d2, d0 d1, d1 d1, d0 d2
+    const int p = j < 6 ? j : 0;
+    const W2 xd2 = w2_mul_xi(d2);
+    const W2 u = w2_pick(w2_pick(d0, d1, p == 1 || p == 4), d2, p == 2);
+    const W2 v = w2_pick(w2_pick(w2_pick(w2_pick(d0, xd2, p == 1), d2, p == 2 || p == 5), d1, p == 3 || p == 4), d0, p == 0);
+    const W2 pr = w2_mul_w(u, v);
+    if (j < 6) wide_put(x, WL_P + p, odd, pr);
+  }
+  __syncthreads();
+  const W2 t0 = w2_sub(wide_get(x, WL_P, odd), wide_get(x, WL_P + 1, odd));                       // D-class differences: fine as product operands
+  const W2 t1 = w2_sub(w2_mul_xi(wide_get(x, WL_P + 2, odd)), wide_get(x, WL_P + 3, odd));
+  const W2 t2 = w2_sub(wide_get(x, WL_P + 4, odd), wide_get(x, WL_P + 5, odd));
+  {   // three products: d2 t1, d1 t2, d0 t0
+    const int p = j < 3 ? j : 0;
+    const W2 pr = w2_mul_w(w2_sel3(p, d2, d1, d0), w2_sel3(p, t1, t2, t0));
+    if (j < 3) wide_put(x, WL_P + 6 + p, odd, pr);
+  }
+  __syncthreads();
+  const W2 dd = w2_xi_lin(w2_add(wide_get(x, WL_P + 6, odd), wide_get(x, WL_P + 7, odd)), 1, wide_get(x, WL_P + 8, odd), 1);
+  const W2 di = w2_inv(dd);
+  {   // three products: di t0, di t1, di t2
+    const int p = j < 3 ? j : 0;
+    const W2 pr = w2_mul_w(di, w2_sel3(p, t0, t1, t2));
+    if (j < 3) wide_put(x, WL_P + 9 + p, odd, pr);
+  }
+  __syncthreads();
+  const W6 t{wide_get(x, WL_P + 9, odd), wide_get(x, WL_P + 10, odd), wide_get(x, WL_P + 11, odd)};
+  w6_mul2_wide<EPW>(a.c0, t, a.c1, t, x);
+  const W6 m = w6_wide_t(x, 6);
+  W12 r;
+  r.c0 = w6_wide_t(x, 0);
+  r.c1 = W6{w2_norm(w2_neg(m.c0)), w2_norm(w2_neg(m.c1)), w2_norm(w2_neg(m.c2))};
+  return r;
+}
 // final_exponentiation29 for a one-wavefront block whose 32 lane pairs all hold the same element
 template <int EPW = 1>
 BN_NOINLINE void final_exponentiation29_wide(S12& out, const S12& fin, WideLds* x) {
   W12 in, t, a, b, d, e, g;
   {
     w12_from_s12(t, fin);
-    w12_inv_nl(b, t);
+    b = w12_inv_wide<EPW>(t, (WideLdsPtr)x);
     a = w12_conj(t);
     w12_mul_wide_nl<EPW>(d, a, b, x);
     a = w12_frobenius_wide<2, EPW>(d, (WideLdsPtr)x);
