@@ -103,6 +103,26 @@ def test_verify_batch_planted_pattern_large(engine):
     assert engine.flags_all(engine.to_device(engine.bls_verify(pk_xy, msgs, sig_xy))) == 1
 
 
+@pytest.mark.parametrize("n", [301, 4097])
+def test_same_signer_on_both_routes(engine, n):
+    """One key for every message at a size where a wavefront holds two Miller loops and all of them read the ONE key (301), and above the
+    one-wavefront route's cap (4097: the line-table kernel): the flags of the per-element verifier with the key repeated."""
+    g = np.random.default_rng(4321 + n)
+    msgs = [g.integers(0, 256, size=int(g.integers(1, 50)), dtype=np.uint8).tobytes() for _ in range(n)]
+    sk = g.integers(0, 1 << 62, size=(1, 4), dtype=np.uint64)
+    pk, _ = engine.g2_scalar_mul(pack(G2, 16), sk)
+    sig, _ = engine.bls_sign(np.repeat(sk, n, 0), msgs)
+    bad, _ = engine.g1_add(sig, np.repeat(pack([1, 2], 8), n, 0))
+    plant = g.random(n) < 0.1
+    plant[[0, n - 1]] = [True, False]
+    mixed = np.where(plant[:, None], bad, sig)
+    sinf = (g.random(n) < 0.05).astype(np.uint8)
+    got = engine.bls_verify_same_signer(pk, msgs, mixed, sig_inf=sinf)
+    assert np.array_equal(got.astype(bool), ~plant & ~sinf.astype(bool))
+    assert np.array_equal(got, engine.bls_verify(np.repeat(pk, n, 0), msgs, mixed, sig_inf=sinf, pipelined=False))
+    assert np.array_equal(engine.bls_verify_same_signer(pk, msgs, mixed, pk_inf=[1], sig_inf=sinf).astype(bool), sinf.astype(bool))
+
+
 @pytest.mark.parametrize("n", [513, 1500, 2047, 3333])
 def test_verify_two_elements_per_wavefront_route(engine, coracle, n):
     """128 < n <= 4096 verifications: 2 n Miller loops and n final exponentiations, two per wavefront.  Planted corruption and identity
