@@ -130,12 +130,33 @@ def cargo_probe():
                                   "do not travel to this box: baseline = C port of the reference"}
 
 
+def host_cpu_facts():
+    """What bounds the all-core leg on this box: logical CPUs, the affinity mask, the cgroup CPU quota (cpu.max / cfs_quota)."""
+    nproc = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = nproc
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                 # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            quota = None
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return {"nproc": nproc, "affinity_cores": aff, "cgroup_cpu_quota_cores": quota, "usable_cores": max(1, min(usable, 256))}
+
+
 def cpu_baseline(check=None, target_seconds=10.0):
     """The C oracle (a port of the reference's pairing(), 256-iteration loops as written) on the host cores: single-thread
     generator pairing (benches/pairing.rs:5-10) and sign (benches/sig.rs:10-21) shapes, then all cores for `target_seconds`.
     `check` = (p_xy, q_xy, gt) host AoS rows the TIMED launches produced: recomputed here and compared bit for bit."""
-    import threading
-
     from oracle import coracle as C
     C.build()
     C.lib()
@@ -144,9 +165,8 @@ def cpu_baseline(check=None, target_seconds=10.0):
     chunk = 32
     p, q = np.repeat(one_p, chunk, 0), np.repeat(one_q, chunk, 0)
     C.pairing(p[:2], q[:2])
-    t0 = time.perf_counter()
-    C.pairing(p, q)
-    single = chunk / (time.perf_counter() - t0)
+    c1, d1 = C.bench_pairing_threads(one_p, one_q, 1, 2.0)            # the same C loop as the all-core leg, one thread
+    single = float(c1.sum()) / d1
     # sign shape: sk = first PRNG draw, msg = 20_i32.to_be_bytes() (benches/sig.rs:7), n >= 100
     ns = 128
     from sylow_amd import _lib                                  # host-side PRNG only (no GPU involved)
@@ -172,31 +192,20 @@ def cpu_baseline(check=None, target_seconds=10.0):
     for i in range(8):
         C.verify(pk[i:i + 1], msgs[i:i + 1], C.sign(sk[i:i + 1], msgs[i:i + 1]))
     sign_verify_ms = (time.perf_counter() - t0) / 8 * 1e3
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    counts = [0] * cores
-    deadline = time.perf_counter() + target_seconds
-
-    def work(i):
-        while time.perf_counter() < deadline:
-            C.pairing(p, q)               # ctypes releases the GIL inside the C call
-            counts[i] += chunk
-
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    total = sum(counts)
+    host = host_cpu_facts()
+    cores = host["usable_cores"]
+    # the all-core loop runs INSIDE the C library (POSIX threads, oracle_bench_pairing_threads): no Python, no GIL hand-over in the loop
+    counts, dt = C.bench_pairing_threads(one_p, one_q, cores, target_seconds)
+    total = int(counts.sum())
+    scaling = (total / dt) / single if single else None
     out = {"value": total / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
-           "sample": f"{total} generator pairings e(G1gen, G2gen) (benches/pairing.rs:5-10 shape) on {cores} threads for {dt:.1f} s; "
-                     f"C restatement of the reference's formulas and loop structure (oracle/sylow_oracle.c), not sylow itself",
-           "single_thread_pairings_per_s": single, "single_thread_signs_per_s": sign_single,
+           "sample": f"{total} generator pairings e(G1gen, G2gen) (benches/pairing.rs:5-10 shape) on {cores} POSIX threads for {dt:.1f} s "
+                     f"(loop in C: oracle_bench_pairing_threads); C restatement of the reference's formulas and loop structure (oracle/sylow_oracle.c), not sylow itself",
+           "single_thread_pairings_per_s": single, "all_core_over_single_thread": scaling,
+           "nproc": host["nproc"], "affinity_cores": host["affinity_cores"], "cgroup_cpu_quota_cores": host["cgroup_cpu_quota_cores"],
+           "per_thread_min_max": [int(counts.min()), int(counts.max())],
+           "checked": None, "mismatches": None,                 # filled below (kept among the first keys: the driver's record keeps a prefix)
+           "single_thread_signs_per_s": sign_single,
            "sign_sample": f"{ns} x sign(sk, 20_i32.to_be_bytes()) (benches/sig.rs:10-21 shape), one thread",
            "single_thread_verifies_per_s": verify_single, "verify_all_true": int(bool(np.all(ok))),
            "verify_sample": f"{nv} x verify(pk, 20_i32.to_be_bytes(), sig) (lib.rs:223-236: hash + two pairings), one thread",
@@ -471,11 +480,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # live clock probe (sylow_hip_clock_probe): every wavefront of the metric's kernels adds its shader-clock and constant-rate tick deltas
+    clk_acc = eng.empty((256,))
+    clk_zero = np.zeros(256, dtype=np.uint64)
+    wall_khz = eng.wall_clock_khz()
+
+    def probe_reset():
+        clk_acc.upload(clk_zero)
+        eng.clock_probe(clk_acc)
+
+    def probe_read():
+        """-> {sustained_mhz, wave_ticks, waves, longest_wave_ms} of the launches since probe_reset(); switches the probe off"""
+        torch.cuda.synchronize()
+        eng.clock_probe(None)
+        mhz, ticks, waves, longest = eng.clock_probe_summary(clk_acc.download(), wall_khz)
+        return {"sustained_mhz": mhz, "wave_ticks": ticks, "waves": waves, "longest_wave_ms": longest}
+
     def timed_loop(fn):
         """The contract's loop: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; wall time is
-        the MAX over ranks; every step also sits between two HIP events on the launch stream (this rank's device time per step)."""
+        the MAX over ranks; every step also sits between two HIP events on the launch stream (this rank's device time per step).  The clock
+        probe is armed after the warm-up and before the opening fence: it covers exactly the K timed steps."""
         for _ in range(args.warmup):
             fn()
+        probe_reset()
         fence()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         t0 = time.perf_counter()
@@ -489,6 +516,7 @@ def main():
         return sharding.max_over_ranks(dt, dist), float(np.mean(ms)), float(np.min(ms)), float(np.max(ms))
 
     elapsed, kern_ms, kern_ms_min, kern_ms_max = timed_loop(step)
+    probe_p = probe_read()
 
     # rows of what the timed launches wrote, for the oracle spot check in the CPU leg
     check = None
@@ -564,6 +592,7 @@ def main():
         flag = and_over_ranks(ok, nv, flag_dev)      # AND over ranks: 4 bytes over xGMI (RCCL MIN)
 
     v_elapsed, verify_ms, verify_ms_min, verify_ms_max = timed_loop(verify_weak)
+    probe_v = probe_read()
     all_valid_weak = int(flag.item())
     n_bad_fused = int(nv - int(ok.download().sum()))
 
@@ -620,7 +649,9 @@ def main():
         eng.sync(); eng.trim(0)
         free_before = torch.cuda.mem_get_info()[0]
         dta, agg_ms = timed_ranks(agg, 3, "aggregate")
-        agg_scratch = int(free_before - torch.cuda.mem_get_info()[0])        # what the library's leased blocks hold after the call: the line tables of the n-pair product
+        agg_scratch_peak = int(free_before - torch.cuda.mem_get_info()[0])   # what the library's leased blocks hold right after the call: the line tables of the n-pair product
+        eng.sync(); eng.trim(0)                                              # a host that shares the GPU hands them back between batches (sylow_hip_trim)
+        agg_scratch = int(free_before - torch.cuda.mem_get_info()[0])        # the steady state between calls
         agg_ok = int(is1.download()[0]) if comm is not None else sharding.all_valid(int(is1.download()[0]), dist)
         # the same with ONE signer for the whole batch: both halves collapse (n hashes, two G1 sums, a two-pair product)
         k1 = eng.xoshiro_fp_soa(SEED + 9, 1)
@@ -635,8 +666,9 @@ def main():
         agg1_ok = int(is1.download()[0])
         del sk1, sig1, sig1i
         aux = {"aggregate_verify_sigs_per_s": world * na / dta, "aggregate_all_valid": agg_ok, "aggregate_batch_per_gpu": na,
-               "aggregate_scratch_bytes": agg_scratch, "aggregate_scratch_note": "device memory the library holds after aggregate_verify (leased blocks, kept for reuse; "
-               "sylow_hip_trim returns them, sylow_hip_set_scratch_limit bounds the line tables -- DESIGN.md 4.1)",
+               "aggregate_scratch_bytes": agg_scratch, "aggregate_scratch_bytes_during_calls": agg_scratch_peak,
+               "aggregate_scratch_note": "device memory the library holds after aggregate_verify + sylow_hip_trim(0) (steady state) and right after the calls (leased blocks, kept for reuse "
+               "until trimmed); the line tables take at most min(12 GB, a quarter of the memory free at the first multi-pair call) unless sylow_hip_set_scratch_limit says otherwise -- DESIGN.md 4.1",
                "aggregate_same_signer_sigs_per_s": world * nv / dta1, "aggregate_same_signer_all_valid": agg1_ok,
                "aggregate_path": ("native: sylow_hip_bls_aggregate_verify_batch over this rank's ncclComm_t (all-gather of %d partial products)" % rccl_ranks) if comm is not None
                                  else "per-rank product, booleans AND-ed through the process group",
@@ -660,6 +692,28 @@ def main():
                        "two_pairings = the same boolean evaluated literally (hash + two full pairings + compare); "
                        "aggregate = prod_i e(sig_i,G2gen) e(-H(m_i),pk_i) == identity as one boolean: hash + G1 sum of the signatures + product tree over the n key pairs + one final exponentiation; "
                        "aggregate_same_signer = one key: hash + two G1 sums + a two-pair product"}
+        # ---- staggered launch A/B on THIS box, through the ABI's option (no environment variable): 3 launches per mode, alternating
+        prev_stagger = eng.get_option("STAGGER")
+        stagger_ab = {}
+        for lg in (args.log2n, 17):
+            m = 1 << lg
+            if m > n or ("2^%d" % lg) in stagger_ab:
+                continue
+            if m == n:
+                p_m, q_m, gt_m = p, q, gt
+            else:
+                p_m = eng.empty((8, m)).upload(np.ascontiguousarray(p.download()[:, :m]))
+                q_m = eng.empty((16, m)).upload(np.ascontiguousarray(q.download()[:, :m]))
+                gt_m = eng.empty((48, m))
+            times = {0: [], 1: []}
+            for _ in range(3):
+                for mode in (0, 1):
+                    eng.set_option("STAGGER", mode)
+                    times[mode].append(hip_timed(torch, stream, lambda: eng._call("sylow_hip_pairing_batch", p_m.ptr, None, q_m.ptr, None, gt_m.ptr, m), 1) * 1e3)
+            stagger_ab["2^%d" % lg] = {"plain_ms": times[0], "staggered_ms": times[1], "gain": float(np.mean(times[0]) / np.mean(times[1]))}
+            del p_m, q_m, gt_m
+        eng.set_option("STAGGER", prev_stagger)
+        aux["stagger_ab"] = dict(stagger_ab, note="k_pairing launched plain (STAGGER option 0) and skewed (1), alternating, 3 single launches each after a warm launch, HIP events; gain = plain / staggered")
         if world == 1 and not args.force_dist:
             p_h, q_h, pk_h, sig_h = p.download(), q.download(), pk.download(), sig.download()
             aux["size_sweep"] = size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n, sk_h=sk.download())
@@ -681,6 +735,55 @@ def main():
         pmc_note = (pmc["source"] if main_cfg else
                     "profiles/pmc_current.json was measured on another build of the kernels (source hash differs): re-run tools/prof_configs.sh"
                     if pmc is not None else "no profiles/pmc_current.json")
+        # ---- live figures of THIS run (clock probe): the engine clock the timed kernels sustained, and the issue fraction against it -------
+        sus_hz = probe_p["sustained_mhz"] * 1e6 if probe_p["sustained_mhz"] else None
+        sus_hz_v = probe_v["sustained_mhz"] * 1e6 if probe_v["sustained_mhz"] else None
+        ideal_p, ideal_v = main_cfg.get("issue_cycles_ideal_per_unit"), ver_cfg.get("issue_cycles_ideal_per_unit")
+        simd_live = kern_s * sus_hz * N_SIMD / n if sus_hz else None                     # SIMD cycles the chip spent per pairing, live
+        simd_live_v = (verify_ms * 1e-3) * sus_hz_v * N_SIMD / nv if sus_hz_v else None
+        sab = aux.get("stagger_ab", {}) if aux else {}
+        # the driver's record keeps a PREFIX of this object's scalar keys: what certifies the line comes first
+        roofline = {
+            "bound": "valu-issue", "unit": "G SIMD issue cycles/s",
+            "achieved": issue_cycles / kern_s / 1e9 if have_issue else None, "peak": ISSUE_PEAK / 1e9,
+            "frac": issue_cycles / kern_s / ISSUE_PEAK if have_issue else None,
+            "traffic": (main_cfg["hbm_bytes_per_unit"] * n) if main_cfg.get("hbm_bytes_per_unit") else None,
+            "sustained_mhz": probe_p["sustained_mhz"],
+            "frac_at_sustained_clock": (ideal_p / simd_live) if (ideal_p and simd_live) else None,
+            "frac_clock_free": main_cfg.get("issue_frac"),
+            "simd_cycles_per_pairing_live": simd_live, "simd_cycles_per_pairing": main_cfg.get("simd_cycles_per_unit"),
+            "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "kernel_ms_min": kern_ms_min, "kernel_ms_max": kern_ms_max,
+            "valu_instr_per_pairing": main_cfg.get("valu_instr_per_unit"), "issue_cycles_ideal_per_pairing": ideal_p,
+            "verify_sustained_mhz": probe_v["sustained_mhz"],
+            "verify_frac_at_sustained_clock": (ideal_v / simd_live_v) if (ideal_v and simd_live_v) else None,
+            "verify_issue_frac_clock_free": ver_cfg.get("issue_frac"),
+            "stagger_gain_2^%d" % args.log2n: (sab.get("2^%d" % args.log2n) or {}).get("gain"),
+            "stagger_gain_2^17": (sab.get("2^17") or {}).get("gain"),
+            "hbm_achieved": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+            # ---- beyond the prefix ----
+            "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
+            "frac_vs_measured_issue_rates": main_cfg.get("issue_frac_vs_measured_issue_rates"),
+            "kernel_ms_profiled": main_cfg.get("ms_per_launch_kernel_sum", main_cfg.get("ms_per_launch")),
+            "int64_class_frac": main_cfg.get("int64_class_frac"),
+            "wave_ticks_per_pairing_live": probe_p["wave_ticks"] / (n * args.steps) if probe_p["wave_ticks"] else None,
+            "probe_wavefronts": probe_p["waves"], "probe_longest_wavefront_ms": probe_p["longest_wave_ms"], "wall_clock_khz": wall_khz,
+            "note": "achieved = (SQ_INSTS_VALU_INT64 x 4 + other VALU x 2 issue cycles per pairing, rocprofv3 PMC: a constant of the BUILD, "
+                    "guarded by the source hash) x batch / live HIP-event kernel time; peak = 1024 SIMDs x 2.4 GHz; "
+                    "sustained_mhz = sum of s_memtime deltas / sum of s_memrealtime deltas over every wavefront of the K timed launches "
+                    "(sylow_hip_clock_probe), x the constant rate: the clock THIS box held under THIS kernel; "
+                    "frac_at_sustained_clock = ideal issue cycles / (kernel time x sustained clock x 1024 SIMDs) -- the live twin of "
+                    "frac_clock_free = issue cycles / (GRBM_GUI_ACTIVE / 8 x 1024) of the profiled pass",
+            "pmc_source": pmc_note,
+            "hbm_note": "ALGORITHMIC bytes (576 per pairing) / kernel time: HBM cannot bind a pairing; the HBM-bound kernels of the path are aux.configs C2a",
+            "algorithmic_bytes_per_launch": PAIRING_BYTES * n,
+            "traffic_note": "HBM bytes per launch, rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
+            "verify_kernel": "k_hash_to_g1 + plk::k_bls_verify_fused", "verify_kernel_ms": verify_ms, "verify_kernel_ms_min": verify_ms_min,
+            "verify_kernel_ms_max": verify_ms_max, "verify_per_s": verifies_per_s,
+            "verify_valu_instr_per_unit": ver_cfg.get("valu_instr_per_unit"),
+            "verify_frac": (ideal_v * nv / (verify_ms * 1e-3) / ISSUE_PEAK) if ideal_v else None,
+            "verify_simd_cycles_per_unit_live": simd_live_v, "verify_simd_cycles_per_unit": ver_cfg.get("simd_cycles_per_unit"),
+            "verify_probe_note": "the verify probe covers plk::k_bls_verify_fused only; verify_kernel_ms also holds k_hash_to_g1 (~5 %), so verify_frac_at_sustained_clock prices the two kernels' time against the pairing kernel's clock",
+            "verify_hbm_bytes_per_unit_measured": ver_cfg.get("hbm_bytes_per_unit")}
         # every value in `config` / `roofline` is a scalar: the driver's record keeps scalars of these two objects and drops nested ones
         out = {
             "metric": "BN254 pairings/s (value) and BLS verifies/s (config.bls_verifies_per_s) at batch=2^%d per GPU" % args.log2n,
@@ -695,27 +798,7 @@ def main():
                        "bls_all_valid": all_valid_weak, "bls_bad_flags_this_rank": n_bad_fused,
                        "bls_verify_note": "sylow_hip_bls_verify_batch + AND over ranks (lib.rs:223-236 as e(sig,G2gen) e(-H(m),pk) == 1), same loop as the pairings",
                        "timed_region_s": elapsed + v_elapsed},
-            "roofline": {"bound": "valu-issue", "unit": "G SIMD issue cycles/s",
-                         "achieved": issue_cycles / kern_s / 1e9 if have_issue else None, "peak": ISSUE_PEAK / 1e9,
-                         "frac": issue_cycles / kern_s / ISSUE_PEAK if have_issue else None,
-                         "frac_clock_free": main_cfg.get("issue_frac"), "frac_vs_measured_issue_rates": main_cfg.get("issue_frac_vs_measured_issue_rates"),
-                         "kernel": "plk::k_pairing", "kernel_ms": kern_ms, "kernel_ms_min": kern_ms_min, "kernel_ms_max": kern_ms_max,
-                         "kernel_ms_profiled": main_cfg.get("ms_per_launch_kernel_sum", main_cfg.get("ms_per_launch")),
-                         "valu_instr_per_pairing": main_cfg.get("valu_instr_per_unit"), "int64_class_frac": main_cfg.get("int64_class_frac"),
-                         "issue_cycles_ideal_per_pairing": main_cfg.get("issue_cycles_ideal_per_unit"), "simd_cycles_per_pairing": main_cfg.get("simd_cycles_per_unit"),
-                         "note": "achieved = (SQ_INSTS_VALU_INT64 x 4 + other VALU x 2 issue cycles per pairing, rocprofv3 PMC) x batch / live HIP-event kernel time; "
-                                 "peak = 1024 SIMDs x 2.4 GHz; frac_clock_free = issue cycles / (GRBM_GUI_ACTIVE / 8 x 1024) inside one profiled pass",
-                         "pmc_source": pmc_note,
-                         "hbm_achieved": hbm_achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
-                         "hbm_note": "ALGORITHMIC bytes (576 per pairing) / kernel time: HBM cannot bind a pairing; the HBM-bound kernels of the path are aux.configs C2a",
-                         "algorithmic_bytes_per_launch": PAIRING_BYTES * n,
-                         "traffic": (main_cfg["hbm_bytes_per_unit"] * n) if main_cfg.get("hbm_bytes_per_unit") else None,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
-                         "verify_kernel": "k_hash_to_g1 + plk::k_bls_verify_fused", "verify_kernel_ms": verify_ms, "verify_kernel_ms_min": verify_ms_min,
-                         "verify_kernel_ms_max": verify_ms_max, "verify_per_s": verifies_per_s,
-                         "verify_issue_frac_clock_free": ver_cfg.get("issue_frac"), "verify_valu_instr_per_unit": ver_cfg.get("valu_instr_per_unit"),
-                         "verify_frac": (ver_cfg["issue_cycles_ideal_per_unit"] * nv / (verify_ms * 1e-3) / ISSUE_PEAK) if ver_cfg.get("issue_cycles_ideal_per_unit") else None,
-                         "verify_hbm_bytes_per_unit_measured": ver_cfg.get("hbm_bytes_per_unit")},
+            "roofline": roofline,
         }
         if aux:
             out["aux"] = aux

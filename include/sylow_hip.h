@@ -79,6 +79,42 @@ int32_t sylow_hip_trim(size_t keep_bytes);
  * in-register schedule (no table at all, ~25 % more Miller-loop work).  Results are identical for every limit.  0 restores the default.
  * Process-wide; takes effect at the next call. */
 int32_t sylow_hip_set_scratch_limit(size_t bytes);
+/* Route selectors and thresholds (A/B measurements, crossover runs, forcing a route in a test).  Process-wide, read at every call; a value
+ * < 0 restores the default.  The LIBRARY reads no environment variable (rounds 1-5 did: eight getenv switches behind this ABI); a host
+ * that wants SYLOW_HIP_* variables reads them itself and calls this (sylow_amd/_lib.py does).  Results are identical
+ * under every setting.
+ *   STAGGER          1 (default) skewed launches of pairing_batch / bls_verify_batch at >= 2 rounds, 0 plain launches, 2 the skew with the
+ *                    parking blocks' flags muted (every finishing block takes its recompute fallback)
+ *   MULTI_TABLES     default: jobs of >= 2 pairs on average go through line tables in HBM; 0 never, 1 always
+ *   WIDE_TAIL        1 (default) one-wavefront-per-element kernels for small batches and single tails, 0 never
+ *   WIDE_PACK        two elements per wavefront in those kernels above this many elements (default: the CU count; 0 never, 1 always)
+ *   AGG_FORK         1 (default) the aggregate verifiers fork the signature half onto a side stream, 0 one stream
+ *   SIGN_WIDE_MAX    largest batch signed / hashed / multiplied on eight lanes per element (default 16384)
+ *   WIDE_MAX         largest batch of pairings on the one-wavefront route (default 6144)
+ *   WIDE_VERIFY_MAX  largest batch of verifications on it (default 4096) */
+#define SYLOW_HIP_OPT_STAGGER 0
+#define SYLOW_HIP_OPT_MULTI_TABLES 1
+#define SYLOW_HIP_OPT_WIDE_TAIL 2
+#define SYLOW_HIP_OPT_WIDE_PACK 3
+#define SYLOW_HIP_OPT_AGG_FORK 4
+#define SYLOW_HIP_OPT_SIGN_WIDE_MAX 5
+#define SYLOW_HIP_OPT_WIDE_MAX 6
+#define SYLOW_HIP_OPT_WIDE_VERIFY_MAX 7
+#define SYLOW_HIP_OPT_COUNT 8
+int32_t sylow_hip_set_option(int32_t option, int64_t value);
+/* @shape value_host=i64[1] */
+int32_t sylow_hip_get_option(int32_t option, int64_t* value_host);      /* HOST pointer; -1 = the default is in force */
+/* Live clock probe of the metric's kernels (plk::k_pairing, plk::k_bls_verify_fused).  `acc` = 256 uint64 words of DEVICE memory, zeroed
+ * by the caller (NULL switches the probe off; the default).  While set, every wavefront of those kernels reads the shader-clock counter
+ * (s_memtime) and the constant-rate counter (s_memrealtime) when it starts and when it ends and adds, with relaxed device-scope atomics, into
+ * slot s = blockIdx % 64:  acc[4 s] += shader-clock ticks, acc[4 s + 1] += constant-rate ticks, acc[4 s + 2] += 1 (wavefronts),
+ * acc[4 s + 3] = max(constant-rate ticks of one wavefront).  sum(acc[4 s]) / sum(acc[4 s + 1]) x the constant rate
+ * (sylow_hip_wall_clock_khz) is the engine clock those wavefronts ran at, weighted by residency: what bench.py reports as
+ * roofline.sustained_mhz.  Process-wide; the pointer must stay valid until the probe is switched off and the stream is drained. */
+/* @shape acc=u64[256]? */
+int32_t sylow_hip_clock_probe(uint64_t* acc);
+/* @shape khz_host=i32[1] */
+int32_t sylow_hip_wall_clock_khz(int32_t* khz_host);                    /* HOST pointer: rate of s_memrealtime on the current device */
 const char* sylow_hip_last_error(void);
 int32_t sylow_hip_device_count(void);
 int32_t sylow_hip_malloc(void** dptr, size_t bytes);

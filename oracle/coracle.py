@@ -303,6 +303,19 @@ def pairing(p_proj, q_proj):
     return out
 
 
+def bench_pairing_threads(p_proj, q_proj, threads, seconds):
+    """bench.py's all-core CPU leg: `threads` POSIX threads (oracle_bench_pairing_threads, inside the C library: no Python in the loop) each
+    evaluate pairing(p, q) on the first input pair until `seconds` have passed.  -> (per-thread counts, elapsed seconds)"""
+    p, q = _u64(p_proj, 12), _u64(q_proj, 24)
+    threads = max(1, int(threads))
+    counts, sink = np.zeros(threads, dtype=np.uint64), np.zeros(threads, dtype=np.uint64)
+    elapsed = ctypes.c_double(0.0)
+    rc = lib().oracle_bench_pairing_threads(_p(p), _p(q), ctypes.c_int(threads), ctypes.c_double(float(seconds)), _p(counts), _p(sink), ctypes.byref(elapsed))
+    if rc != 0:
+        raise RuntimeError("oracle_bench_pairing_threads: a thread could not be created")
+    return counts, float(elapsed.value)
+
+
 def glued_pairing(p_proj, q_proj, offsets):
     p, q = _u64(p_proj, 12), _u64(q_proj, 24)
     off = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -27,6 +27,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <time.h>
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -953,6 +955,43 @@ API void oracle_final_exponentiation(const u64 *f, u64 *out, size_t n) {
 API void oracle_pairing(const u64 *p, const u64 *q, u64 *out, size_t n) {
   oracle_init();
   for (size_t i = 0; i < n; ++i) st12(out + 48 * i, pairing(ldg1(p + 12 * i), ldg2(q + 24 * i)));
+}
+/* ---- bench.py's cpu_baseline leg: the all-core loop in C (one thread per host core, core count stated) --------------------
+ * `threads` POSIX threads each evaluate pairing(p, q) on the one projective input pair (benches/pairing.rs:5-10: the generators) until
+ * `seconds` of CLOCK_MONOTONIC have passed; counts[t] = pairings thread t finished, *elapsed = wall seconds from the first thread's start
+ * to the last thread's end.  A checksum word of every thread's last result goes to sink[t] so that the loop cannot be optimised away.
+ * Returns 0, or -1 if a thread could not be created (counts then cover the threads that ran). */
+typedef struct { const u64 *p, *q; double deadline; u64 count, sink; } bench_arg;
+static double mono_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void *bench_worker(void *v) {
+  bench_arg *a = (bench_arg *)v;
+  u64 out[48];
+  g1p P = ldg1(a->p);
+  g2p Q = ldg2(a->q);
+  do {
+    st12(out, pairing(P, Q));
+    a->sink ^= out[0] + a->count;
+    a->count += 1;
+  } while (mono_now() < a->deadline);
+  return NULL;
+}
+API int oracle_bench_pairing_threads(const u64 *p, const u64 *q, int threads, double seconds, u64 *counts, u64 *sink, double *elapsed) {
+  oracle_init();
+  if (threads < 1) threads = 1;
+  pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+  bench_arg *args = (bench_arg *)malloc((size_t)threads * sizeof(bench_arg));
+  const double t0 = mono_now();
+  int started = 0, rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    args[t].p = p; args[t].q = q; args[t].deadline = t0 + seconds; args[t].count = 0; args[t].sink = 0;
+    if (pthread_create(&th[t], NULL, bench_worker, &args[t]) != 0) { rc = -1; break; }
+    ++started;
+  }
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  *elapsed = mono_now() - t0;
+  for (int t = 0; t < threads; ++t) { counts[t] = t < started ? args[t].count : 0; sink[t] = t < started ? args[t].sink : 0; }
+  free(th); free(args);
+  return rc;
 }
 /* glued_pairing (pairing.rs:1029-1037): job j covers pairs [off[j], off[j+1]); projective inputs */
 API void oracle_glued_pairing(const u64 *p, const u64 *q, const u64 *off, u64 *out, size_t njobs) {

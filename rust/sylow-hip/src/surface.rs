@@ -779,6 +779,41 @@ pub fn set_scratch_limit(bytes: usize) -> Result<(), device::Error> {
     device::check(unsafe { ffi::sylow_hip_set_scratch_limit(bytes) })
 }
 
+/// The library's route selectors and thresholds (`SYLOW_HIP_OPT_*` of include/sylow_hip.h; the library reads no environment variable).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+#[repr(i32)]
+pub enum RouteOption { Stagger = 0, MultiTables = 1, WideTail = 2, WidePack = 3, AggFork = 4, SignWideMax = 5, WideMax = 6, WideVerifyMax = 7 }
+
+/// `sylow_hip_set_option`: `None` restores the default.  Process-wide; results do not depend on any setting.
+pub fn set_option(option: RouteOption, value: Option<u64>) -> Result<(), device::Error> {
+    // SAFETY: plain value arguments.
+    device::check(unsafe { ffi::sylow_hip_set_option(option as i32, value.map_or(-1, |v| v as i64)) })
+}
+
+/// `sylow_hip_get_option`: `None` = the default is in force.
+pub fn get_option(option: RouteOption) -> Result<Option<u64>, device::Error> {
+    let mut v: i64 = -1;
+    // SAFETY: one host word.
+    device::check(unsafe { ffi::sylow_hip_get_option(option as i32, &mut v) })?;
+    Ok(if v < 0 { None } else { Some(v as u64) })
+}
+
+/// Live clock probe of the metric's kernels (`sylow_hip_clock_probe`): `acc` = 256 zeroed device words, or `None` to switch it off.  The
+/// buffer must outlive the probe.  Returns the accumulators' meaning in include/sylow_hip.h.
+pub fn clock_probe(acc: Option<&DeviceBuf<u64>>) -> Result<(), device::Error> {
+    if let Some(a) = acc { assert!(a.len >= 256); }
+    // SAFETY: a device buffer of at least 256 words, or NULL.
+    device::check(unsafe { ffi::sylow_hip_clock_probe(acc.map_or(ptr::null_mut(), |a| a.as_mut_ptr())) })
+}
+
+/// Rate of the constant-rate counter the clock probe reads, in kHz (`sylow_hip_wall_clock_khz`).
+pub fn wall_clock_khz() -> Result<i32, device::Error> {
+    let mut khz: i32 = 0;
+    // SAFETY: one host word.
+    device::check(unsafe { ffi::sylow_hip_wall_clock_khz(&mut khz) })?;
+    Ok(khz)
+}
+
 /// Hand the current device's idle scratch blocks above `keep_bytes` back to the driver (`sylow_hip_trim`): the library keeps the largest
 /// block a call has needed for reuse, which after a 2^20-pair product is several GB.
 pub fn trim(keep_bytes: usize) -> Result<(), device::Error> {

@@ -137,6 +137,10 @@ SIGNATURES = {
     "sylow_hip_fp12_hook_batch": [c_i32, c_u64p, c_u64p, c_u64p, c_sz, c_vp],
     "sylow_hip_trim": [c_sz],
     "sylow_hip_set_scratch_limit": [c_sz],
+    "sylow_hip_set_option": [c_i32, ctypes.c_int64],
+    "sylow_hip_get_option": [c_i32, ctypes.POINTER(ctypes.c_int64)],
+    "sylow_hip_clock_probe": [c_u64p],
+    "sylow_hip_wall_clock_khz": [ctypes.POINTER(c_i32)],
     "sylow_hip_g1_sum_batch": [c_u64p, c_u8p, c_sz, c_u64p, c_u8p, c_vp],
     "sylow_hip_pairing_host": [c_u64p, c_u8p, c_u64p, c_u8p, c_u64p, c_sz, c_sz],
     "sylow_hip_bls_verify_host": [c_u64p, c_u8p, c_u8p, c_u64p, c_u64p, c_u8p, c_u8p, c_sz, c_sz],
@@ -146,6 +150,10 @@ SIGNATURES = {
     "sylow_hip_host_free": [c_vp],
 }
 _RESTYPE = {"sylow_hip_last_error": ctypes.c_char_p}
+
+# SYLOW_HIP_OPT_* of include/sylow_hip.h.  The LIBRARY reads no environment variable; this host layer does, once, when it loads the library:
+# SYLOW_HIP_<NAME>=<integer> becomes sylow_hip_set_option(<NAME>, value) -- what tests/test_gpu_routes.py and the A/B scripts under tools/ set
+OPTIONS = {"STAGGER": 0, "MULTI_TABLES": 1, "WIDE_TAIL": 2, "WIDE_PACK": 3, "AGG_FORK": 4, "SIGN_WIDE_MAX": 5, "WIDE_MAX": 6, "WIDE_VERIFY_MAX": 7}
 
 
 class SylowHipError(RuntimeError):
@@ -197,6 +205,15 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, c_i32)
+        for name, opt in OPTIONS.items():
+            v = os.environ.get("SYLOW_HIP_" + name)
+            if v is not None and v.strip() != "":
+                try:
+                    value = int(v)
+                except ValueError:
+                    raise SylowHipError(f"SYLOW_HIP_{name}={v!r}: not an integer") from None
+                if lib.sylow_hip_set_option(opt, value) != 0:
+                    raise SylowHipError(f"sylow_hip_set_option({name}) failed")
         _lib = lib
     return _lib
 

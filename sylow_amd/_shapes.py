@@ -4,12 +4,13 @@ live DeviceArray must be at least as large as the header says for the call's siz
 launch, with the entry point, the parameter and both sizes in the message, instead of a kernel writing past a buffer."""
 from __future__ import annotations
 
+import operator
 import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sylow_hip.h")
-ITEMSIZE = {"u64": 8, "u8": 1, "i32": 4, "void": 1}
+ITEMSIZE = {"u64": 8, "i64": 8, "u8": 1, "i32": 4, "void": 1}
 _EXPR_OK = re.compile(r"^[\w\s+*()]+$")
 
 
@@ -56,7 +57,10 @@ _TABLE = None
 def table():
     global _TABLE
     if _TABLE is None:
-        _TABLE = parse()
+        try:
+            _TABLE = parse()
+        except OSError:            # the package deployed without the repo's include/ directory: no table, nothing to check
+            _TABLE = {}
     return _TABLE
 
 
@@ -66,18 +70,32 @@ def check_call(name, args, live):
     if ent is None:
         return
     names, shapes = ent
-    values = {n: int(a) for n, a in zip(names, args) if n not in shapes and isinstance(a, int)}
+    values = {}
+    for n, a in zip(names, args):
+        if n in shapes or a is None or isinstance(a, (bytes, bool)):
+            continue
+        try:
+            values[n] = operator.index(a)                  # Python ints and numpy integers alike
+        except TypeError:
+            pass
     for n, a in zip(names, args):
         sh = shapes.get(n)
         if sh is None:
             continue
         if a is None or a == 0:
-            if not sh.optional and sh.nbytes(values) != 0:       # NULL is fine where the call needs zero elements (an empty batch)
+            try:
+                empty = sh.nbytes(values) == 0                   # NULL is fine where the call needs zero elements (an empty batch)
+            except NameError:
+                empty = True
+            if not sh.optional and not empty:
                 raise ValueError(f"{name}: {n} must not be NULL")
             continue
         have = live.get(a) if isinstance(a, int) else None
         if have is None:
             continue                                       # not the base of one of our arrays (an offset pointer, a torch tensor): not checkable
-        need = sh.nbytes(values)
+        try:
+            need = sh.nbytes(values)
+        except NameError:
+            continue                                       # a size argument of the expression was not an integer: not checkable
         if need is not None and have < need:
             raise ValueError(f"{name}: {n} holds {have} bytes, the call needs {sh.dtype}[{sh.expr}] = {need} bytes")

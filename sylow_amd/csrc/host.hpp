@@ -32,6 +32,9 @@ int32_t g2_gen_comb(const bn254::i32** out, hipStream_t st);     // fixed-base t
 void dst_arg(DstPrime& dp, const uint8_t* dst, size_t len);     // NULL -> sylow's DST (lib.rs:90)
 size_t scratch_limit();                                         // sylow_hip_set_scratch_limit: 0 = default
 unsigned compute_units();                                       // CUs of the calling thread's current device (0 if unknown)
+long long option(int opt);                                      // sylow_hip_set_option: the value in force, -1 = the default (SYLOW_HIP_OPT_*)
+inline long long option_or(int opt, long long dflt) { const long long v = option(opt); return v < 0 ? dflt : v; }
+uint64_t* clock_probe();                                        // sylow_hip_clock_probe: the accumulator the metric's kernels add to, or NULL
 }  // namespace host
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return host::fail(e_, #x); } while (0)

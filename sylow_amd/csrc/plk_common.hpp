@@ -24,10 +24,30 @@ BN_DEV void store_s12(u64* base, size_t n, size_t i, int odd, const S12& a) {
 // the parked chunks (b - nblk + first).  See k_pairing for why.
 struct Stagger {
   unsigned first, count, nblk;
-  unsigned mute;                    // test mode (SYLOW_HIP_STAGGER=2): parking blocks never publish, so every finishing block takes the recompute fallback
+  unsigned mute;                    // test mode (SYLOW_HIP_OPT_STAGGER = 2): parking blocks never publish, so every finishing block takes the recompute fallback
   u64* park;                        // [48][count * BLOCK / 2] raw Miller values
   unsigned* done;                   // [count] set by a parking block when its values are visible
+  u64* clk;                         // sylow_hip_clock_probe: [64][4] accumulators, or NULL (the default)
 };
+// Live clock probe (include/sylow_hip.h: sylow_hip_clock_probe).  Every wavefront reads the shader-clock counter and the constant-rate counter
+// when it starts and when it ends; lane 0 adds the two deltas, a wavefront count and the longest residency into slot blockIdx % 64.  Four scalar
+// registers across the kernel and four fire-and-forget atomics per wavefront (32 768 wavefronts per 2^20 pairings): not measurable in the kernel's
+// time (same-box A/B in DESIGN.md section 8).
+struct ClockProbe { u64 c0, w0; };
+BN_DEV void probe_begin(ClockProbe& pb, const u64* clk) {
+  if (clk) { pb.c0 = __builtin_amdgcn_s_memtime(); pb.w0 = __builtin_amdgcn_s_memrealtime(); }
+}
+BN_DEV void probe_end(const ClockProbe& pb, u64* clk) {
+  if (!clk) return;
+  const u64 dc = __builtin_amdgcn_s_memtime() - pb.c0, dw = __builtin_amdgcn_s_memrealtime() - pb.w0;
+  if ((threadIdx.x & 63) == 0) {
+    u64* a = clk + 4 * (blockIdx.x & 63);
+    __hip_atomic_fetch_add(a + 0, dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a + 1, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a + 2, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(a + 3, dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 // role of this block -- 0: whole element, 1: Miller loop only (park), 2: final exponentiation only -- and the chunk of elements it works on
 BN_DEV int stagger_role(const Stagger& st, unsigned& chunk) {
   chunk = blockIdx.x;
@@ -58,6 +78,9 @@ BN_DEV bool stagger_wait(const Stagger& st, unsigned chunk) {
     ready = r;
   }
   __syncthreads();
+  // every wavefront reads st.park next: the acquire above was thread 0's; the barrier orders the workgroup but is no agent-scope acquire for
+  // the other wavefronts' vector loads in the memory model (one L1 per CU makes it hold in practice) -- one fence per wavefront makes it formal
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return ready != 0;
 }
 
@@ -77,5 +100,14 @@ constexpr int LINE_TABLE_WORDS = LINE_TABLE_LINES * 36 + LINE_TABLE_LINES;
 
 namespace plkh {
 // plk_pairing.hip: fills `sg` for a staggered launch of `nblk` blocks, `full` of them whole chunks (count = 0: plain launch)
-hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st);
+// `resident` = blocks of the kernel one CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor, queried by the caller for ITS kernel)
+hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st, int resident);
+template <class K> int blocks_per_cu(K kernel) {          // cached per kernel; 2 (what the kernels are built for) if the query fails
+  static const int v = [&] {
+    int b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kernel, BLOCK, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 2; }
+    return b;
+  }();
+  return v;
+}
 }  // namespace plkh

@@ -2,6 +2,8 @@
 // batch-wide product (chunked Miller loops + a log-depth tree of Fp12 products + one final exponentiation).
 #include "plk_common.hpp"
 
+#include <atomic>
+
 namespace plk {
 // ------------------------------------------------------------------ glued pairing ----------------------------------------
 // Wave-uniform schedule: chunks of KMAX pairs share the squarings of
@@ -768,39 +770,56 @@ __global__ void __launch_bounds__(BLOCK) k_evm_pair_finalize(const uint8_t* pst,
 
 // Jobs of two or more pairs on average: lines to HBM, then the table-driven loop, then the final exponentiations (see k_pair_lines).
 // Job batches share one leased workspace, reused in stream order: 19.5 KB per slot and job, batches of whole GPU rounds (2^16 lane
-// pairs) up to TBL_BYTES.  SYLOW_HIP_MULTI_TABLES=0 / 1 forces the in-register / the table route for every job size (A/B runs).
-static int multi_tables_mode() {
-  static const int v = [] { const char* e = getenv("SYLOW_HIP_MULTI_TABLES"); return e ? atoi(e) : -1; }();
-  return v;
-}
-// Bytes the line tables of one call may take: 12 GB, or the host's bound (sylow_hip_set_scratch_limit)
+// pairs) up to TBL_BYTES.  SYLOW_HIP_OPT_MULTI_TABLES = 0 / 1 forces the in-register / the table route for every job size (A/B runs).
+static int multi_tables_mode() { return (int)host::option(SYLOW_HIP_OPT_MULTI_TABLES); }
+// Bytes the line tables of one call may take: the host's bound (sylow_hip_set_scratch_limit), or by default a quarter of the device memory
+// that was FREE when this device's first multi-pair call arrived, at most 12 GB (an empty MI355X: 12 GB, nine rounds of two-slot jobs; a GPU
+// that is shared and mostly full: proportionally less -- never a constant that ignores the other tenants).  hipMemGetInfo is asked once per
+// device (it costs tens of microseconds; the small aggregate verifications are 2 ms calls).
 static size_t table_budget() {
   const size_t lim = host::scratch_limit();
-  return lim ? lim : (size_t)12 << 30;
+  if (lim) return lim;
+  static std::atomic<size_t> cache[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) { (void)hipGetLastError(); return (size_t)12 << 30; }
+  size_t v = cache[d].load(std::memory_order_relaxed);
+  if (!v) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)48 << 30; }
+    v = free_b / 4;
+    if (v > ((size_t)12 << 30)) v = (size_t)12 << 30;
+    if (v < ((size_t)64 << 20)) v = (size_t)64 << 20;
+    cache[d].store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
+// bytes of line tables one job of kt slots takes (k_pair_lines' layout)
+static size_t table_bytes_per_job(size_t kt) { return (size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4); }
+static size_t table_slots(size_t n_jobs, size_t n_pairs) {       // slots per job: the batch average, rounded up, 1..8; longer jobs take the in-register tail
+  size_t kt = n_jobs ? (n_pairs + n_jobs - 1) / n_jobs : 1;
+  return kt < 1 ? 1 : kt > 8 ? 8 : kt;
+}
+// The table route slices a batch into blocks of at least 1024 jobs: a budget below 1024 jobs' tables (20 - 160 MB by the job size) cannot be
+// honoured by it, so such a batch takes the in-register schedule (no table at all) -- the bound a host sets is never silently exceeded.
 static bool use_tables(size_t n_jobs, size_t n_pairs) {
   const int m = multi_tables_mode();
   if (m == 0) return false;
-  if (m == 1) return n_pairs != 0;
-  return n_pairs >= 2 * n_jobs;
+  if (m != 1 && n_pairs < 2 * n_jobs) return false;
+  if (!n_pairs) return false;
+  const size_t need = table_bytes_per_job(table_slots(n_jobs, n_pairs)) * (n_jobs < 1024 ? n_jobs : 1024);
+  return need <= table_budget();
 }
-// SYLOW_HIP_WIDE_TAIL=0: the single final exponentiation of the one-boolean shapes on one lane pair (default: on the whole wavefront)
-static int wide_tail() {
-  static const int v = [] { const char* e = getenv("SYLOW_HIP_WIDE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
-  return v;
-}
-// SYLOW_HIP_WIDE_PACK=t: the small-batch kernels put two elements on a wavefront above t elements (0 = never, 1 = always: A/B runs and
+// SYLOW_HIP_OPT_WIDE_TAIL = 0: the single final exponentiation of the one-boolean shapes on one lane pair (default: on the whole wavefront)
+static int wide_tail() { return host::option(SYLOW_HIP_OPT_WIDE_TAIL) == 0 ? 0 : 1; }
+// SYLOW_HIP_OPT_WIDE_PACK = t: the small-batch kernels put two elements on a wavefront above t elements (0 = never, 1 = always: A/B runs and
 // tests/test_gpu_routes.py).  Default: the number of compute units -- one wavefront per CU is the fastest shape (1.72 ms per pairing up
 // to 256), a second wavefront on a CU already costs more (1.9 ms) than a wavefront of two elements (1.76 ms), and from there on the
 // packed form has half the wavefronts: 1024 pairings 1.91 against 2.11 ms, 2048 2.15 against 3.74 ms, 4096 3.8 against 4.25 ms.
 static size_t wide_pack() {
-  static const size_t v = [] {
-    const char* e = getenv("SYLOW_HIP_WIDE_PACK");
-    if (e) return (size_t)strtoull(e, nullptr, 10);
-    const unsigned cus = host::compute_units();
-    return (size_t)(cus ? cus : 256);
-  }();
-  return v;
+  const long long o = host::option(SYLOW_HIP_OPT_WIDE_PACK);
+  if (o >= 0) return (size_t)o;
+  const unsigned cus = host::compute_units();
+  return (size_t)(cus ? cus : 256);
 }
 // Two elements per wavefront (16 lane pairs each) cost a second product pass in the dense Fp12 products of the final exponentiation only.
 static void launch_miller_wide(const u64* pa, const uint8_t* pa_inf, const u64* qa, const uint8_t* qa_inf, u64* fa,
@@ -829,16 +848,15 @@ __global__ void __launch_bounds__(BLOCK) k_gt_eq_flags(const u64* a, const u64* 
 namespace plkh {
 // Small batches on one wavefront per one or two elements (k_miller_wide_batch / k_final_exp_wide_batch): up to this many pairings the
 // latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each, and one more half-round)
-// SYLOW_HIP_WIDE_MAX=n / SYLOW_HIP_WIDE_VERIFY_MAX=n move the two caps (crossover runs, tools/dbg/time_small.py)
-static size_t env_size(const char* name) { const char* e = getenv(name); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0; }
+// SYLOW_HIP_OPT_WIDE_MAX / _WIDE_VERIFY_MAX move the two caps (crossover runs, tools/dbg/time_small.py)
 size_t wide_batch_max() {
-  static const size_t v = env_size("SYLOW_HIP_WIDE_MAX");
+  const size_t v = (size_t)host::option_or(SYLOW_HIP_OPT_WIDE_MAX, 0);
   return !wide_tail() ? 0 : v ? v : wide_pack() ? 6144 : 2048;      // 6144 pairings: three half-rounds of wavefronts, 3.6 against 4.2 ms; 7168: 4.6
 }
 // ... and up to this many verifications (2 n Miller loops + n final exponentiations; two rounds of wavefronts at the cap: 4096
 // verifications 3.8 against 5.4 ms on the lane-pair kernel, 6144: 5.7 against 5.4)
 size_t wide_verify_max() {
-  static const size_t v = env_size("SYLOW_HIP_WIDE_VERIFY_MAX");
+  const size_t v = (size_t)host::option_or(SYLOW_HIP_OPT_WIDE_VERIFY_MAX, 0);
   return !wide_tail() ? 0 : v ? v : wide_pack() ? 4096 : 1024;
 }
 // pairing(P_i, Q_i), i < n: raw values through `scratch` (48 n words), Gt values to gt_out (SoA stride n)
@@ -892,12 +910,10 @@ static int32_t multi_pairing_tables(const uint64_t* p_xy, const uint8_t* p_inf, 
   // iso: the line tables may be built on the isomorphic curves (k_pair_lines<true>) -- whenever the value ends in a final exponentiation, here or
   // in the caller; 0 only where the reference's raw Miller value itself is the result (glued_miller_loop_batch)
   hipStream_t st = (hipStream_t)stream;
-  size_t kt = (n_pairs + n_jobs - 1) / n_jobs;                 // slots per job: the batch average, rounded up; longer jobs take the in-register tail
-  if (kt < 1) kt = 1;
-  if (kt > 8) kt = 8;
+  const size_t kt = table_slots(n_jobs, n_pairs);
   constexpr size_t ROUND = 65536;
   const size_t TBL_BYTES = table_budget();
-  const size_t per_job = (size_t)plk::LT_LINES * kt * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);
+  const size_t per_job = table_bytes_per_job(kt);
   const size_t rounds = TBL_BYTES / (per_job * ROUND);
   // whole rounds of the GPU's 2^16 resident lane pairs while the budget allows; under a host-set limit below one round
   // (sylow_hip_set_scratch_limit) as many jobs as fit, in blocks of 1024 -- phase B / C then run under-filled, the price of the bound
@@ -997,7 +1013,7 @@ static int32_t miller_product_tree(const uint64_t* p_xy, const uint8_t* p_inf, c
     launch_miller_wide(p_xy, p_inf, q_xy, q_inf, bufa, nullptr, nullptr, nullptr, nullptr, nullptr, n_pairs, st);
   } else {
   plk::k_chunk_offsets<<<GRID(n_jobs + 1)>>>(off, n_jobs, n_pairs, chunk, range);
-  // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_MULTI_TABLES=0: the in-register KPROD-slot schedule)
+  // chunks of two or more pairs: lines to HBM + the table-driven loop (SYLOW_HIP_OPT_MULTI_TABLES = 0: the in-register KPROD-slot schedule)
   const size_t round_table = (size_t)65536 * chunk * plk::LT_LINES * plk::LT_CHUNKS * 2 * sizeof(plk::u32x4);     // one round of chunk-slot jobs
   if (chunk >= 2 && multi_tables_mode() != 0 && (round_table <= table_budget() || multi_tables_mode() == 1)) {
     rc = multi_pairing_tables(p_xy, p_inf, q_xy, q_inf, off, n_jobs, n_pairs, skip_infinity, bufa, nullptr, 1, /*iso=*/1, stream);
@@ -1098,14 +1114,13 @@ int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint
 // A short-lived side stream for work that does not depend on the long kernels of the caller's stream (here: the sum of the
 // signatures and the one Miller loop it feeds run beside the batch's hashing instead of after it).  open(): the side stream waits for
 // everything the caller's stream holds at this point; join(): the caller's stream waits for the side work.  Any failure to create the
-// stream or its events degrades to the caller's stream (same results, no overlap); SYLOW_HIP_AGG_FORK=0 forces that.
+// stream or its events degrades to the caller's stream (same results, no overlap); SYLOW_HIP_OPT_AGG_FORK = 0 forces that.
 namespace {
 struct Fork {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t open(hipStream_t main) {
-    static const bool off = [] { const char* e = getenv("SYLOW_HIP_AGG_FORK"); return e && e[0] == '0'; }();
-    if (off) return main;
+    if (host::option(SYLOW_HIP_OPT_AGG_FORK) == 0) return main;
     if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; (void)hipGetLastError(); return main; }
     if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {

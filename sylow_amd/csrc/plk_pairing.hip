@@ -33,7 +33,7 @@ __global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
 // in a leased block (role M), the blocks that follow them into those slots therefore start their Miller loops while their SIMD partners are
 // in the final exponentiation, and the parked values are finished by extra blocks at the end of the grid (role F).  Same arithmetic, same
 // results; 1.6 % of a 2^20 batch takes the detour through 384 bytes of HBM per element.
-__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, Stagger st) {
+BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, const Stagger& st) {
   unsigned chunk;
   int role = stagger_role(st, chunk);
   const size_t t = (size_t)chunk * blockDim.x + threadIdx.x, i = pair_index(t);
@@ -63,6 +63,12 @@ __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, cons
   }
   if (role == 1) { stagger_publish(st, chunk); return; }
   store_s12(gout, n, i, odd, g);
+}
+__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, Stagger st) {
+  ClockProbe pb;
+  probe_begin(pb, st.clk);
+  pairing_body(pxy, pinf, qxy, qinf, gout, n, st);
+  probe_end(pb, st.clk);
 }
 
 // test hook: the lane-pair Fp12 layer one operation at a time (ops 16.. of sylow_hip_fp12_hook_batch); `b` carries the second
@@ -117,23 +123,21 @@ int32_t fp12_op(int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out,
 }  // namespace plkh
 
 namespace plkh {
-// SYLOW_HIP_STAGGER=0: every block runs its whole element (A/B runs); =2: the skew with the parking blocks' flags muted, so that every
+// SYLOW_HIP_OPT_STAGGER = 0: every block runs its whole element (A/B runs); 2: the skew with the parking blocks' flags muted, so that every
 // finishing block times out and takes its recompute fallback (tests/test_gpu_routes.py runs the parity tests under both)
-static int stagger_mode() {
-  static const int v = [] { const char* e = getenv("SYLOW_HIP_STAGGER"); return e ? atoi(e) : 1; }();
-  return v;
-}
+static int stagger_mode() { return (int)host::option_or(SYLOW_HIP_OPT_STAGGER, 1); }
 // Fills `sg` for a staggered launch of `nblk` blocks (`full` of them whole chunks) when the batch is at least two rounds of the resident
 // blocks (2 per CU): measured on k_pairing, 2^17 elements 14.46 -> 14.00 ms, 2^18 27.86 -> 27.33, 2^19 54.95 -> 54.3, 2^20 108.5 -> 108.0;
 // exactly one round (2^16) LOSES 2 % (the parked half runs its final exponentiations beside the other half's), so smaller batches stay plain.
 // Leaves sg.count = 0 (plain launch) when the lease fails.  The caller releases `ws` after the launch.
-hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st) {
-  sg = plk::Stagger{0, 0, (unsigned)nblk, stagger_mode() == 2 ? 1u : 0u, nullptr, nullptr};
-  const unsigned cus = host::compute_units();
-  if (stagger_mode() == 0 || !cus || full < 4 * (size_t)cus || nblk >= 0x7fffffffu) return hipSuccess;
-  const size_t park_bytes = (size_t)cus * (BLOCK / 2) * 48 * sizeof(u64), flag_bytes = ((size_t)cus * sizeof(unsigned) + 255) & ~(size_t)255;
+hipError_t stagger_setup(plk::Stagger& sg, host::Lease& ws, size_t nblk, size_t full, hipStream_t st, int resident) {
+  sg = plk::Stagger{0, 0, (unsigned)nblk, stagger_mode() == 2 ? 1u : 0u, nullptr, nullptr, host::clock_probe()};
+  // the first resident set is `resident` blocks per CU (2 for these kernels: asked of the occupancy API, not assumed); its second half parks
+  const unsigned cus = host::compute_units(), half = cus * (unsigned)(resident > 1 ? resident : 2) / 2;
+  if (stagger_mode() == 0 || !cus || resident < 2 || full < 4 * (size_t)half || nblk >= 0x7fffffffu) return hipSuccess;
+  const size_t park_bytes = (size_t)half * (BLOCK / 2) * 48 * sizeof(u64), flag_bytes = ((size_t)half * sizeof(unsigned) + 255) & ~(size_t)255;
   if (ws.acquire(park_bytes + flag_bytes, st) != SYLOW_HIP_OK) { (void)hipGetLastError(); return hipSuccess; }
-  sg.first = cus; sg.count = cus;
+  sg.first = half; sg.count = half;
   sg.park = (u64*)ws.p; sg.done = (unsigned*)((uint8_t*)ws.p + park_bytes);
   return hipMemsetAsync(sg.done, 0, flag_bytes, st);
 }
@@ -168,7 +172,7 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
   const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
   plk::Stagger sg;
   host::Lease ws;
-  HIPCHK(plkh::stagger_setup(sg, ws, nblk, full, st));
+  HIPCHK(plkh::stagger_setup(sg, ws, nblk, full, st, plkh::blocks_per_cu(plk::k_pairing)));
   plk::k_pairing<<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, st>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, sg);
   const hipError_t e = hipGetLastError();
   const int32_t rc = ws.release();

@@ -145,9 +145,9 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
 // precomputed.  -H(m_i) comes from k_hash_to_g1 (affine SoA hneg / hneg_inf): one Keccak expansion per element, and the hashing code's
 // registers and stack frame stay out of this kernel (hashing inside it -- each lane of a pair mapping one field element -- measured 1 % slower).
 template <bool PK_TABLE>
-__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
-                                                const u64* hneg, const uint8_t* hneg_inf,
-                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, Stagger st) {
+BN_DEV void bls_verify_fused_body(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
+                                  const u64* hneg, const uint8_t* hneg_inf,
+                                  const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, const Stagger& st) {
   __shared__ i32 tabA[LINE_TABLE_WORDS];
   __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
   // staggered launch (k_pairing, plk_pairing.hip): role 1 parks the two-pair Miller value, role 2 finishes a parked chunk
@@ -264,6 +264,15 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
   const bool one = s12_is_one(g);
   if (active && !odd) okout[i] = one ? 1 : 0;
 }
+template <bool PK_TABLE>
+__global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
+                                                const u64* hneg, const uint8_t* hneg_inf,
+                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, Stagger st) {
+  ClockProbe pb;
+  probe_begin(pb, st.clk);
+  bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, st);
+  probe_end(pb, st.clk);
+}
 }  // namespace plk
 
 namespace plkh {
@@ -284,11 +293,11 @@ static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const 
   u64* hneg = (u64*)ws.p;
   uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
   rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
-  plk::Stagger sg{0, 0, 0, 0, nullptr, nullptr};
+  plk::Stagger sg{0, 0, 0, 0, nullptr, nullptr, nullptr};
   host::Lease wp;
   const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
   if (rc == SYLOW_HIP_OK) {
-    const hipError_t es = plkh::stagger_setup(sg, wp, nblk, full, (hipStream_t)stream);
+    const hipError_t es = plkh::stagger_setup(sg, wp, nblk, full, (hipStream_t)stream, plkh::blocks_per_cu(plk::k_bls_verify_fused<PK_TABLE>));
     if (es != hipSuccess) rc = host::fail(es, "stagger flags");
   }
   if (rc == SYLOW_HIP_OK)

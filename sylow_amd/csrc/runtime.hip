@@ -190,6 +190,10 @@ int32_t fail(hipError_t e, const char* what) {
 static const uint8_t SYLOW_DST[] = "WARLOCK-CHAOS-V01-CS01-SHA-256";   // lib.rs:90 (30 bytes)
 static std::atomic<size_t> g_scratch_limit{0};
 size_t scratch_limit() { return g_scratch_limit.load(std::memory_order_relaxed); }
+static std::atomic<long long> g_option[SYLOW_HIP_OPT_COUNT];            // 0 = default, else value + 1
+long long option(int opt) { return (opt < 0 || opt >= SYLOW_HIP_OPT_COUNT) ? -1 : g_option[opt].load(std::memory_order_relaxed) - 1; }
+static std::atomic<uint64_t*> g_clock_probe{nullptr};
+uint64_t* clock_probe() { return g_clock_probe.load(std::memory_order_relaxed); }
 unsigned compute_units() {
   static std::atomic<unsigned> cache[64];
   int d = 0;
@@ -425,6 +429,26 @@ int32_t sylow_hip_trim(size_t keep_bytes) {
 // Upper bound for the line tables of the multi-pair routes (plk_multi.hip), the one scratch user whose size is not proportional to its
 // input: 0 = the default (12 GB).  Process-wide; read at the start of each call.
 int32_t sylow_hip_set_scratch_limit(size_t bytes) { host::g_scratch_limit.store(bytes, std::memory_order_relaxed); return SYLOW_HIP_OK; }
+// Route selectors and thresholds (include/sylow_hip.h): the library reads no environment variable
+int32_t sylow_hip_set_option(int32_t option, int64_t value) {
+  ARGCHK(option >= 0 && option < SYLOW_HIP_OPT_COUNT);
+  host::g_option[option].store(value < 0 ? 0 : (long long)value + 1, std::memory_order_relaxed);
+  return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_get_option(int32_t option, int64_t* value_host) {
+  ARGCHK(option >= 0 && option < SYLOW_HIP_OPT_COUNT && value_host);
+  *value_host = (int64_t)host::option(option);
+  return SYLOW_HIP_OK;
+}
+int32_t sylow_hip_clock_probe(uint64_t* acc) { host::g_clock_probe.store(acc, std::memory_order_relaxed); return SYLOW_HIP_OK; }
+int32_t sylow_hip_wall_clock_khz(int32_t* khz_host) {
+  ARGCHK(khz_host);
+  int d = 0, khz = 0;
+  HIPCHK(hipGetDevice(&d));
+  HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d));
+  *khz_host = khz;
+  return SYLOW_HIP_OK;
+}
 int32_t sylow_hip_malloc(void** dptr, size_t bytes) { ARGCHK(dptr); HIPCHK(hipMalloc(dptr, bytes ? bytes : 1)); return SYLOW_HIP_OK; }
 int32_t sylow_hip_free(void* dptr) { HIPCHK(hipFree(dptr)); return SYLOW_HIP_OK; }
 int32_t sylow_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {

@@ -24,10 +24,7 @@ k_bls_sign(const u64* sk, const uint8_t* msgs, const u64* off, DstPrime dp, u64*
 
 constexpr size_t SIGN_WIDE_MAX = 16384;      // 8 signatures per wavefront: up to two wavefronts per SIMD (16 384: 1.36 against 1.74 ms; 24 576: 1.98 against 1.76)
 namespace g1h {
-size_t sign_wide_max() {                      // SYLOW_HIP_SIGN_WIDE_MAX: crossover measurements (tools/dbg/time_sign.py)
-  static const size_t v = [] { const char* e = getenv("SYLOW_HIP_SIGN_WIDE_MAX"); return e ? (size_t)atoll(e) : SIGN_WIDE_MAX; }();
-  return v;
-}
+size_t sign_wide_max() { return (size_t)host::option_or(SYLOW_HIP_OPT_SIGN_WIDE_MAX, (long long)SIGN_WIDE_MAX); }     // the option: crossover measurements (tools/dbg/time_sign.py)
 }
 
 extern "C" {
@@ -35,7 +32,7 @@ int32_t sylow_hip_bls_sign_batch(const uint64_t* sk, const uint8_t* msgs, const 
                                  uint64_t* sig_xy, uint8_t* sig_inf, size_t n, void* stream) {
   ARGCHK(sk && msgs && msg_offsets && sig_xy && sig_inf); if (!n) return SYLOW_HIP_OK;
   // single calls and small batches: eight lanes per signature (sign_wide.hip) -- one signature 2.1 -> 0.67 ms; the one-lane kernel below wins
-  // once the batch fills the chip's lanes (SYLOW_HIP_WIDE_TAIL=0 switches every one-wavefront-per-element route off, this one included)
+  // once the batch fills the chip's lanes (SYLOW_HIP_OPT_WIDE_TAIL = 0 switches every one-wavefront-per-element route off, this one included)
   if (plkh::wide_batch_max() != 0 && n <= g1h::sign_wide_max()) return g1h::sign_wide(sk, msgs, msg_offsets, sig_xy, sig_inf, n, stream);
   DstPrime dp; host::dst_arg(dp, nullptr, 0);
   host::Lease ws;

@@ -137,6 +137,34 @@ class Engine:
         _lib.check(self.lib.sylow_hip_set_device(self.device), "sylow_hip_set_device")
         _lib.check(self.lib.sylow_hip_trim(keep_bytes), "sylow_hip_trim")
 
+    def set_option(self, name: str, value: int = -1):
+        """A route selector / threshold of the library (sylow_hip_set_option; names = _lib.OPTIONS, value < 0 = the default).  Process-wide."""
+        _lib.check(self.lib.sylow_hip_set_option(_lib.OPTIONS[name], value), "sylow_hip_set_option")
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64(0)
+        _lib.check(self.lib.sylow_hip_get_option(_lib.OPTIONS[name], ctypes.byref(v)), "sylow_hip_get_option")
+        return int(v.value)
+
+    def wall_clock_khz(self) -> int:
+        v = ctypes.c_int32(0)
+        _lib.check(self.lib.sylow_hip_wall_clock_khz(ctypes.byref(v)), "sylow_hip_wall_clock_khz")
+        return int(v.value)
+
+    def clock_probe(self, acc=None):
+        """Switch the live clock probe of the metric's kernels on (acc: a zeroed DeviceArray of 256 uint64) or off (None)."""
+        if acc is not None and acc.nbytes < 256 * 8:
+            raise ValueError("clock_probe: the accumulator holds fewer than 256 uint64 words")
+        _lib.check(self.lib.sylow_hip_clock_probe(acc.ptr if acc is not None else None), "sylow_hip_clock_probe")
+
+    @staticmethod
+    def clock_probe_summary(words, khz):
+        """(sustained MHz, shader-clock ticks, wavefronts, longest wavefront in ms) from the 256 accumulator words and the constant rate."""
+        w = np.asarray(words, dtype=np.uint64).reshape(64, 4)
+        clk, wall, waves = int(w[:, 0].sum()), int(w[:, 1].sum()), int(w[:, 2].sum())
+        mhz = clk / wall * khz / 1e3 if wall else None
+        return mhz, clk, waves, (int(w[:, 3].max()) / khz if khz else None)
+
     def set_scratch_limit(self, nbytes: int = 0):
         """Upper bound for the multi-pair routes' line tables (sylow_hip_set_scratch_limit; 0 = the default of 12 GB).  Process-wide."""
         _lib.check(self.lib.sylow_hip_set_scratch_limit(nbytes), "sylow_hip_set_scratch_limit")

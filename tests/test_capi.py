@@ -84,20 +84,43 @@ def test_host_xoshiro_matches_the_test_stream():
     assert lib.sylow_hip_host_xoshiro_fp(1, None, 4, 4) == -2
 
 
-def test_environment_switches_are_the_documented_ones():
-    """Every variable the library reads is a route selector named in INTEGRATION.md and forced by tests/test_gpu_routes.py (or a
-    threshold named there); nothing undocumented changes what the library computes with."""
+def test_library_reads_no_environment_variable_and_options_are_documented():
+    """Round 6: the route selectors are sylow_hip_set_option values, not getenv switches behind the ABI.  The C++ / HIP sources read no
+    environment variable at all; the Python host layer maps SYLOW_HIP_<NAME> onto the options when it loads the library, and every option is
+    named in the header, in INTEGRATION.md and forced (or moved) by tests/test_gpu_routes.py."""
     import glob
-    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    read = set()
     for f in glob.glob(os.path.join(root, "sylow_amd", "csrc", "*.h*")):
-        src = open(f).read()
-        read |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', src)) | set(re.findall(r'env_size\("([A-Z0-9_]+)"\)', src))
-    assert read == {"SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER",
-                    "SYLOW_HIP_SIGN_WIDE_MAX", "SYLOW_HIP_WIDE_MAX", "SYLOW_HIP_WIDE_VERIFY_MAX"}
+        src = re.sub(r"//[^\n]*", " ", open(f).read())
+        assert "getenv" not in src and "environ" not in src, f
+    from sylow_amd import _lib
+    hdr = open(os.path.join(root, "include", "sylow_hip.h")).read()
+    defs = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"#define SYLOW_HIP_OPT_([A-Z_]+) (\d+)", hdr))
+    count = defs.pop("COUNT")
+    assert defs == _lib.OPTIONS and sorted(defs.values()) == list(range(count))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     routes = open(os.path.join(root, "tests", "test_gpu_routes.py")).read()
-    for name in read:
-        assert name in doc, name
-        assert name in routes, name
+    for name in defs:
+        assert "SYLOW_HIP_" + name in doc, name
+        assert "SYLOW_HIP_" + name in routes, name
+
+
+def test_options_round_trip_without_a_gpu():
+    import ctypes
+
+    import sylow_amd
+    from sylow_amd import _lib
+    lib = sylow_amd.load()
+    v = ctypes.c_int64(7)
+    for name, opt in _lib.OPTIONS.items():
+        assert lib.sylow_hip_get_option(opt, ctypes.byref(v)) == 0
+        before = v.value
+        assert lib.sylow_hip_set_option(opt, 12345) == 0
+        assert lib.sylow_hip_get_option(opt, ctypes.byref(v)) == 0 and v.value == 12345
+        assert lib.sylow_hip_set_option(opt, 0) == 0
+        assert lib.sylow_hip_get_option(opt, ctypes.byref(v)) == 0 and v.value == 0
+        assert lib.sylow_hip_set_option(opt, before) == 0                      # -1 (default) unless the environment set it
+        assert lib.sylow_hip_get_option(opt, ctypes.byref(v)) == 0 and v.value == before
+    assert lib.sylow_hip_set_option(len(_lib.OPTIONS), 1) == -2 and lib.sylow_hip_set_option(-1, 1) == -2
+    assert lib.sylow_hip_get_option(0, None) == -2
+    assert lib.sylow_hip_clock_probe(None) == 0                                # switching the probe off needs no device

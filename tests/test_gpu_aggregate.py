@@ -221,3 +221,51 @@ def test_weighted_batch_verification_vs_oracle(engine, coracle):
     _, ok_plain = engine.bls_aggregate_verify(pk[:1], msgs, perm)
     _, ok_w = engine.bls_batch_verify_weighted(pk[:1], msgs, perm, limbs([3 + 2 * i for i in range(n)]))
     assert ok_plain and not ok_w
+
+
+def test_fallback_path_and_collectives_in_one_process(engine, pairs):
+    """The staggered launch's recompute fallback (STAGGER option 2: the parking blocks' flags muted) and the RCCL aggregates in ONE process,
+    at the smallest skewed size (2^17): bls_verify_batch under the muted skew -> sylow_hip_all_valid over a real one-rank ncclComm_t (one wrong
+    signature planted inside the parked range flips it), and pairing_product_all of 2^17 pairs on the same communicator equals the local product."""
+    lib = _rccl()
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert lib.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    n, d = 1 << 17, 64
+    prev = engine.get_option("STAGGER")
+    try:
+        engine.set_option("STAGGER", 2)
+        pk64, msgs64, sig64 = signed_batch(engine, d, same_signer=False, seed=SEED + 93)
+        idx = np.arange(n) % d
+        dpk, dsig = engine.to_device_soa(pk64[idx], 16), engine.to_device_soa(sig64[idx], 8)
+        blob = b"".join(msgs64[i] for i in idx)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(msgs64[i]) for i in idx])
+        dm, doff = engine.to_device(np.frombuffer(blob, dtype=np.uint8)), engine.to_device(off)
+        ok = engine.empty((n,), np.uint8)
+        engine._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n)
+        assert engine.all_valid(ok, comm=comm.value) == 1 and ok.download().all()
+        bad = sig64[idx].copy()
+        bad[40000] = sig64[(idx[40000] + 1) % d]                       # element 40000 lies in a parked chunk (32768 .. 65535)
+        dbad = engine.to_device_soa(bad, 8)
+        engine._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dbad.ptr, None, ok.ptr, n)
+        flags = ok.download()
+        assert engine.all_valid(ok, comm=comm.value) == 0 and flags.sum() == n - 1 and flags[40000] == 0
+        p, q = pairs
+        m = p.shape[0]
+        pidx = np.arange(n) % m
+        gt_c, one_c = engine.pairing_product_all(p[pidx], q[pidx], comm=comm.value)
+        gt_l, one_l = engine.pairing_product(p[pidx], q[pidx])
+        assert np.array_equal(gt_c, gt_l) and one_c == one_l
+    finally:
+        engine.set_option("STAGGER", prev)
+        engine.sync()
+        lib.ncclCommDestroy(comm)

@@ -113,6 +113,15 @@ def test_c5_ecpairing_2_16_jobs(engine, coracle, k):
     g = np.random.default_rng(109 + k)
     a = [int(x) for x in g.integers(1, 1 << 62, size=n)]
     b = [int(x) for x in g.integers(1, 1 << 62, size=n)]
+    # SURVEY d1 states uniform scalars: the 128 jobs sampled against the oracle below (and every 97th job besides) take scalars drawn from the
+    # full range [1, r) -- the 62-bit draws of the other jobs only keep the host-side set-up of 2^16 k big-integer products short
+    jidx = np.sort(np.random.default_rng(6 + k).choice(nj, 128, replace=False))
+    full = sorted(set(jidx.tolist()) | set(range(0, nj, 97)))
+    wide = np.random.default_rng(77 + k)
+    for j in full:
+        for i in range(k):
+            a[j * k + i] = 1 + int.from_bytes(wide.bytes(32), "big") % (R_ORDER - 1)
+            b[j * k + i] = 1 + int.from_bytes(wide.bytes(32), "big") % (R_ORDER - 1)
     # make each job multiply to one: last b chosen so that sum a_i b_i = 0 mod r; spoil every 5th job
     for j in range(nj):
         s = sum(a[j * k + i] * b[j * k + i] for i in range(k - 1)) % R_ORDER
@@ -126,8 +135,8 @@ def test_c5_ecpairing_2_16_jobs(engine, coracle, k):
     assert np.array_equal(is_one, expect)
     # 128 PRNG-chosen jobs of the full-size launch against the oracle's glued_pairing (pairing.rs:1029-1037), Gt values bit for bit
     # (about a fifth of them are the spoiled jobs, whose value is not one)
-    jidx = np.sort(np.random.default_rng(6 + k).choice(nj, 128, replace=False))
     rows = (jidx[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+    assert sum(a[r] >> 250 for r in rows) > 0 and sum(b[r] >> 250 for r in rows) > 0      # the sampled jobs carry full-range scalars
     one4 = np.zeros((rows.size, 4), dtype=np.uint64); one4[:, 0] = 1
     p_proj = np.concatenate([p[rows], one4], axis=1)
     q_proj = np.concatenate([q[rows], one4, np.zeros((rows.size, 4), dtype=np.uint64)], axis=1)

@@ -299,3 +299,28 @@ def test_g1_generator_mul_fixed_base_table(engine, coracle):
     one = np.zeros((32, 4), dtype=np.uint64); one[:, 0] = 1
     exp, _ = coracle.g1_to_affine(coracle.g1_scalar_mul(np.concatenate([np.repeat(pack([1, 2], 8), 32, 0), one], axis=1), limbs(ks[:32])))
     assert np.array_equal(got[:32][~got_inf[:32].astype(bool)], exp[~got_inf[:32].astype(bool)])
+
+
+def test_g1_double_direct_vs_oracle(engine, coracle):
+    """sylow_hip_g1_double_batch against the oracle's `double` (group.rs:339-386 through g1.rs) row by row -- random points, the generator,
+    its negative, the identity (flagged, and as the canonical (0, 1)), a ragged size -- and against add(P, P): E(Fp) has no 2-torsion
+    (r is odd), so no finite input doubles to the identity."""
+    rng = Xoshiro(SEED + 31)
+    n = 131
+    pts, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), n, 0), limbs([rng.fp() for _ in range(n)]))
+    pts[0] = pack(G1, 8)[0]
+    pts[1] = pack([1, P - 2], 8)[0]
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[2, 64, n - 1]] = 1
+    pts[2] = pack([0, 1], 8)[0]                                         # the canonical encoding of the identity, flagged
+    got_xy, got_inf = engine.g1_double(pts, inf)
+    one = np.zeros((n, 4), dtype=np.uint64); one[:, 0] = 1
+    proj = np.concatenate([pts, one], axis=1)
+    proj[inf.astype(bool)] = np.concatenate([pack([0, 1], 8)[0], np.zeros(4, dtype=np.uint64)])       # (0, 1, 0)
+    exp_xy, exp_inf = coracle.g1_to_affine(coracle.g1_double(proj))
+    assert np.array_equal(got_inf, exp_inf) and np.array_equal(got_inf, inf)
+    assert np.array_equal(got_xy, exp_xy)
+    add_xy, add_inf = engine.g1_add(pts, pts, inf, inf)
+    fin = ~inf.astype(bool)
+    assert np.array_equal(add_xy[fin], got_xy[fin]) and np.array_equal(add_inf, got_inf)
+    assert not got_inf[fin].any()                                      # 2-torsion-free

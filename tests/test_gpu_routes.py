@@ -1,4 +1,5 @@
-"""Every route switch the library still has, forced over the pairing / verification / multi-pairing test files in a child run -- the
+"""Every route option the library has (sylow_hip_set_option; the Python layer maps the SYLOW_HIP_<NAME> variables below onto it when it loads
+the library -- the library itself reads no environment variable), forced over the pairing / verification / multi-pairing test files in a child run -- the
 default build picks by batch size, so no single plain run covers every route for every shape:
   SYLOW_HIP_MULTI_TABLES=0   in-register shared-squaring schedule for every multi-pair job (default: by the batch's average job size)
   SYLOW_HIP_MULTI_TABLES=1   lines-to-HBM + table-driven loop for every job, one-pair jobs included
@@ -14,7 +15,7 @@ default build picks by batch size, so no single plain run covers every route for
   SYLOW_HIP_STAGGER=2        the skewed launch with the parking blocks' flags muted: every finishing block waits out its bound and
                              recomputes its chunk (the fallback that makes the skew independent of dispatch order); the every-row
                              test of the skewed launch is added to the files for this switch
-(sylow_amd/csrc/plk_multi.hip; besides these the library reads only SYLOW_HIP_SIGN_WIDE_MAX, the signing threshold, in sign.hip.)"""
+(sylow_amd/csrc/plk_multi.hip; besides these there is only SYLOW_HIP_SIGN_WIDE_MAX, the signing threshold, consumed in sign.hip.)"""
 import os
 import subprocess
 import sys
@@ -37,7 +38,8 @@ def test_forced_route_passes_the_same_tests(route):
         pytest.skip("already inside a forced-route run")
     env = dict(os.environ, **route)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--deselect",
-                        "tests/test_gpu_aggregate.py::test_rccl_entry_points_one_rank_communicator"] + FILES
+                        "tests/test_gpu_aggregate.py::test_rccl_entry_points_one_rank_communicator", "--deselect",
+                        "tests/test_gpu_aggregate.py::test_fallback_path_and_collectives_in_one_process"] + FILES
                        + (["tests/test_gpu_full_size.py::test_c3_pairings_2_18_bilinearity", "tests/test_gpu_full_size.py::test_staggered_launch_every_row"]
                           if "SYLOW_HIP_STAGGER" in route else []),
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)

@@ -237,3 +237,52 @@ def test_scratch_limit_bounds_the_line_tables_and_keeps_results(engine, coracle)
                                 np.arange(25, dtype=np.uint64) * np.uint64(k))
     assert np.array_equal(gt1[idx], exp)
     engine.trim(0)
+
+
+def test_options_and_clock_probe_on_the_metric_kernels(engine, coracle):
+    """Round 6: the route selectors are ABI options (sylow_hip_set_option), and the metric's kernels carry a live clock probe
+    (sylow_hip_clock_probe).  One batch of 2^17 + 77 pairings under STAGGER = 0 / 1 / 2 gives identical Gt values (2: every finishing
+    block takes its recompute fallback); with the probe armed the wavefront count is the launch's, the sustained clock is a plausible
+    engine clock, the results do not change, and a disarmed probe leaves the accumulator alone."""
+    n, d = (1 << 17) + 77, 32
+    rng = np.random.default_rng(616)
+    a = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    b = limbs([int(x) for x in rng.integers(1, 1 << 62, size=d)])
+    p32, _ = engine.g1_scalar_mul(np.repeat(pack(G1, 8), d, 0), a)
+    q32, _ = engine.g2_scalar_mul(np.repeat(pack(G2, 16), d, 0), b)
+    one4 = np.zeros((d, 4), dtype=np.uint64); one4[:, 0] = 1
+    gt32 = coracle.pairing(np.concatenate([p32, one4], axis=1), np.concatenate([q32, one4, np.zeros((d, 4), dtype=np.uint64)], axis=1))
+    idx = np.arange(n) % d
+    dp, dq, dg = engine.to_device_soa(p32[idx], 8), engine.to_device_soa(q32[idx], 16), engine.empty((48, n))
+    prev = engine.get_option("STAGGER")
+    acc = engine.empty((256,)).upload(np.zeros(256, dtype=np.uint64))
+    khz = engine.wall_clock_khz()
+    assert 1000 <= khz <= 1000000
+    try:
+        outs = {}
+        for mode in (0, 1, 2):
+            engine.set_option("STAGGER", mode)
+            assert engine.get_option("STAGGER") == mode
+            if mode == 1:
+                engine.clock_probe(acc)
+            engine._call("sylow_hip_pairing_batch", dp.ptr, None, dq.ptr, None, dg.ptr, n)
+            engine.sync()
+            if mode == 1:
+                engine.clock_probe(None)
+            outs[mode] = engine.from_device_soa(dg)
+        assert np.array_equal(outs[0], gt32[idx])
+        assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0])
+        words = acc.download()
+        mhz, ticks, waves, longest_ms = engine.clock_probe_summary(words, khz)
+        blocks = (2 * n + 255) // 256
+        cus = (waves // 4 - blocks)                                  # the skewed launch adds one finishing block per parked block
+        assert waves % 4 == 0 and cus in (0, 128, 256, 304, 512), (waves, blocks)
+        assert 500.0 < mhz < 3500.0, mhz
+        assert 0.5 < longest_ms < 200.0, longest_ms
+        # disarmed: another launch adds nothing
+        engine._call("sylow_hip_pairing_batch", dp.ptr, None, dq.ptr, None, dg.ptr, n)
+        engine.sync()
+        assert np.array_equal(acc.download(), words)
+    finally:
+        engine.clock_probe(None)
+        engine.set_option("STAGGER", prev)

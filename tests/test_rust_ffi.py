@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-C2RUST = {"int32_t": "i32", "uint64_t": "u64", "size_t": "usize", "uint8_t": "u8", "char": "c_char", "void": "c_void"}
+C2RUST = {"int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "size_t": "usize", "uint8_t": "u8", "char": "c_char", "void": "c_void"}
 
 
 def parse_header():

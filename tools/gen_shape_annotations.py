@@ -98,6 +98,9 @@ S["bls_verify_line_table_batch"] = "pk_table=i32[*] pk_inf=u8[1]? " + MSG + " si
 S["evm_ecadd_batch"] = "in=u8[128*n] out=u8[64*n] status=u8[n]"
 S["evm_ecmul_batch"] = "in=u8[96*n] out=u8[64*n] status=u8[n]"
 S["evm_ecpairing_batch"] = "in=u8[192*n_pairs]? pair_offsets=u64[n_jobs+1] result=u8[n_jobs] status=u8[n_jobs]"
+S["get_option"] = "value_host=i64[1]"
+S["clock_probe"] = "acc=u64[256]?"
+S["wall_clock_khz"] = "khz_host=i32[1]"
 S["flags_all"] = "flags=u8[n] out_dev=i32[1]"
 S["all_valid"] = "flags=u8[n] comm=void[*]? out_dev=i32[1]"
 AGG = "pk_xy=u64[16*n_pk] pk_inf=u8[n_pk]? " + MSG + " sig_xy=u64[8*n] sig_inf=u8[n]?"

@@ -91,7 +91,8 @@ def main():
                           "ms_per_launch_kernel_sum": ksum / c["reps"] / 1e6, "ms_per_launch_span": span / c["reps"] / 1e6,
                           "kernels": {name: {"calls_per_launch": e["calls"] / c["reps"], "ms_per_launch": e["ns"] / c["reps"] / 1e6} for name, e in k.items()}}
     # counters
-    for pas in ("mix", "stall", "fetch", "write"):
+    passes = sorted(d for d in os.listdir(out_dir) if d != "trace" and os.path.isdir(os.path.join(out_dir, d)))     # mix, stall, fetch, write (+ the residue groups of prof_residue.sh)
+    for pas in passes:
         files = glob.glob(os.path.join(out_dir, pas, "**", "p_counter_collection.csv"), recursive=True)
         if not files:
             continue
