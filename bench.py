@@ -334,7 +334,8 @@ def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n, sk_h=None)
     inputs re-packed to each size's stride outside the clock): where single ecPairing calls, Groth16-size batches and the metric's
     2^20 sit on the same curve (examples/reth_bn128.rs:156-217)."""
     rows = []
-    for m in (1, 64, 1 << 10, 1 << 11, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+    # 8192 / 16384: the lane-quad route (plk_quad.hip, round 6); 32768: one wavefront per SIMD of lane pairs; 65536: one full round
+    for m in (1, 64, 1 << 10, 1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 18, 1 << 20):
         if m > n:
             break
         reps = 20 if m <= (1 << 12) else 5 if m <= (1 << 16) else 3
@@ -345,7 +346,7 @@ def size_sweep(eng, torch, stream, p_h, q_h, pk_h, sig_h, dm, off, n, sk_h=None)
         tv = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_verify_batch", pkm.ptr, None, dm.ptr, offm.ptr, sgm.ptr, None, okm.ptr, m), reps)
         rows.append({"n": m, "pairing_ms": tp * 1e3, "pairing_us_per_element": tp * 1e6 / m, "pairings_per_s": m / tp,
                      "verify_ms": tv * 1e3, "verify_us_per_element": tv * 1e6 / m, "verifies_per_s": m / tv, "verify_all_ok": int(okm.download().all()), "reps": reps})
-        if sk_h is not None:                              # sign (lib.rs:179-187): n <= 8192 on eight lanes per signature (sign_wide.hip), one lane above
+        if sk_h is not None:                              # sign (lib.rs:179-187): n <= 16384 on eight lanes per signature (sign_wide.hip), one lane above
             skm, so, soi = eng.empty((4, m)).upload(np.ascontiguousarray(sk_h[:, :m])), eng.empty((8, m)), eng.empty((m,), np.uint8)
             ts = hip_timed(torch, stream, lambda: eng._call("sylow_hip_bls_sign_batch", skm.ptr, dm.ptr, offm.ptr, so.ptr, soi.ptr, m), reps)
             rows[-1].update({"sign_ms": ts * 1e3, "sign_us_per_element": ts * 1e6 / m, "signs_per_s": m / ts,

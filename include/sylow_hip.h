@@ -91,7 +91,9 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
  *   AGG_FORK         1 (default) the aggregate verifiers fork the signature half onto a side stream, 0 one stream
  *   SIGN_WIDE_MAX    largest batch signed / hashed / multiplied on eight lanes per element (default 16384)
  *   WIDE_MAX         largest batch of pairings on the one-wavefront route (default 6144)
- *   WIDE_VERIFY_MAX  largest batch of verifications on it (default 4096) */
+ *   WIDE_VERIFY_MAX  largest batch of verifications on it (default 4096)
+ *   QUAD_MAX         largest batch of pairings / Miller loops / final exponentiations / verifications on one lane QUAD per element
+ *                    (plk_quad.hip; default: 64 x the CU count = 16384, one wavefront per SIMD; 0 never) */
 #define SYLOW_HIP_OPT_STAGGER 0
 #define SYLOW_HIP_OPT_MULTI_TABLES 1
 #define SYLOW_HIP_OPT_WIDE_TAIL 2
@@ -100,7 +102,8 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
 #define SYLOW_HIP_OPT_SIGN_WIDE_MAX 5
 #define SYLOW_HIP_OPT_WIDE_MAX 6
 #define SYLOW_HIP_OPT_WIDE_VERIFY_MAX 7
-#define SYLOW_HIP_OPT_COUNT 8
+#define SYLOW_HIP_OPT_QUAD_MAX 8
+#define SYLOW_HIP_OPT_COUNT 9
 int32_t sylow_hip_set_option(int32_t option, int64_t value);
 /* @shape value_host=i64[1] */
 int32_t sylow_hip_get_option(int32_t option, int64_t* value_host);      /* HOST pointer; -1 = the default is in force */

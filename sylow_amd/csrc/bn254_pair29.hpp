@@ -128,6 +128,66 @@ BN_DEV W2 w2_mul_ilp(const W2& a, const W2& b) { return W2{w2_mul_ilp_leaf(W_ARG
 BN_DEV W2 w2_sqr(const W2& a) { return W2{w2_sqr_leaf(W_ARGS(a.c))}; }
 BN_DEV W2 w2_scale(const W2& a, const F29& k) { return W2{f29_mul_leaf(W_ARGS(a.c), W_ARGS(k))}; }
 
+// ---- leaf PAIRS: two INDEPENDENT leaves named in one call (round 6) -------------------------------------------------------------------
+// Every routine below names its product leaves two at a time where two are independent.  On lane pairs (the default build: BN_QUAD 0) the
+// pair is evaluated one leaf after the other -- the same calls in the same order as before.  A translation unit compiled with BN_QUAD 1
+// (plk_quad.hip: batches too small to fill the chip with one lane pair per element) gives every element a QUAD of lanes -- two lane pairs
+// that hold the SAME state (replicated: same code, same inputs, hence the same digits) -- and splits each leaf pair between them: sub-pair 0
+// forms the first leaf, sub-pair 1 the second, one DPP exchange (quad_perm [1,0,3,2]: lanes 0 <-> 1 and 6 <-> 7 of a group of eight are
+// the c0 / c1 lanes of the two sub-pairs of one element, 2 <-> 3 and 4 <-> 5 those of the other) hands each the other's result:
+// 18 selects + one leaf + 9 exchanges + 18 selects instead of two leaves.  The linear layer is replicated.  Same formulas, same operand
+// classes, same integers into every Montgomery reduction: the quad build's values are digit for digit the lane-pair build's.
+#ifndef BN_QUAD
+#define BN_QUAD 0
+#endif
+#if BN_QUAD
+// geometry of a quad (bn254_pair.hpp: lane l and 7 - l of a group of eight are partners; pairs 0 / 1 form one element, pairs 2 / 3 the other)
+template <class T> BN_DEV int quad_pair(T t) { return (int)((t & 3) ^ (((t >> 2) & 1) ? 3 : 0)); }      // 0..3: the lane pair inside the group of eight
+template <class T> BN_DEV T quad_index(T t) { return (T)(((t >> 3) << 1) | (T)(quad_pair(t) >> 1)); }   // element of thread t: 16 per wavefront
+template <class T> BN_DEV int quad_sub(T t) { return quad_pair(t) & 1; }                                // which of the element's two lane pairs
+BN_DEV bool quad_sub1() { return quad_sub(__lane_id()) != 0; }
+BN_DEV F29 quad_xchg9(const F29& a) {                                   // the other sub-pair's lane of the same role
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = __builtin_amdgcn_mov_dpp(a.v[i], 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  return r;
+}
+BN_DEV void quad_share(W2& r0, W2& r1, const F29& mine) {              // mine = leaf 0 on sub-pair 0, leaf 1 on sub-pair 1
+  const bool s = quad_sub1();
+  const F29 other = quad_xchg9(mine);
+  r0 = W2{sel9(s, mine, other)};
+  r1 = W2{sel9(s, other, mine)};
+}
+#endif
+// On lane pairs the pair forms are MACROS that expand to the two original statements, operand expressions included: an inline function would
+// evaluate the second leaf's operands before the first call and keep them live across it (measured on the ISA: +9 % moves in the Miller loop).
+#if BN_QUAD
+BN_DEV void w2_mul2(W2& r0, W2& r1, const W2& a0, const W2& b0, const W2& a1, const W2& b1) {
+  const bool s = quad_sub1();
+  quad_share(r0, r1, w2_mul(W2{sel9(s, a0.c, a1.c)}, W2{sel9(s, b0.c, b1.c)}).c);
+}
+BN_DEV void w2_sqr2(W2& r0, W2& r1, const W2& a0, const W2& a1) { quad_share(r0, r1, w2_sqr(W2{sel9(quad_sub1(), a0.c, a1.c)}).c); }
+BN_DEV void w2_scale2(W2& r0, W2& r1, const W2& a0, const F29& k0, const W2& a1, const F29& k1) {
+  const bool s = quad_sub1();
+  quad_share(r0, r1, w2_scale(W2{sel9(s, a0.c, a1.c)}, sel9(s, k0, k1)).c);
+}
+#define W2_MUL2(r0, r1, a0, b0, a1, b1) w2_mul2(r0, r1, a0, b0, a1, b1)
+#define W2_MUL2_SEL(INL, r0, r1, a0, b0, a1, b1) w2_mul2(r0, r1, a0, b0, a1, b1)
+#define W2_SQR2(r0, r1, a0, a1) w2_sqr2(r0, r1, a0, a1)
+// a product and a square: the square goes through the product leaf as a * a -- the same integer into the same reduction
+// ((a0 + a1)(a0 - a1) = a0^2 - a1^2 and a0 * 2 a1 = a1 a0 + a0 a1 exactly), so the digits are those of the squaring leaf
+#define W2_MUL_SQR(r0, r1, a0, b0, a1) do { const W2 sq_ = (a1); w2_mul2(r0, r1, a0, b0, sq_, sq_); } while (0)
+#define W2_SQR_MUL(r0, r1, a0, a1, b1) do { const W2 sq_ = (a0); w2_mul2(r0, r1, sq_, sq_, a1, b1); } while (0)
+#define W2_SCALE2(r0, r1, a0, k0, a1, k1) w2_scale2(r0, r1, a0, k0, a1, k1)
+#else
+#define W2_MUL2(r0, r1, a0, b0, a1, b1) do { (r0) = w2_mul(a0, b0); (r1) = w2_mul(a1, b1); } while (0)
+#define W2_MUL2_SEL(INL, r0, r1, a0, b0, a1, b1) do { (r0) = w2_mul_sel<INL>(a0, b0); (r1) = w2_mul_sel<INL>(a1, b1); } while (0)
+#define W2_SQR2(r0, r1, a0, a1) do { (r0) = w2_sqr(a0); (r1) = w2_sqr(a1); } while (0)
+#define W2_MUL_SQR(r0, r1, a0, b0, a1) do { (r0) = w2_mul(a0, b0); (r1) = w2_sqr(a1); } while (0)
+#define W2_SQR_MUL(r0, r1, a0, a1, b1) do { (r0) = w2_sqr(a0); (r1) = w2_mul(a1, b1); } while (0)
+#define W2_SCALE2(r0, r1, a0, k0, a1, k1) do { (r0) = w2_scale(a0, k0); (r1) = w2_scale(a1, k1); } while (0)
+#endif
+
 // ---- lazy linear layer ------------------------------------------------------------------------------------------------
 BN_DEV W2 w2_add(const W2& a, const W2& b) { return W2{f29_add(a.c, b.c)}; }
 BN_DEV W2 w2_sub(const W2& a, const W2& b) { return W2{f29_sub(a.c, b.c)}; }
@@ -174,12 +234,10 @@ struct W6Raw { W2 v0, x0, y1, v2, y2; };
 template <bool INL = false> BN_DEV W2 w2_mul_sel(const W2& a, const W2& b) { return INL ? w2_mul_inl(a, b) : w2_mul(a, b); }
 template <bool INL = false>
 BN_DEV W6Raw w6_mul_raw(const W6& a, const W6& b) {
-  const W2 v0 = w2_mul_sel<INL>(a.c0, b.c0);
-  const W2 v1 = w2_mul_sel<INL>(a.c1, b.c1);
-  const W2 v2 = w2_mul_sel<INL>(a.c2, b.c2);
-  const W2 s0 = w2_mul_sel<INL>(w2_sub(a.c1, a.c2), w2_sub(b.c1, b.c2));
-  const W2 s1 = w2_mul_sel<INL>(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
-  const W2 s2 = w2_mul_sel<INL>(w2_sub(a.c0, a.c2), w2_sub(b.c0, b.c2));
+  W2 v0, v1, v2, s0, s1, s2;
+  W2_MUL2_SEL(INL, v0, v1, a.c0, b.c0, a.c1, b.c1);
+  W2_MUL2_SEL(INL, v2, s0, a.c2, b.c2, w2_sub(a.c1, a.c2), w2_sub(b.c1, b.c2));
+  W2_MUL2_SEL(INL, s1, s2, w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1), w2_sub(a.c0, a.c2), w2_sub(b.c0, b.c2));
   return W6Raw{v0, w2_sub(w2_add(v1, v2), s0), w2_sub(w2_add(v0, v1), s1), v2, w2_add(w2_sub(w2_add(v0, v2), s2), v1)};
 }
 template <bool INL = false>
@@ -220,10 +278,9 @@ BN_DEV W12 w12_mul(const W12& a, const W12& b) {
 BN_DEV W6 w6_mul_b2zero(const W6& a, const W6& b) {
   // (a0 + a1 v + a2 v^2)(b0 + b1 v): v^0: a0 b0 + xi a2 b1, v^1: a0 b1 + a1 b0, v^2: a1 b1 + a2 b0 -- the two products with a2 directly, the
   // cross term by subtractive Karatsuba (a0 - a1)(b0 - b1): five products, no carry-normalised pre-additions.  Operands R / N.
-  const W2 v0 = w2_mul(a.c0, b.c0);
-  const W2 v1 = w2_mul(a.c1, b.c1);
-  const W2 p21 = w2_mul(a.c2, b.c1);
-  const W2 p20 = w2_mul(a.c2, b.c0);
+  W2 v0, v1, p21, p20;
+  W2_MUL2(v0, v1, a.c0, b.c0, a.c1, b.c1);
+  W2_MUL2(p21, p20, a.c2, b.c1, a.c2, b.c0);
   const W2 s1 = w2_mul(w2_sub(a.c0, a.c1), w2_sub(b.c0, b.c1));
   W6 r;
   r.c0 = w2_xi_lin(p21, 1, v0, 1);                                       // v0 + xi a2 b1
@@ -286,8 +343,7 @@ BN_DEV W6 w6_frobenius(const W6& a) {
   const uint32_t (&k2)[2][8] = (E == 1) ? C_FROB6_C2_1 : (E == 2) ? C_FROB6_C2_2 : C_FROB6_C2_3;
   W6 r;
   r.c0 = oddE ? w2_conj(a.c0) : a.c0;
-  r.c1 = w2_mul(oddE ? w2_conj(a.c1) : a.c1, w2_const(k1));
-  r.c2 = w2_mul(oddE ? w2_conj(a.c2) : a.c2, w2_const(k2));
+  W2_MUL2(r.c1, r.c2, oddE ? w2_conj(a.c1) : a.c1, w2_const(k1), oddE ? w2_conj(a.c2) : a.c2, w2_const(k2));
   return r;
 }
 template <int E>
@@ -295,20 +351,22 @@ BN_DEV W12 w12_frobenius(const W12& a) {
   const uint32_t (&k)[2][8] = (E == 1) ? C_FROB12_C1_1 : (E == 2) ? C_FROB12_C1_2 : C_FROB12_C1_3;
   const W2 kk = w2_const(k);
   const W6 x1 = w6_frobenius<E>(a.c1);
-  return W12{w6_frobenius<E>(a.c0), W6{w2_mul(x1.c0, kk), w2_mul(x1.c1, kk), w2_mul(x1.c2, kk)}};
+  W6 y;
+  W2_MUL2(y.c0, y.c1, x1.c0, kk, x1.c1, kk);
+  y.c2 = w2_mul(x1.c2, kk);
+  return W12{w6_frobenius<E>(a.c0), y};
 }
 // fp12.rs:426-503 (mul_by_024): x0 = ell_0, x2 = ell_vv, x4 = ell_vw, all R / N.  f R / N.  Output R.
 BN_DEV W12 w12_sparse_mul(const W12& f, const W2& x0, const W2& x4, const W2& x2) {
   const W2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
-  const W2 d0 = w2_mul(z0, x0);
-  const W2 d2 = w2_mul(z2, x2);
-  const W2 d4 = w2_mul(z4, x4);
-  const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p10 = w2_mul(z1, x0);
-  const W2 p34 = w2_mul(z3, x4), p30 = w2_mul(z3, x0), p52 = w2_mul(z5, x2);
+  W2 d0, d2, d4, p12, p54, p10, p34, p30, p52, q02, q24, q04;
+  W2_MUL2(d0, d2, z0, x0, z2, x2);
+  W2_MUL2(d4, p12, z4, x4, z1, x2);
+  W2_MUL2(p54, p10, z5, x4, z1, x0);
+  W2_MUL2(p34, p30, z3, x4, z3, x0);
   // the three cross sums z_i x_j + z_j x_i by subtractive Karatsuba: d_i + d_j - (z_i - z_j)(x_i - x_j), differences lazy (D-class operands)
-  const W2 q02 = w2_mul(w2_sub(z0, z2), w2_sub(x0, x2));
-  const W2 q24 = w2_mul(w2_sub(z2, z4), w2_sub(x2, x4));
-  const W2 q04 = w2_mul(w2_sub(z0, z4), w2_sub(x0, x4));
+  W2_MUL2(p52, q02, z5, x2, w2_sub(z0, z2), w2_sub(x0, x2));
+  W2_MUL2(q24, q04, w2_sub(z2, z4), w2_sub(x2, x4), w2_sub(z0, z4), w2_sub(x0, x4));
   const W2 qs = w2_mul(w2_norm(w2_add(w2_add(z1, z3), z5)), w2_norm(w2_add(w2_add(x0, x2), x4)));
   W12 o;
   o.c0.c0 = w2_xi_lin(w2_add(p12, d4), 1, d0, 1);                                            // xi (z1 x2 + d4) + d0
@@ -339,12 +397,13 @@ BN_DEV W2 w2_lin_v(const W2& x, const W2& y, i32 m) {                   // reduc
 }
 BN_DEV W12 w12_sparse_mul_unit(const W12& f, i32 u, const W2& x4, const W2& x2) {
   const W2 z0 = f.c0.c0, z1 = f.c0.c1, z2 = f.c0.c2, z3 = f.c1.c0, z4 = f.c1.c1, z5 = f.c1.c2;
-  const W2 d2 = w2_mul(z2, x2), d4 = w2_mul(z4, x4);
-  const W2 p12 = w2_mul(z1, x2), p54 = w2_mul(z5, x4), p34 = w2_mul(z3, x4), p52 = w2_mul(z5, x2);
-  const W2 a02 = w2_mul(z0, x2), a04 = w2_mul(z0, x4);
+  W2 d2, d4, p12, p54, p34, p52, a02, a04, q24, q13;
+  W2_MUL2(d2, d4, z2, x2, z4, x4);
+  W2_MUL2(p12, p54, z1, x2, z5, x4);
+  W2_MUL2(p34, p52, z3, x4, z5, x2);
+  W2_MUL2(a02, a04, z0, x2, z0, x4);
   const W2 x24 = w2_sub(x2, x4);                                          // lazy difference (D-class): subtractive Karatsuba, see w6_mul_raw
-  const W2 q24 = w2_mul(w2_sub(z2, z4), x24);                             // d2 + d4 - (z2 x4 + z4 x2)
-  const W2 q13 = w2_mul(w2_sub(z1, z3), x24);                             // p12 + p34 - (z1 x4 + z3 x2)
+  W2_MUL2(q24, q13, w2_sub(z2, z4), x24, w2_sub(z1, z3), x24);            // d2 + d4 - (z2 x4 + z4 x2);  p12 + p34 - (z1 x4 + z3 x2)
   W12 o;
   o.c0.c0 = w2_xi_lin_v(w2_add(p12, d4), z0, u);                         // xi (z1 x2 + z4 x4) + u z0
   o.c0.c1 = w2_xi_lin_v(w2_add(p54, d2), z1, u);                         // xi (z5 x4 + z2 x2) + u z1
@@ -382,8 +441,8 @@ BN_DEV W2 w2_xi_norm_sub(const W2& x, const W2& y) {                  // norm(y 
 }
 template <bool INL = false>
 BN_DEV void w_fp4_square_fold(W2& out0, W2& m, const W2& a, const W2& b, const W2& z) {      // out0 = reduce(3 (a^2 + xi b^2) - 2 z), m = a b
-  m = INL ? w2_mul_inl(a, b) : w2_mul(a, b);
-  const W2 w = INL ? w2_mul_inl(w2_sub(a, b), w2_xi_norm_sub(b, a)) : w2_mul(w2_sub(a, b), w2_xi_norm_sub(b, a));
+  W2 w;
+  W2_MUL2_SEL(INL, m, w, a, b, w2_sub(a, b), w2_xi_norm_sub(b, a));
   const F29 mo = xchg9(m.c);
   const F29* const t[4] = {&w.c, &m.c, &mo, &z.c};
   const i32 c[4] = {bn_keep(3), bn_keep(30), bn_keep_v(lane_odd() ? 3 : -3), bn_keep(-2)};
@@ -453,6 +512,29 @@ BN_DEV W2 w2_mul_27m3u(const W2& a) {                                    // (a0 
 }
 template <bool ISO = false>
 BN_DEV void g2_doubling_step29(G2W& r, W2& l0, W2& l1, W2& l2) {
+#if BN_QUAD
+  // the nine (ten) leaves in five rounds: (X Y, X^2) (Y^2, Z^2) ((Y + Z)^2 [, b' 3c]) (b h, a (b - f)) (g^2, e^2)
+  W2 xy, xx, b, c, yz2, e;
+  W2_MUL_SQR(xy, xx, r.x, r.y, r.x);
+  const W2 a = w2_halve(xy);                                             // N
+  l2 = w2_norm(w2_triple(xx));                                           // 3 X^2, N, |V| < 3.4
+  W2_SQR2(b, c, r.y, r.z);
+  if (ISO) {
+    yz2 = w2_sqr(w2_norm(w2_add(r.y, r.z)));
+    e = w2_mul_27m3u(c);                                                 // E'': (9 - u) * 3c, N
+  } else {
+    W2_SQR_MUL(yz2, e, w2_norm(w2_add(r.y, r.z)), w2_twist_b(), w2_norm(w2_triple(c)));   // b' * 3c, N
+  }
+  const W2 h = w2_norm(w2_sub(yz2, w2_add(b, c)));                       // (Y+Z)^2 - (b+c), N, |V| < 3.4
+  l1 = w2_neg(h);                                                        // D
+  l0 = w2_xi_lin(w2_sub(e, b), 1, b, 0);                                 // xi (e - b), R
+  const W2 f = w2_norm(w2_triple(e));                                    // 3e, N, |V| < 3.4
+  W2_MUL2(r.z, r.x, b, h, a, w2_sub(b, f));                              // Z3 = b h;  X3 = a (b - f): D operand
+  const W2 g = w2_halve(w2_norm(w2_add(b, f)));                          // (b + f) / 2, N
+  W2 gg, ee;
+  W2_SQR2(gg, ee, g, e);
+  r.y = w2_lin2(gg, 1, ee, -3);                                          // g^2 - 3 e^2, R
+#else
   const W2 a = w2_halve(w2_mul(r.x, r.y));                              // N
   l2 = w2_norm(w2_triple(w2_sqr(r.x)));                                  // 3 X^2, N, |V| < 3.4
   const W2 b = w2_sqr(r.y);
@@ -466,9 +548,31 @@ BN_DEV void g2_doubling_step29(G2W& r, W2& l0, W2& l1, W2& l2) {
   r.x = w2_mul(a, w2_sub(b, f));                                         // a (b - f): D operand
   const W2 g = w2_halve(w2_norm(w2_add(b, f)));                          // (b + f) / 2, N
   r.y = w2_lin2(w2_sqr(g), 1, w2_sqr(e), -3);                            // g^2 - 3 e^2, R
+#endif
 }
 // pairing.rs:756-772, Q = (bx, by) affine, R-class.  Line coefficients: l0 R, l1 D, l2 D.
 BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l1, W2& l2) {
+#if BN_QUAD
+  // the thirteen leaves in seven rounds: (z bx, z by) (e bx, d by) (dn^2, en^2) (dn f, x f) (z e^2, z h) (dn j, h y) (en (i - j))
+  W2 zbx, zby, ebx, dby;
+  W2_MUL2(zbx, zby, r.z, bx, r.z, by);
+  const W2 d = w2_sub(r.x, zbx);                                         // D
+  const W2 e = w2_sub(r.y, zby);                                         // D
+  W2_MUL2(ebx, dby, e, bx, d, by);
+  l0 = w2_xi_lin(w2_sub(ebx, dby), 1, bx, 0);                            // xi (e bx - d by), R
+  l1 = d;
+  l2 = w2_neg(e);
+  const W2 dn = w2_norm(d), en = w2_norm(e);                             // N (squarings need non-negative limbs)
+  W2 f, ee, h, i, zee, zh, dj, hy;
+  W2_SQR2(f, ee, dn, en);
+  W2_MUL2(h, i, dn, f, r.x, f);
+  W2_MUL2(zee, zh, r.z, ee, r.z, h);
+  const W2 j = w2_norm(w2_sub(w2_add(zee, h), w2_add(i, i)));            // z e^2 + h - 2i, N, |V| < 5
+  W2_MUL2(dj, hy, dn, j, h, r.y);
+  r.z = zh;
+  r.x = dj;
+  r.y = w2_norm(w2_sub(w2_mul(en, w2_sub(i, j)), hy));                   // e (i - j) - h y, N
+#else
   const W2 d = w2_sub(r.x, w2_mul(r.z, bx));                             // D
   const W2 e = w2_sub(r.y, w2_mul(r.z, by));                             // D
   l0 = w2_xi_lin(w2_sub(w2_mul(e, bx), w2_mul(d, by)), 1, bx, 0);        // xi (e bx - d by), R
@@ -482,6 +586,7 @@ BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l
   r.z = w2_mul(r.z, h);
   r.x = w2_mul(dn, j);
   r.y = w2_norm(w2_sub(w2_mul(en, w2_sub(i, j)), w2_mul(h, r.y)));       // e (i - j) - h y, N
+#endif
 }
 // Product of two lines (a0 + a2 v^2 + a4 v w)(b0 + b2 v^2 + b4 v w) with v^3 = xi, w^2 = v:
 //   1: a0 b0 + xi a4 b4   v: xi a2 b2   v^2: a0 b2 + a2 b0   w: xi (a2 b4 + a4 b2)   v w: a0 b4 + a4 b0   v^2 w: 0
@@ -491,11 +596,11 @@ BN_DEV void g2_addition_step29(G2W& r, const W2& bx, const W2& by, W2& l0, W2& l
 // live Fp12 operands doubled the loop's stack frame (720 -> 1328 B per lane) and the spill waits cost more than 2 products save.
 // Inputs R / N, outputs R.
 BN_DEV W12 w12_line_product(const W2& a0, const W2& a4, const W2& a2, const W2& b0, const W2& b4, const W2& b2) {
-  const W2 d0 = w2_mul(a0, b0), d2 = w2_mul(a2, b2), d4 = w2_mul(a4, b4);
+  W2 d0, d2, d4, k02, k24, k04;
+  W2_MUL2(d0, d2, a0, b0, a2, b2);
   // a_i b_j + a_j b_i = d_i + d_j - (a_i - a_j)(b_i - b_j): lazy differences as operands (coefficients R / N)
-  const W2 k02 = w2_mul(w2_sub(a0, a2), w2_sub(b0, b2));
-  const W2 k24 = w2_mul(w2_sub(a2, a4), w2_sub(b2, b4));
-  const W2 k04 = w2_mul(w2_sub(a0, a4), w2_sub(b0, b4));
+  W2_MUL2(d4, k02, a4, b4, w2_sub(a0, a2), w2_sub(b0, b2));
+  W2_MUL2(k24, k04, w2_sub(a2, a4), w2_sub(b2, b4), w2_sub(a0, a4), w2_sub(b0, b4));
   W12 r;
   r.c0.c0 = w2_xi_lin(d4, 1, d0, 1);
   r.c0.c1 = w2_xi_lin(d2, 1, d2, 0);
@@ -544,7 +649,7 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   {
     W2 qx = w2_from_s2(qxs), qy = w2_from_s2(qys);
     if (ISO) {
-      qx = w2_scale(qx, f29_iso_s2()); qy = w2_scale(qy, f29_iso_s3());
+      W2_SCALE2(qx, qy, qx, f29_iso_s2(), qy, f29_iso_s3());
       qxs = w2_to_s2(qx); qys = w2_to_s2(qy);                                 // the two Frobenius images at the end start from phi Q
     }
     lds_put9(lds, 2, qx.c);
@@ -559,14 +664,22 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   W12 f;
   G2W r{QX(), QY(false), w2_from_s2(s2_one())};
   W2 l0, l1, l2;
+  auto line_mul = [&](const W12& x) {                                    // x * (l0 + l1 P.y (v w) + l2 P.x (v^2)): the two scalings are one leaf pair
+    W2 s1, s2;
+    W2_SCALE2(s1, s2, l1, PY(), l2, PX());
+    return w12_sparse_mul(x, l0, s1, s2);
+  };
   const u64 nz = BN_ATE_NAF_NZ, ng = BN_ATE_NAF_NEG;
   static_assert((BN_ATE_NAF_NZ >> 63) & 1, "the first digit of 6x+2 after the leading one is non-zero");
   {   // i = 0: f = 1, so f^2 * l_dbl * l_add is the product of the two lines
     g2_doubling_step29<ISO>(r, l0, l1, l2);
-    const W2 d0 = l0, d4 = w2_scale(l1, PY()), d2 = w2_scale(l2, PX());
+    const W2 d0 = l0;
+    W2 d4, d2, e4, e2;
+    W2_SCALE2(d4, d2, l1, PY(), l2, PX());
     g2_addition_step29(r, QX(), QY((ng >> 63) & 1), l0, l1, l2);
     park(r);
-    f = w12_line_product(d0, d4, d2, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
+    W2_SCALE2(e4, e2, l1, PY(), l2, PX());
+    f = w12_line_product(d0, d4, d2, l0, e4, e2);
   }
 #pragma unroll 1
   for (int i = 1; i < 64; ++i) {
@@ -574,12 +687,12 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
     g2_doubling_step29<ISO>(r, l0, l1, l2);
     park(r);
     f = w12_sqr<BN_MILLER_SQR_INL>(f);
-    f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
+    f = line_mul(f);
     if ((nz >> (63 - i)) & 1) {
       r = unpark(r);
       g2_addition_step29(r, QX(), QY((ng >> (63 - i)) & 1), l0, l1, l2);
       park(r);
-      f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
+      f = line_mul(f);
     }
   }
   r = unpark(r);
@@ -588,9 +701,9 @@ BN_NOINLINE void miller_loop29g(S12& fout, const Fp& pxs, const Fp& pys, const S
   g2_psi_affine(q2x, q2y, q1x, q1y);
   q2y = s2_neg(q2y);
   g2_addition_step29(r, w2_from_s2(q1x), w2_from_s2(q1y), l0, l1, l2);
-  f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
+  f = line_mul(f);
   g2_addition_step29(r, w2_from_s2(q2x), w2_from_s2(q2y), l0, l1, l2);
-  f = w12_sparse_mul(f, l0, w2_scale(l1, PY()), w2_scale(l2, PX()));
+  f = line_mul(f);
   w12_to_s12(fout, f);
 }
 
@@ -671,12 +784,18 @@ BN_DEV W2 w2_inv(const W2& a) {
 }
 BN_DEV W2 w2_mul_xi(const W2& a) { return w2_xi_lin(a, 1, a, 0); }     // R
 BN_DEV W6 w6_inv(const W6& a) {                                          // input R / N, output N
-  const W2 t0 = w2_sub(w2_sqr(a.c0), w2_mul(a.c1, w2_mul_xi(a.c2)));    // D-class differences of two N values: fine as product operands
-  const W2 t1 = w2_sub(w2_mul_xi(w2_sqr(a.c2)), w2_mul(a.c0, a.c1));
-  const W2 t2 = w2_sub(w2_sqr(a.c1), w2_mul(a.c0, a.c2));
-  const W2 d = w2_xi_lin(w2_add(w2_mul(a.c2, t1), w2_mul(a.c1, t2)), 1, w2_mul(a.c0, t0), 1);
+  W2 s0, m12, s2, m01, s1, m02, u1, u2, o0, o1;
+  W2_SQR_MUL(s0, m12, a.c0, a.c1, w2_mul_xi(a.c2));
+  W2_SQR_MUL(s2, m01, a.c2, a.c0, a.c1);
+  W2_SQR_MUL(s1, m02, a.c1, a.c0, a.c2);
+  const W2 t0 = w2_sub(s0, m12);                                         // D-class differences of two N values: fine as product operands
+  const W2 t1 = w2_sub(w2_mul_xi(s2), m01);
+  const W2 t2 = w2_sub(s1, m02);
+  W2_MUL2(u1, u2, a.c2, t1, a.c1, t2);
+  const W2 d = w2_xi_lin(w2_add(u1, u2), 1, w2_mul(a.c0, t0), 1);
   const W2 di = w2_inv(d);
-  return W6{w2_mul(di, t0), w2_mul(di, t1), w2_mul(di, t2)};
+  W2_MUL2(o0, o1, di, t0, di, t1);
+  return W6{o0, o1, w2_mul(di, t2)};
 }
 BN_NOINLINE void w12_inv_nl(W12& r, const W12& ain) {
   W12 a = ain;

@@ -2,6 +2,12 @@
 // hash-to-G1 (XMD-Keccak256 + SvdW), BLS signing, the G1 wire format and the EIP-196 ecAdd / ecMul byte adapters.
 #include "host.hpp"
 
+// An affine SoA point as projective coordinates.  A FLAGGED point is the identity whatever its coordinate words hold: it is loaded as the
+// canonical (0 : 1 : 0) -- (x : y : 0) with x != 0 is not a point of the curve and the complete formulas owe it nothing
+BN_DEV G1P load_g1_flagged(const u64* xy, const uint8_t* inf, size_t n, size_t i) {
+  const bool z = inf && inf[i];
+  return G1P{z ? fp_zero() : load_fp(xy, n, i, 0), z ? fp_one() : load_fp(xy, n, i, 4), z ? fp_zero() : fp_one()};
+}
 // tables: NULL = window tables in the stack frame, else a block of n * G1_TABLE_BYTES_PER_LANE bytes (lane i's table contiguous)
 __global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf, const u64* ks, u64* oxy, uint8_t* oinf, size_t n, uint8_t* tables) {
   size_t i = TID;
@@ -19,8 +25,7 @@ __global__ void HEAVY_BOUNDS k_g1_scalar_mul(const u64* pxy, const uint8_t* pinf
 __global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
-  G1P b{load_fp(bxy, n, i, 0), load_fp(bxy, n, i, 4), (binf && binf[i]) ? fp_zero() : fp_one()};
+  G1P a = load_g1_flagged(axy, ainf, n, i), b = load_g1_flagged(bxy, binf, n, i);
   G1P r = g1_add(a, b);
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, r);
@@ -31,8 +36,8 @@ __global__ void __launch_bounds__(BLOCK) k_g1_add(const u64* axy, const uint8_t*
 __global__ void __launch_bounds__(BLOCK) k_g1_sub(const u64* axy, const uint8_t* ainf, const u64* bxy, const uint8_t* binf, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
-  G1P b{load_fp(bxy, n, i, 0), fp_neg(load_fp(bxy, n, i, 4)), (binf && binf[i]) ? fp_zero() : fp_one()};
+  G1P a = load_g1_flagged(axy, ainf, n, i), b = load_g1_flagged(bxy, binf, n, i);
+  b.y = fp_neg(b.y);
   G1P r = g1_add(a, b);
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, r);
@@ -69,7 +74,7 @@ __global__ void HEAVY_BOUNDS k_g1_lincomb(const u64* pxy, const uint8_t* pinf, c
 #pragma unroll 1
   for (size_t t = 0; t < n_terms; ++t) {
     const size_t i = t * n_jobs + j;
-    G1P p{load_fp(pxy, n, i, 0), load_fp(pxy, n, i, 4), (pinf && pinf[i]) ? fp_zero() : fp_one()};
+    G1P p = load_g1_flagged(pxy, pinf, n, i);
     u32 k[8];
     load_scalar(k, ks, n, i);
     acc = g1_add(acc, g1_scalar_mul(p, k));
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(BLOCK) k_g1_from_bytes(const uint8_t* in, u64*
 __global__ void __launch_bounds__(BLOCK) k_g1_double(const u64* axy, const uint8_t* ainf, u64* oxy, uint8_t* oinf, size_t n) {
   size_t i = TID;
   if (i >= n) return;
-  G1P a{load_fp(axy, n, i, 0), load_fp(axy, n, i, 4), (ainf && ainf[i]) ? fp_zero() : fp_one()};
+  G1P a = load_g1_flagged(axy, ainf, n, i);
   G1P r = g1_double(a);
   Fp x, y; bool rinf;
   g1_to_affine(x, y, rinf, r);

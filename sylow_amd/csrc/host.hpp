@@ -89,6 +89,13 @@ int32_t verify_two_pairings_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_
 int32_t pairing_wide_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* scratch, uint64_t* gt_out, size_t n, void* stream);
 int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* hneg, const uint8_t* hneg_inf, const uint64_t* sig_xy, const uint8_t* sig_inf,
                           uint64_t* scratch, uint8_t* ok, size_t n, void* stream, int one_key = 0);
+// plk_quad.hip: mid-size batches on one lane QUAD per element (the lane-pair tower compiled with BN_QUAD 1); 0 from quad_batch_max = route off
+size_t quad_batch_max();
+int32_t pairing_quad_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream);
+int32_t miller_loop_quad_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
+int32_t final_exp_quad_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
+int32_t verify_fused_quad(int pk_is_table, const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint64_t* hneg, const uint8_t* hneg_inf,
+                          const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, void* stream);
 // plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
 }  // namespace plkh

@@ -206,7 +206,10 @@ BN_NOINLINE bool g2q_in_subgroup_proj(const G2Q& q_in) {
 }
 BN_DEV bool g2q_in_subgroup(const S2& x, const S2& y) { return g2q_in_subgroup_proj(G2Q{w2_from_s2(x), w2_from_s2(y), OpsW2::one()}); }
 BN_DEV G2Q load_g2q(const u64* xy, const uint8_t* inf, size_t n, size_t i, int odd) {
-  return G2Q{w2_from_s2(load_s2(xy, n, i, 0, odd)), w2_from_s2(load_s2(xy, n, i, 8, odd)), (inf && inf[i]) ? OpsW2::zero() : OpsW2::one()};
+  // a FLAGGED point is the identity whatever its coordinate words hold: the canonical (0 : 1 : 0), as load_g1_flagged (g1.hip)
+  const bool z = inf && inf[i];
+  const W2 zero = OpsW2::zero(), one = OpsW2::one();
+  return G2Q{z ? zero : w2_from_s2(load_s2(xy, n, i, 0, odd)), z ? one : w2_from_s2(load_s2(xy, n, i, 8, odd)), z ? zero : one};
 }
 BN_DEV void store_g2q_affine(u64* oxy, uint8_t* oinf, size_t n, size_t i, int odd, const G2Q& r) {      // r on E'
   S2 x, y; bool rinf;

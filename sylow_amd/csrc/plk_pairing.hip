@@ -67,6 +67,7 @@ BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, co
 __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, Stagger st) {
   ClockProbe pb;
   probe_begin(pb, st.clk);
+  wave_static_priority();
   pairing_body(pxy, pinf, qxy, qinf, gout, n, st);
   probe_end(pb, st.clk);
 }
@@ -148,11 +149,13 @@ int32_t sylow_hip_miller_loop_batch(const uint64_t* p_xy, const uint64_t* q_xy, 
   ARGCHK(p_xy && q_xy && f_out); if (!n) return SYLOW_HIP_OK;
   // small batches: one wavefront per one or two Miller loops on the reference's curves (same field values step by step: the raw value)
   if (n <= plkh::wide_batch_max()) return plkh::miller_raw_wide_batch(p_xy, q_xy, f_out, n, stream);
+  if (n <= plkh::quad_batch_max()) return plkh::miller_loop_quad_batch(p_xy, q_xy, f_out, n, stream);     // mid-size batches: a lane quad per element (plk_quad.hip)
   plk::k_miller_loop<<<GRID(2 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
 }
 int32_t sylow_hip_final_exp_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
   ARGCHK(f && gt_out); if (!n) return SYLOW_HIP_OK;
   if (n <= plkh::wide_batch_max()) return plkh::final_exp_wide_batch(f, gt_out, n, stream);      // small batches: one wavefront per one or two elements
+  if (n <= plkh::quad_batch_max()) return plkh::final_exp_quad_batch(f, gt_out, n, stream);
   plk::k_final_exp<<<GRID(2 * n)>>>(f, gt_out, n); LAUNCHED();
 }
 int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
@@ -167,6 +170,8 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
     const int32_t r2 = ws.release();
     return rc != SYLOW_HIP_OK ? rc : r2;
   }
+  // mid-size batches (up to one wavefront per SIMD of quads): a lane QUAD per element, 1.5 x the speed of a lone lane pair (plk_quad.hip)
+  if (n <= plkh::quad_batch_max()) return plkh::pairing_quad_batch(p_xy, p_inf, q_xy, q_inf, gt_out, n, stream);
   // staggered launch (see k_pairing): needs one full resident set of blocks (2 per CU) made of whole chunks
   hipStream_t st = (hipStream_t)stream;
   const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;

@@ -1,0 +1,86 @@
+// plk_quad.hip -- pairing() on lane QUADS: the whole lane-pair tower (bn254_pair29.hpp) compiled with BN_QUAD 1, for batches too small to fill
+// the chip with one lane pair per element.
+//
+// One lane pair per element is the most efficient shape (plk_pairing.hip: 32 elements per wavefront) but its latency is one whole pairing on
+// a single wavefront: 4.3 ms with one wavefront per SIMD -- the time of EVERY batch between the one-wavefront-per-element cap (6144) and
+// 32 768 elements, however few SIMDs it fills (round 5: 16 384 pairings at 3.8 M/s against 9.7 M/s at 2^20).  Here an element takes a quad
+// of lanes = two lane pairs holding the same state; every pair of independent product leaves is split between them and the results are
+// exchanged by one DPP quad permutation (bn254_pair29.hpp "leaf PAIRS").  Same formulas, same operand classes, the same integer into every
+// Montgomery reduction: Gt values are bit for bit those of k_pairing (tests/test_gpu_quad.py compares every row).
+#define BN_QUAD 1
+#include "plk_common.hpp"
+#include "plk_verify_body.hpp"
+
+namespace plk {
+// pairing.rs:870-893 -- thread t: role pair_role(t) of sub-pair quad_sub(t) of element quad_index(t); 16 elements per wavefront
+__global__ void HEAVY_BOUNDS k_pairing_quad(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n) {
+  const size_t t = TID, i = quad_index(t);
+  const int odd = pair_role(t);
+  if (i >= n) return;                                            // all four lanes of a quad leave together
+  const bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
+  S12 g;
+  if (either_zero) {
+    g = s12_one();
+  } else {
+    const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+    const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+    S12 f;
+    miller_loop29g<true, true>(f, px, py, qx, qy);               // isomorphic curves, as k_pairing: a factor in Fp*, gone after the next line
+    final_exponentiation29(g, f);
+  }
+  if (quad_sub(t) == 0) store_s12(gout, n, i, odd, g);
+}
+// raw Miller loop and final exponentiation on quads (the reference's curves: the raw value bit for bit)
+__global__ void HEAVY_BOUNDS k_miller_loop_quad(const u64* pxy, const u64* qxy, u64* fout, size_t n) {
+  const size_t t = TID, i = quad_index(t);
+  const int odd = pair_role(t);
+  if (i >= n) return;
+  const Fp px = load_fp(pxy, n, i, 0), py = load_fp(pxy, n, i, 4);
+  const S2 qx = load_s2(qxy, n, i, 0, odd), qy = load_s2(qxy, n, i, 8, odd);
+  S12 f;
+  miller_loop29g<true>(f, px, py, qx, qy);
+  if (quad_sub(t) == 0) store_s12(fout, n, i, odd, f);
+}
+__global__ void HEAVY_BOUNDS k_final_exp_quad(const u64* fin, u64* gout, size_t n) {
+  const size_t t = TID, i = quad_index(t);
+  const int odd = pair_role(t);
+  if (i >= n) return;
+  S12 f, g;
+  load_s12(f, fin, n, i, odd);
+  final_exponentiation29(g, f);
+  if (quad_sub(t) == 0) store_s12(gout, n, i, odd, g);
+}
+// lib.rs:223-236 as e(sig, G2gen) e(-H(m), pk) == 1 (plk_verify_body.hpp) on quads; never staggered (at most one wavefront per SIMD)
+template <bool PK_TABLE>
+__global__ void HEAVY_BOUNDS k_bls_verify_fused_quad(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table, const u64* hneg, const uint8_t* hneg_inf,
+                                                     const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n) {
+  const Stagger none{0, 0, 0, 0, nullptr, nullptr, nullptr};
+  bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, none);
+}
+}  // namespace plk
+
+namespace plkh {
+// Largest batch that takes a quad per element: up to one wavefront per SIMD of quads (16 per wavefront: 4 x CUs x 16 elements; 16 384 on this
+// part).  Above that the lane-pair kernel's single round is as fast.  SYLOW_HIP_OPT_QUAD_MAX moves it (0: never).
+size_t quad_batch_max() {
+  const long long o = host::option(SYLOW_HIP_OPT_QUAD_MAX);
+  if (o >= 0) return (size_t)o;
+  const unsigned cus = host::compute_units();
+  return (size_t)(cus ? cus : 256) * 4 * 16;
+}
+int32_t pairing_quad_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream) {
+  plk::k_pairing_quad<<<GRID(4 * n)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n); LAUNCHED();
+}
+int32_t miller_loop_quad_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
+  plk::k_miller_loop_quad<<<GRID(4 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
+}
+int32_t verify_fused_quad(int pk_is_table, const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint64_t* hneg, const uint8_t* hneg_inf,
+                          const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, void* stream) {
+  if (pk_is_table) plk::k_bls_verify_fused_quad<true><<<GRID(4 * n)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n);
+  else plk::k_bls_verify_fused_quad<false><<<GRID(4 * n)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n);
+  LAUNCHED();
+}
+int32_t final_exp_quad_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {
+  plk::k_final_exp_quad<<<GRID(4 * n)>>>(f, gt_out, n); LAUNCHED();
+}
+}  // namespace plkh

@@ -9,6 +9,9 @@ default build picks by batch size, so no single plain run covers every route for
                              default only batches above 16384 reach it; below, sign_wide.hip's eight lanes per signature)
   SYLOW_HIP_WIDE_PACK=0 / 1  the one-wavefront kernels of small batches with one element per wavefront at every size / two elements per
                              wavefront from two elements on (default: two above one wavefront per compute unit, up to 6144 pairings)
+  SYLOW_HIP_QUAD_MAX=0       no lane-quad kernels (plk_quad.hip): batches between the one-wavefront cap and 16384 elements run on one lane pair per element
+  SYLOW_HIP_QUAD_MAX=1048576 (with WIDE_TAIL=0) EVERY batch of pairings / Miller loops / final exponentiations / verifications of these files on
+                             one lane quad per element, single elements included
   SYLOW_HIP_AGG_FORK=0       the aggregate verifiers without their side stream
   SYLOW_HIP_STAGGER=0        k_pairing / k_bls_verify_fused launched plain (default from 2^17 elements: the launch is skewed by half a
                              period, plk_pairing.hip) -- the full-size C3 test is added to the files for this switch
@@ -27,14 +30,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_pairing.py", "tests/test_gpu_hash_bls.py", "tests/test_gpu_multi_pairing.py", "tests/test_gpu_evm.py",
          "tests/test_gpu_aggregate.py", "tests/test_gpu_lane_pair.py", "tests/test_gpu_precomputed.py", "tests/test_gpu_hash_chain.py", "tests/test_gpu_groups.py",
          "tests/test_gpu_fuzz_invariants.py", "tests/test_gpu_fr_threshold.py"]
-ROUTES = [{"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"}, {"SYLOW_HIP_STAGGER": "0"},
+ROUTES = [{"SYLOW_HIP_QUAD_MAX": "0"}, {"SYLOW_HIP_QUAD_MAX": "1048576", "SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_MULTI_TABLES": "0"}, {"SYLOW_HIP_MULTI_TABLES": "1"}, {"SYLOW_HIP_WIDE_TAIL": "0"}, {"SYLOW_HIP_AGG_FORK": "0"}, {"SYLOW_HIP_STAGGER": "0"},
           {"SYLOW_HIP_STAGGER": "2"}, {"SYLOW_HIP_WIDE_PACK": "0"}, {"SYLOW_HIP_WIDE_PACK": "1"},
           {"SYLOW_HIP_MULTI_TABLES": "0", "SYLOW_HIP_WIDE_TAIL": "0", "SYLOW_HIP_AGG_FORK": "0"}]
 
 
 @pytest.mark.parametrize("route", ROUTES, ids=lambda r: ",".join(f"{k[10:]}={v}" for k, v in r.items()))
 def test_forced_route_passes_the_same_tests(route):
-    if any(k.startswith("SYLOW_HIP_") and k in ("SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER") for k in os.environ):
+    if any(k.startswith("SYLOW_HIP_") and k in ("SYLOW_HIP_MULTI_TABLES", "SYLOW_HIP_WIDE_TAIL", "SYLOW_HIP_WIDE_PACK", "SYLOW_HIP_AGG_FORK", "SYLOW_HIP_STAGGER", "SYLOW_HIP_QUAD_MAX") for k in os.environ):
         pytest.skip("already inside a forced-route run")
     env = dict(os.environ, **route)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--deselect",

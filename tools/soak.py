@@ -60,7 +60,7 @@ while time.time() - t0 < budget:
     sig, sinf = eng.bls_sign(sk, msgs)
     sig2, _ = eng.bls_sign(sk, msgs)
     assert np.array_equal(sig, sig2), ("sign nondeterministic", nv)
-    ks = [int(rng.next() % nv) for _ in range(3)]          # a slice of the signatures and hashes against the oracle (eight-lane routes below 8192)
+    ks = [int(rng.next() % nv) for _ in range(3)]          # a slice of the signatures and hashes against the oracle (eight-lane routes up to 16384)
     es, _ = C.g1_to_affine(C.sign(sk[ks], [msgs[i] for i in ks]))
     assert np.array_equal(sig[ks], es), ("sign parity", nv, ks)
     hx, _ = eng.hash_to_g1([msgs[i] for i in ks])
