@@ -93,7 +93,9 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
  *   WIDE_MAX         largest batch of pairings on the one-wavefront route (default 6144)
  *   WIDE_VERIFY_MAX  largest batch of verifications on it (default 4096)
  *   QUAD_MAX         largest batch of pairings / Miller loops / final exponentiations / verifications on one lane QUAD per element
- *                    (plk_quad.hip; default: 64 x the CU count = 16384, one wavefront per SIMD; 0 never) */
+ *                    (plk_quad.hip; default: 64 x the CU count = 16384, one wavefront per SIMD; 0 never)
+ *   TAIL_SPLIT       1 (default) a batch of one to three whole rounds of one wavefront per SIMD (128 x the CU count = 32768 elements each) plus a
+ *                    tail that fits the quad route runs the tail on quads on a side stream beside the rounds, 0 one launch */
 #define SYLOW_HIP_OPT_STAGGER 0
 #define SYLOW_HIP_OPT_MULTI_TABLES 1
 #define SYLOW_HIP_OPT_WIDE_TAIL 2
@@ -103,7 +105,8 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
 #define SYLOW_HIP_OPT_WIDE_MAX 6
 #define SYLOW_HIP_OPT_WIDE_VERIFY_MAX 7
 #define SYLOW_HIP_OPT_QUAD_MAX 8
-#define SYLOW_HIP_OPT_COUNT 9
+#define SYLOW_HIP_OPT_TAIL_SPLIT 9
+#define SYLOW_HIP_OPT_COUNT 10
 int32_t sylow_hip_set_option(int32_t option, int64_t value);
 /* @shape value_host=i64[1] */
 int32_t sylow_hip_get_option(int32_t option, int64_t* value_host);      /* HOST pointer; -1 = the default is in force */

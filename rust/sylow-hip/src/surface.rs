@@ -782,7 +782,7 @@ pub fn set_scratch_limit(bytes: usize) -> Result<(), device::Error> {
 /// The library's route selectors and thresholds (`SYLOW_HIP_OPT_*` of include/sylow_hip.h; the library reads no environment variable).
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
 #[repr(i32)]
-pub enum RouteOption { Stagger = 0, MultiTables = 1, WideTail = 2, WidePack = 3, AggFork = 4, SignWideMax = 5, WideMax = 6, WideVerifyMax = 7, QuadMax = 8 }
+pub enum RouteOption { Stagger = 0, MultiTables = 1, WideTail = 2, WidePack = 3, AggFork = 4, SignWideMax = 5, WideMax = 6, WideVerifyMax = 7, QuadMax = 8, TailSplit = 9 }
 
 /// `sylow_hip_set_option`: `None` restores the default.  Process-wide; results do not depend on any setting.
 pub fn set_option(option: RouteOption, value: Option<u64>) -> Result<(), device::Error> {

@@ -154,7 +154,7 @@ _RESTYPE = {"sylow_hip_last_error": ctypes.c_char_p}
 # SYLOW_HIP_OPT_* of include/sylow_hip.h.  The LIBRARY reads no environment variable; this host layer does, once, when it loads the library:
 # SYLOW_HIP_<NAME>=<integer> becomes sylow_hip_set_option(<NAME>, value) -- what tests/test_gpu_routes.py and the A/B scripts under tools/ set
 OPTIONS = {"STAGGER": 0, "MULTI_TABLES": 1, "WIDE_TAIL": 2, "WIDE_PACK": 3, "AGG_FORK": 4, "SIGN_WIDE_MAX": 5, "WIDE_MAX": 6, "WIDE_VERIFY_MAX": 7,
-           "QUAD_MAX": 8}
+           "QUAD_MAX": 8, "TAIL_SPLIT": 9}
 
 
 class SylowHipError(RuntimeError):

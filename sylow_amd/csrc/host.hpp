@@ -35,6 +35,39 @@ unsigned compute_units();                                       // CUs of the ca
 long long option(int opt);                                      // sylow_hip_set_option: the value in force, -1 = the default (SYLOW_HIP_OPT_*)
 inline long long option_or(int opt, long long dflt) { const long long v = option(opt); return v < 0 ? dflt : v; }
 uint64_t* clock_probe();                                        // sylow_hip_clock_probe: the accumulator the metric's kernels add to, or NULL
+// A short-lived side stream for work that may run BESIDE what the caller's stream holds next (the aggregate verifiers' signature half beside the
+// hashing; the lane-quad tail of a batch beside its full rounds).  open(): the side stream waits for everything the caller's stream holds at this
+// point; join(): the caller's stream waits for the side work.  Any failure to create the stream or its events degrades to the caller's stream
+// (same results, no overlap), and so does enable = false.
+struct Fork {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t open(hipStream_t main, bool enable = true) {
+    if (!enable) return main;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; (void)hipGetLastError(); return main; }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      close();
+      return main;
+    }
+    return side;
+  }
+  int32_t join(hipStream_t main) {
+    if (!side) return SYLOW_HIP_OK;
+    hipError_t e = hipEventRecord(ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(side); return fail(e, "join of the side stream"); }
+    return SYLOW_HIP_OK;
+  }
+  void close() {     // destroying a stream / an event with work in flight is deferred by the runtime until that work completes
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+    ev_fork = ev_join = nullptr; side = nullptr;
+  }
+  ~Fork() { close(); }
+};
 }  // namespace host
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return host::fail(e_, #x); } while (0)
@@ -91,11 +124,12 @@ int32_t verify_wide_batch(const uint64_t* pk_xy, const uint8_t* pk_inf, const ui
                           uint64_t* scratch, uint8_t* ok, size_t n, void* stream, int one_key = 0);
 // plk_quad.hip: mid-size batches on one lane QUAD per element (the lane-pair tower compiled with BN_QUAD 1); 0 from quad_batch_max = route off
 size_t quad_batch_max();
-int32_t pairing_quad_batch(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, void* stream);
+size_t tail_split(size_t n);       // the remainder of a batch of whole rounds + a short tail that runs on quads beside the rounds, or 0
+int32_t pairing_quad_range(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, size_t m, void* stream);
 int32_t miller_loop_quad_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream);
 int32_t final_exp_quad_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream);
 int32_t verify_fused_quad(int pk_is_table, const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint64_t* hneg, const uint8_t* hneg_inf,
-                          const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, void* stream);
+                          const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, size_t m, void* stream);
 // plk_group.hip: EIP-197 pair decoding + validation into SoA arrays (one lane pair per 192-byte pair)
 int32_t evm_decode_pairs(const uint8_t* in, size_t n_pairs, uint64_t* pxy, uint8_t* pinf, uint64_t* qxy, uint8_t* qinf, uint8_t* pst, void* stream);
 }  // namespace plkh

@@ -1115,37 +1115,7 @@ int32_t sylow_hip_pairing_product_partial_batch(const uint64_t* p_xy, const uint
 // signatures and the one Miller loop it feeds run beside the batch's hashing instead of after it).  open(): the side stream waits for
 // everything the caller's stream holds at this point; join(): the caller's stream waits for the side work.  Any failure to create the
 // stream or its events degrades to the caller's stream (same results, no overlap); SYLOW_HIP_OPT_AGG_FORK = 0 forces that.
-namespace {
-struct Fork {
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipStream_t open(hipStream_t main) {
-    if (host::option(SYLOW_HIP_OPT_AGG_FORK) == 0) return main;
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; (void)hipGetLastError(); return main; }
-    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventRecord(ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      close();
-      return main;
-    }
-    return side;
-  }
-  int32_t join(hipStream_t main) {
-    if (!side) return SYLOW_HIP_OK;
-    hipError_t e = hipEventRecord(ev_join, side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
-    if (e != hipSuccess) { (void)hipStreamSynchronize(side); return host::fail(e, "join of the side stream"); }
-    return SYLOW_HIP_OK;
-  }
-  void close() {     // destroying a stream / an event with work in flight is deferred by the runtime until that work completes
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side) (void)hipStreamDestroy(side);
-    ev_fork = ev_join = nullptr; side = nullptr;
-  }
-  ~Fork() { close(); }
-};
-}  // namespace
+using host::Fork;
 static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, size_t n_pk, const uint8_t* msgs, const uint64_t* msg_offsets,
                                  const uint64_t* sig_xy, const uint8_t* sig_inf, const uint64_t* weights, size_t n, uint64_t* f_out, void* stream) {
   ARGCHK(f_out && (n == 0 || (pk_xy && msgs && msg_offsets && sig_xy && (n_pk == 1 || n_pk == n))));
@@ -1164,7 +1134,7 @@ static int32_t aggregate_partial(const uint64_t* pk_xy, const uint8_t* pk_inf, s
   // The G2gen half -- e(sum_i sig_i, G2gen), or e(sum_i w_i sig_i, G2gen) with weights: a (scalar multiplication,) summation tree and ONE
   // Miller loop, a few ms of pure latency -- depends on the signatures (and weights) only: it runs on a side stream beside the hashing.
   Fork fork;
-  hipStream_t sd = fork.open(st);
+  hipStream_t sd = fork.open(st, host::option(SYLOW_HIP_OPT_AGG_FORK) != 0);
   {
     const u64* sp = sig_xy;
     const uint8_t* spi = sig_inf;

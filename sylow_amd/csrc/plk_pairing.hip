@@ -33,7 +33,8 @@ __global__ void HEAVY_BOUNDS k_final_exp(const u64* fin, u64* gout, size_t n) {
 // in a leased block (role M), the blocks that follow them into those slots therefore start their Miller loops while their SIMD partners are
 // in the final exponentiation, and the parked values are finished by extra blocks at the end of the grid (role F).  Same arithmetic, same
 // results; 1.6 % of a 2^20 batch takes the detour through 384 bytes of HBM per element.
-BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, const Stagger& st) {
+// n = the SoA stride of every array, m <= n = the elements this launch covers (a batch whose tail runs on the lane-quad route beside it)
+BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, size_t m, const Stagger& st) {
   unsigned chunk;
   int role = stagger_role(st, chunk);
   const size_t t = (size_t)chunk * blockDim.x + threadIdx.x, i = pair_index(t);
@@ -47,7 +48,7 @@ BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, co
     store_s12(gout, n, i, odd, g);
     return;
   }
-  if (i >= n) return;
+  if (i >= m) return;
   const bool either_zero = (pinf && pinf[i]) || (qinf && qinf[i]);
   S12 g;
   if (either_zero) {
@@ -64,11 +65,11 @@ BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, co
   if (role == 1) { stagger_publish(st, chunk); return; }
   store_s12(gout, n, i, odd, g);
 }
-__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, Stagger st) {
+__global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, size_t m, Stagger st) {
   ClockProbe pb;
   probe_begin(pb, st.clk);
   wave_static_priority();
-  pairing_body(pxy, pinf, qxy, qinf, gout, n, st);
+  pairing_body(pxy, pinf, qxy, qinf, gout, n, m, st);
   probe_end(pb, st.clk);
 }
 
@@ -171,16 +172,26 @@ int32_t sylow_hip_pairing_batch(const uint64_t* p_xy, const uint8_t* p_inf, cons
     return rc != SYLOW_HIP_OK ? rc : r2;
   }
   // mid-size batches (up to one wavefront per SIMD of quads): a lane QUAD per element, 1.5 x the speed of a lone lane pair (plk_quad.hip)
-  if (n <= plkh::quad_batch_max()) return plkh::pairing_quad_batch(p_xy, p_inf, q_xy, q_inf, gt_out, n, stream);
-  // staggered launch (see k_pairing): needs one full resident set of blocks (2 per CU) made of whole chunks
+  if (n <= plkh::quad_batch_max()) return plkh::pairing_quad_range(p_xy, p_inf, q_xy, q_inf, gt_out, n, n, stream);
+  // A batch of k whole rounds of one wavefront per SIMD plus a short tail would leave the tail's few blocks as second wavefronts of their SIMDs
+  // for a whole extra pairing time (32 768 pairings 4.3 ms, 33 000: 7.3 ms): the tail takes the quad route on a side stream BESIDE the rounds
   hipStream_t st = (hipStream_t)stream;
-  const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
+  const size_t tail = plkh::tail_split(n), m = n - tail;
+  host::Fork fk;
+  hipStream_t side = tail ? fk.open(st) : st;
+  // staggered launch (see k_pairing): needs one full resident set of blocks (2 per CU) made of whole chunks
+  const size_t nblk = (2 * m + BLOCK - 1) / BLOCK, full = (2 * m) / BLOCK;
   plk::Stagger sg;
   host::Lease ws;
   HIPCHK(plkh::stagger_setup(sg, ws, nblk, full, st, plkh::blocks_per_cu(plk::k_pairing)));
-  plk::k_pairing<<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, st>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, sg);
+  plk::k_pairing<<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, st>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, m, sg);
   const hipError_t e = hipGetLastError();
-  const int32_t rc = ws.release();
+  int32_t rc = ws.release();
+  if (tail && e == hipSuccess && rc == SYLOW_HIP_OK) {
+    rc = plkh::pairing_quad_range(p_xy + m, p_inf ? p_inf + m : nullptr, q_xy + m, q_inf ? q_inf + m : nullptr, gt_out + m, n, tail, side);
+    const int32_t rj = fk.join(st);
+    if (rc == SYLOW_HIP_OK) rc = rj;
+  }
   return e != hipSuccess ? host::fail(e, "kernel launch") : rc;
 }
 // test hook: raw Fp12 selector.  0..11: the one-element-per-lane layer (tower.hip: 8 product on the carry-free core, 9 cyclotomic square on

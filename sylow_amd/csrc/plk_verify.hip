@@ -133,11 +133,11 @@ __global__ void HEAVY_BOUNDS k_bls_verify(const u64* pkxy, const uint8_t* pkinf,
 template <bool PK_TABLE>
 __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
                                                 const u64* hneg, const uint8_t* hneg_inf,
-                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, Stagger st) {
+                                                const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, size_t m, Stagger st) {
   ClockProbe pb;
   probe_begin(pb, st.clk);
   wave_static_priority();
-  bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, st);
+  bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, m, st);
   probe_end(pb, st.clk);
 }
 }  // namespace plk
@@ -161,20 +161,31 @@ static int32_t launch_fused(const uint64_t* pk_xy, const uint8_t* pk_inf, const 
   uint8_t* hinf = (uint8_t*)(hneg + 8 * n);
   rc = g1h::hash_to_g1(msgs, msg_offsets, hneg, hinf, n, /*negate=*/1, stream);
   if (rc == SYLOW_HIP_OK && n <= plkh::quad_batch_max()) {      // mid-size batches: a lane quad per element (plk_quad.hip)
-    rc = plkh::verify_fused_quad(PK_TABLE ? 1 : 0, pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n, stream);
+    rc = plkh::verify_fused_quad(PK_TABLE ? 1 : 0, pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n, n, stream);
     const int32_t r2 = ws.release();
     return rc != SYLOW_HIP_OK ? rc : r2;
   }
+  // whole rounds + a short tail: the tail on quads on a side stream beside the rounds (sylow_hip_pairing_batch, plk_pairing.hip); the side stream
+  // forks here, behind the hashing kernel
+  const size_t tail = rc == SYLOW_HIP_OK ? plkh::tail_split(n) : 0, m = n - tail;
+  host::Fork fk;
+  hipStream_t side = tail ? fk.open((hipStream_t)stream) : (hipStream_t)stream;
   plk::Stagger sg{0, 0, 0, 0, nullptr, nullptr, nullptr};
   host::Lease wp;
-  const size_t nblk = (2 * n + BLOCK - 1) / BLOCK, full = (2 * n) / BLOCK;
+  const size_t nblk = (2 * m + BLOCK - 1) / BLOCK, full = (2 * m) / BLOCK;
   if (rc == SYLOW_HIP_OK) {
     const hipError_t es = plkh::stagger_setup(sg, wp, nblk, full, (hipStream_t)stream, plkh::blocks_per_cu(plk::k_bls_verify_fused<PK_TABLE>));
     if (es != hipSuccess) rc = host::fail(es, "stagger flags");
   }
   if (rc == SYLOW_HIP_OK)
-    plk::k_bls_verify_fused<PK_TABLE><<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, (hipStream_t)stream>>>(pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n, sg);
-  const hipError_t e = hipGetLastError();
+    plk::k_bls_verify_fused<PK_TABLE><<<dim3((unsigned)(nblk + sg.count)), dim3(BLOCK), 0, (hipStream_t)stream>>>(pk_xy, pk_inf, pk_table, hneg, hinf, sig_xy, sig_inf, gen, ok, n, m, sg);
+  hipError_t e = hipGetLastError();
+  if (tail && rc == SYLOW_HIP_OK && e == hipSuccess) {
+    rc = plkh::verify_fused_quad(PK_TABLE ? 1 : 0, (PK_TABLE || !pk_xy) ? pk_xy : pk_xy + m, (PK_TABLE || !pk_inf) ? pk_inf : pk_inf + m, pk_table, hneg + m, hinf + m,
+                                 sig_xy + m, sig_inf ? sig_inf + m : nullptr, gen, ok + m, n, tail, side);
+    const int32_t rj = fk.join((hipStream_t)stream);
+    if (rc == SYLOW_HIP_OK) rc = rj;
+  }
   const int32_t r3 = wp.release();
   const int32_t r2 = ws.release();
   if (rc != SYLOW_HIP_OK) return rc;

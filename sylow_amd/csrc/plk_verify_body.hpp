@@ -23,7 +23,7 @@ BN_DEV i32 table_unit(const i32* tab, int at) { return tab[LINE_TABLE_LINES * 36
 template <bool PK_TABLE>
 BN_DEV void bls_verify_fused_body(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table,
                                   const u64* hneg, const uint8_t* hneg_inf,
-                                  const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, const Stagger& st) {
+                                  const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, size_t m, const Stagger& st) {
   __shared__ i32 tabA[LINE_TABLE_WORDS];
   __shared__ i32 tabB[PK_TABLE ? LINE_TABLE_WORDS : 1];
   // staggered launch (k_pairing, plk_pairing.hip): role 1 parks the two-pair Miller value, role 2 finishes a parked chunk
@@ -44,7 +44,7 @@ BN_DEV void bls_verify_fused_body(const u64* pkxy, const uint8_t* pkinf, const i
   stage_table(tabA, gen_table);
   if (PK_TABLE) stage_table(tabB, pk_table);
   __syncthreads();
-  const bool active = i < n;
+  const bool active = i < m;                 // n = the arrays' SoA stride, m <= n = the elements of this launch
   const size_t ii = active ? i : 0;          // out-of-range lanes recompute element 0 (uniform control flow), store nothing
   const Fp hxs = load_fp(hneg, n, ii, 0), hys = load_fp(hneg, n, ii, 4);     // pair B is (-H, pk)
   const bool hinf = hneg_inf[ii] != 0;

@@ -120,3 +120,54 @@ def test_verify_quad_route_every_row(engine, coracle, same_signer):
     sig_proj = np.concatenate([sigs[rows], one4], axis=1)
     exp = coracle.verify(pk_proj, [msgs[idx[r]] for r in rows], sig_proj).astype(np.uint8)
     assert np.array_equal(quad[rows], exp)
+
+
+@pytest.mark.parametrize("n", [32768 + 777, 65536 + 4099])
+def test_tail_split_every_row(engine, coracle, points, n):
+    """A batch of whole rounds (32768 elements each) plus a short tail: the tail runs on quads on a side stream beside the rounds' lane-pair grid
+    (plk_pairing.hip, plk_verify.hip: tail_split).  Every row of pairing_batch and every flag of bls_verify_batch equals the single-launch
+    route's (TAIL_SPLIT option 0); rows around the seam and in the tail against the oracle; identities and wrong signatures on both sides."""
+    from test_gpu_aggregate import signed_batch
+    p, q = points
+    d = p.shape[0]
+    idx = (np.arange(n) * 13 + 5) % d
+    seam = (n // 32768) * 32768
+    pinf, qinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    pinf[[3, seam - 1, seam, seam + 1, n - 1]] = 1
+    qinf[[4, seam + 2, n - 2]] = 1
+    dp, dq = engine.to_device_soa(p[idx], 8), engine.to_device_soa(q[idx], 16)
+    dpi, dqi, dg = engine.to_device(pinf), engine.to_device(qinf), engine.empty((48, n))
+    pk, msgs, sig = signed_batch(engine, 48, same_signer=False, seed=SEED + 62)
+    vid = idx % 48
+    sigs = sig[vid].copy()
+    bad = np.array([0, seam - 2, seam - 1, seam, seam + 1, seam + 300, n - 1])
+    sigs[bad] = sig[(vid[bad] + 1) % 48]
+    blob = b"".join(msgs[i] for i in vid)
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(msgs[i]) for i in vid])
+    dm, doff = engine.to_device(np.frombuffer(blob, dtype=np.uint8)), engine.to_device(off)
+    dsig, dpk, ok = engine.to_device_soa(sigs, 8), engine.to_device_soa(pk[vid], 16), engine.empty((n,), np.uint8)
+
+    def run():
+        dg.upload(np.zeros((48, n), dtype=np.uint64)); ok.upload(np.full(n, 7, dtype=np.uint8))
+        engine._call("sylow_hip_pairing_batch", dp.ptr, dpi.ptr, dq.ptr, dqi.ptr, dg.ptr, n)
+        engine._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n)
+        return engine.from_device_soa(dg), ok.download()
+
+    prev = engine.get_option("TAIL_SPLIT")
+    try:
+        engine.set_option("TAIL_SPLIT", 1)
+        g1, o1 = run()
+        engine.set_option("TAIL_SPLIT", 0)
+        g0, o0 = run()
+    finally:
+        engine.set_option("TAIL_SPLIT", prev)
+    assert np.array_equal(g1, g0) and np.array_equal(o1, o0)
+    want = np.ones(n, dtype=np.uint8); want[bad] = 0
+    assert np.array_equal(o1, want)
+    rows = np.concatenate([np.arange(seam - 8, seam + 24), np.arange(n - 8, n), [3, 4]])
+    one4 = np.zeros((d, 4), dtype=np.uint64); one4[:, 0] = 1
+    gt = coracle.pairing(np.concatenate([p, one4], axis=1), np.concatenate([q, one4, np.zeros((d, 4), dtype=np.uint64)], axis=1))
+    exp = gt[idx[rows]]
+    ident = np.zeros(48, dtype=np.uint64); ident[0] = 1
+    exp[(pinf | qinf)[rows].astype(bool)] = ident
+    assert np.array_equal(g1[rows], exp)

@@ -1,4 +1,5 @@
-"""Mid-size batches: pairing_batch on the quad route (plk_quad.hip) against the lane-pair route (QUAD_MAX option 0), same box, same inputs.
+"""Mid-size batches: pairing_batch / bls_verify_batch with the library defaults (lane-quad route up to 16384 elements, quad tails beside whole
+rounds: plk_quad.hip) against the lane-pair kernels alone (QUAD_MAX option 0), same box, same inputs.  Column "quad" = the defaults.
 usage: time_quad.py [sizes...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -6,7 +7,7 @@ import numpy as np
 import sylow_amd
 from bench import SEED, make_points
 eng = sylow_amd.Engine(0)   # SYLOW_HIP_LIB selects the build
-sizes = [int(x) for x in sys.argv[1:]] or [6144, 7168, 8192, 12288, 16384, 24576, 32768, 65536]
+sizes = [int(x) for x in sys.argv[1:]] or [6144, 7168, 8192, 12288, 16384, 24576, 32768, 33000, 40000, 49152, 65536, 70000, 81920, 98304, 100000, 114688, 131072]
 nmax = max(sizes)
 p, q, ka, kb = make_points(eng, nmax, SEED + 3)
 ph, qh = p.download(), q.download()
@@ -14,7 +15,7 @@ for n in sizes:
     dp, dq = eng.empty((8, n)).upload(np.ascontiguousarray(ph[:, :n])), eng.empty((16, n)).upload(np.ascontiguousarray(qh[:, :n]))
     dg = eng.empty((48, n))
     res = {}
-    for name, qm in (("pair", 0), ("quad", 1 << 20)):
+    for name, qm in (("pair", 0), ("quad", -1)):
         eng.set_option("QUAD_MAX", qm)
         eng._call("sylow_hip_pairing_batch", dp.ptr, None, dq.ptr, None, dg.ptr, n); eng.sync()
         best = 1e9
@@ -40,7 +41,7 @@ for n in sizes:
     dpk, dsig = eng.empty((16, n)).upload(np.ascontiguousarray(pkh[:, :n])), eng.empty((8, n)).upload(np.ascontiguousarray(sigh[:, :n]))
     ok = eng.empty((n,), np.uint8)
     res = {}
-    for name, qm in (("pair", 0), ("quad", 1 << 20)):
+    for name, qm in (("pair", 0), ("quad", -1)):
         eng.set_option("QUAD_MAX", qm)
         eng._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n); eng.sync()
         best = 1e9
