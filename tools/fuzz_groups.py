@@ -20,12 +20,19 @@ ONE4 = np.array([[1, 0, 0, 0]], dtype=np.uint64)
 r = R.R_ORDER
 EDGE = [0, 1, 2, 3, r - 1, r, r + 1, P - 1, (1 << 253) - 1, 1 << 127, (1 << 128) - 1, 17, 35, 4965661367192848881, 4965661367192848880]
 
+# A FLAGGED affine point is the identity whatever its coordinate words hold: what From<Affine> for Projective gives the reference is the
+# canonical (0 : 1 : 0) (group.rs:271-277), and that is what the oracle is fed (round 6: the group-law kernels load flagged points the same way)
 def g1_proj(xy, inf):
     z = np.repeat(ONE4, xy.shape[0], 0) * (1 - inf.astype(np.uint64))[:, None]
-    return np.concatenate([xy, z], axis=1)
+    out = np.concatenate([xy, z], axis=1)
+    out[inf.astype(bool)] = np.array([0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0], dtype=np.uint64)
+    return out
 def g2_proj(xy, inf):
     z = np.concatenate([np.repeat(ONE4, xy.shape[0], 0), np.zeros((xy.shape[0], 4), np.uint64)], axis=1) * (1 - inf.astype(np.uint64))[:, None]
-    return np.concatenate([xy, z], axis=1)
+    out = np.concatenate([xy, z], axis=1)
+    ident = np.zeros(24, dtype=np.uint64); ident[8] = 1
+    out[inf.astype(bool)] = ident
+    return out
 def scalars(n):
     ks = [rng.fp() for _ in range(n)]
     for j in range(min(n, 6)):
