@@ -315,4 +315,39 @@ inline std::vector<G1Affine> sub(const std::vector<G1Affine>& a, const std::vect
   return from_device_soa<G1Affine>(dout, n);
 }
 
+// ---- runtime knobs of the library (no reference counterpart: the reference is one element on one thread) -----------------------------------
+// Route selectors and thresholds (SYLOW_HIP_OPT_*): process-wide, results identical under every setting; value < 0 restores the default.
+inline void set_option(int32_t option, int64_t value) { check(sylow_hip_set_option(option, value), "sylow_hip_set_option"); }
+inline int64_t get_option(int32_t option) {
+  int64_t v = -1;
+  check(sylow_hip_get_option(option, &v), "sylow_hip_get_option");
+  return v;
+}
+// Live clock probe of the metric's kernels: arm() zeroes 256 device words and hands them to the library, read() returns the engine clock (MHz)
+// the wavefronts launched since arm() ran at (0 if none ran) and disarms.
+class ClockProbe {
+ public:
+  ClockProbe() : acc_(256 * sizeof(uint64_t)) {}
+  ~ClockProbe() { sylow_hip_clock_probe(nullptr); }
+  void arm() {
+    const std::vector<uint64_t> zero(256, 0);
+    check(sylow_hip_memcpy_h2d(acc_.as<void>(), zero.data(), zero.size() * 8, nullptr), "h2d"); check(sylow_hip_stream_sync(nullptr), "sync");
+    check(sylow_hip_clock_probe(acc_.as<uint64_t>()), "sylow_hip_clock_probe");
+  }
+  double read_mhz(uint64_t* wavefronts = nullptr) {
+    check(sylow_hip_stream_sync(nullptr), "sync");
+    check(sylow_hip_clock_probe(nullptr), "sylow_hip_clock_probe");
+    std::vector<uint64_t> w(256);
+    check(sylow_hip_memcpy_d2h(w.data(), acc_.as<void>(), w.size() * 8, nullptr), "d2h"); check(sylow_hip_stream_sync(nullptr), "sync");
+    int32_t khz = 0;
+    check(sylow_hip_wall_clock_khz(&khz), "sylow_hip_wall_clock_khz");
+    uint64_t clk = 0, wall = 0, waves = 0;
+    for (int s = 0; s < 64; ++s) { clk += w[4 * s]; wall += w[4 * s + 1]; waves += w[4 * s + 2]; }
+    if (wavefronts) *wavefronts = waves;
+    return wall ? (double)clk / (double)wall * khz / 1e3 : 0.0;
+  }
+ private:
+  DeviceBuffer acc_;
+};
+
 }  // namespace sylow

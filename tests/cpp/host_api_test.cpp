@@ -110,6 +110,23 @@ int main() {
       bool pinned_same = true;
       for (size_t i = 0; i < n; ++i) pinned_same = pinned_same && (gp[i] == plain[i]);
       std::printf("PIPELINE %d%d%d %zu\n", same ? 1 : 0, v1 == v2 ? 1 : 0, pinned_same ? 1 : 0, n - good);
+      // round 6: route options and the live clock probe through the C++ layer.  The same 70000 pairings with the quad tail switched off
+      // (TAIL_SPLIT 0: 70000 = two rounds of 32768 + 4464) and with the skew muted; the probe armed around a skewed launch of 2^17 + 5.
+      set_option(SYLOW_HIP_OPT_TAIL_SPLIT, 0);
+      auto no_tail = pairing(ps, qs);
+      set_option(SYLOW_HIP_OPT_TAIL_SPLIT, -1);
+      bool opt_same = get_option(SYLOW_HIP_OPT_TAIL_SPLIT) == -1;
+      for (size_t i = 0; i < n; ++i) opt_same = opt_same && (no_tail[i] == plain[i]);
+      std::vector<G1Affine> pb((1u << 17) + 5, ps[1]);
+      std::vector<G2Affine> qb(pb.size(), qs[1]);
+      ClockProbe probe;
+      probe.arm();
+      auto big = pairing(pb, qb);
+      uint64_t waves = 0;
+      const double mhz = probe.read_mhz(&waves);
+      bool big_same = true;
+      for (size_t i = 0; i < big.size(); ++i) big_same = big_same && (big[i] == plain[1]);
+      std::printf("OPTIONS %d%d %d %d\n", opt_same ? 1 : 0, big_same ? 1 : 0, (mhz > 500.0 && mhz < 3500.0) ? 1 : 0, waves >= 4 * ((2 * pb.size() + 255) / 256) ? 1 : 0);
     }
     return 0;
   } catch (const std::exception& e) {

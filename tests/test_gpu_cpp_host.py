@@ -46,6 +46,9 @@ def test_cpp_host_layer_runs(kats, coracle):
     # 70000 host elements through the two-stream pipeline == the unpipelined calls (pairing with identity flags, verify with two swapped
     # signatures = exactly 2 failures, pinned staging vectors)
     assert lines["PIPELINE"] == "111 2"
+    # round 6: sylow::set_option / get_option (TAIL_SPLIT 0 gives the same 70000 Gt values) and sylow::ClockProbe around a skewed launch of
+    # 2^17 + 5 pairings (identical values, a plausible engine clock, at least the launch's wavefronts counted)
+    assert lines["OPTIONS"] == "11 1 1"
     sk0 = np.array([[5, 0, 0, 0]], dtype=np.uint64)
     sig_ref, _ = coracle.g1_to_affine(coracle.sign(sk0, [bytes([0, 0, 0, 20])]))
     want = [sum(int(sig_ref[0, 4 * i + k]) << (64 * k) for k in range(4)) for i in range(2)]
