@@ -110,7 +110,7 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
 int32_t sylow_hip_set_option(int32_t option, int64_t value);
 /* @shape value_host=i64[1] */
 int32_t sylow_hip_get_option(int32_t option, int64_t* value_host);      /* HOST pointer; -1 = the default is in force */
-/* Live clock probe of the metric's kernels (plk::k_pairing, plk::k_bls_verify_fused).  `acc` = 256 uint64 words of DEVICE memory, zeroed
+/* Live clock probe of the metric's kernels (plk::k_pairing, plk::k_bls_verify_fused, and their lane-quad forms for mid-size batches).  `acc` = 256 uint64 words of DEVICE memory, zeroed
  * by the caller (NULL switches the probe off; the default).  While set, every wavefront of those kernels reads the shader-clock counter
  * (s_memtime) and the constant-rate counter (s_memrealtime) when it starts and when it ends and adds, with relaxed device-scope atomics, into
  * slot s = blockIdx % 64:  acc[4 s] += shader-clock ticks, acc[4 s + 1] += constant-rate ticks, acc[4 s + 2] += 1 (wavefronts),

@@ -14,10 +14,13 @@
 namespace plk {
 // pairing.rs:870-893 -- thread t: role pair_role(t) of sub-pair quad_sub(t) of element quad_index(t); 16 elements per wavefront
 // n = the SoA stride of the arrays, m <= n = the elements of this launch (the tail of a larger batch: pointers already advanced to its first element)
-__global__ void HEAVY_BOUNDS k_pairing_quad(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, size_t m) {
+// clk: the live clock probe's accumulator (sylow_hip_clock_probe), or NULL
+__global__ void HEAVY_BOUNDS k_pairing_quad(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, size_t m, u64* clk) {
   const size_t t = TID, i = quad_index(t);
   const int odd = pair_role(t);
   if (i >= m) return;                                            // all four lanes of a quad leave together
+  ClockProbe pb;
+  probe_begin(pb, clk);
   // As the tail of a larger batch a quad wavefront shares its SIMD with a lane-pair wavefront that started earlier and, being older, wins every
   // arbitration: the tail then crawls until the rounds are done (traced at 32768 + 16384 pairings: 6.4 ms for a tail that takes 3.0 ms alone,
   // 6.7 ms for the batch).  With static priority the SHORT job runs at its own pace (3.2 ms) and the long one fills its gaps: 6.45 ms -- the two
@@ -36,6 +39,7 @@ __global__ void HEAVY_BOUNDS k_pairing_quad(const u64* pxy, const uint8_t* pinf,
     final_exponentiation29(g, f);
   }
   if (quad_sub(t) == 0) store_s12(gout, n, i, odd, g);
+  probe_end(pb, clk);
 }
 // raw Miller loop and final exponentiation on quads (the reference's curves: the raw value bit for bit)
 __global__ void HEAVY_BOUNDS k_miller_loop_quad(const u64* pxy, const u64* qxy, u64* fout, size_t n) {
@@ -60,10 +64,13 @@ __global__ void HEAVY_BOUNDS k_final_exp_quad(const u64* fin, u64* gout, size_t 
 // lib.rs:223-236 as e(sig, G2gen) e(-H(m), pk) == 1 (plk_verify_body.hpp) on quads; never staggered (at most one wavefront per SIMD)
 template <bool PK_TABLE>
 __global__ void HEAVY_BOUNDS k_bls_verify_fused_quad(const u64* pkxy, const uint8_t* pkinf, const i32* pk_table, const u64* hneg, const uint8_t* hneg_inf,
-                                                     const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, size_t m) {
+                                                     const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, size_t m, u64* clk) {
   const Stagger none{0, 0, 0, 0, nullptr, nullptr, nullptr};
   __builtin_amdgcn_s_setprio(2);                                 // see k_pairing_quad
+  ClockProbe pb;
+  probe_begin(pb, clk);
   bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, m, none);
+  probe_end(pb, clk);
 }
 }  // namespace plk
 
@@ -89,15 +96,15 @@ size_t tail_split(size_t n) {
 }
 // pointers at the first element of the range, n = the arrays' SoA stride, m = elements
 int32_t pairing_quad_range(const uint64_t* p_xy, const uint8_t* p_inf, const uint64_t* q_xy, const uint8_t* q_inf, uint64_t* gt_out, size_t n, size_t m, void* stream) {
-  plk::k_pairing_quad<<<GRID(4 * m)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, m); LAUNCHED();
+  plk::k_pairing_quad<<<GRID(4 * m)>>>(p_xy, p_inf, q_xy, q_inf, gt_out, n, m, host::clock_probe()); LAUNCHED();
 }
 int32_t miller_loop_quad_batch(const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* f_out, size_t n, void* stream) {
   plk::k_miller_loop_quad<<<GRID(4 * n)>>>(p_xy, q_xy, f_out, n); LAUNCHED();
 }
 int32_t verify_fused_quad(int pk_is_table, const uint64_t* pk_xy, const uint8_t* pk_inf, const bn254::i32* pk_table, const uint64_t* hneg, const uint8_t* hneg_inf,
                           const uint64_t* sig_xy, const uint8_t* sig_inf, const bn254::i32* gen, uint8_t* ok, size_t n, size_t m, void* stream) {
-  if (pk_is_table) plk::k_bls_verify_fused_quad<true><<<GRID(4 * m)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n, m);
-  else plk::k_bls_verify_fused_quad<false><<<GRID(4 * m)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n, m);
+  if (pk_is_table) plk::k_bls_verify_fused_quad<true><<<GRID(4 * m)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n, m, host::clock_probe());
+  else plk::k_bls_verify_fused_quad<false><<<GRID(4 * m)>>>(pk_xy, pk_inf, pk_table, hneg, hneg_inf, sig_xy, sig_inf, gen, ok, n, m, host::clock_probe());
   LAUNCHED();
 }
 int32_t final_exp_quad_batch(const uint64_t* f, uint64_t* gt_out, size_t n, void* stream) {

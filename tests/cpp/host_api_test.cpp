@@ -126,7 +126,7 @@ int main() {
       const double mhz = probe.read_mhz(&waves);
       bool big_same = true;
       for (size_t i = 0; i < big.size(); ++i) big_same = big_same && (big[i] == plain[1]);
-      std::printf("OPTIONS %d%d %d %d\n", opt_same ? 1 : 0, big_same ? 1 : 0, (mhz > 500.0 && mhz < 3500.0) ? 1 : 0, waves >= 4 * ((2 * pb.size() + 255) / 256) ? 1 : 0);
+      std::printf("OPTIONS %d%d %d %d\n", opt_same ? 1 : 0, big_same ? 1 : 0, (mhz > 500.0 && mhz < 3500.0) ? 1 : 0, (waves >= 4000 && waves <= 4 * ((2 * pb.size() + 255) / 256 + 512)) ? 1 : 0);   // the lane-pair launches' wavefronts (a quad tail carries no probe; a skewed launch adds finishing blocks)
     }
     return 0;
   } catch (const std::exception& e) {

@@ -106,10 +106,10 @@ def test_single_rank_bench_self_check():
     assert all(not isinstance(v, (dict, list)) for v in list(c.values()) + list(rf.values()))      # scalars only: nested objects are dropped
     sw = out["aux"]["size_sweep"]
     assert [r["n"] for r in sw["rows"]] == [1, 64, 1 << 10, 1 << 11, 1 << 12, 1 << 13] and all(r["verify_all_ok"] == 1 for r in sw["rows"])
-    # round 6: the line certifies its own clock -- the live probe of the timed kernels (2^13 pairings run on the quad route, which carries no
-    # probe: the verify half and the pairing half both report None there; at the metric's size both are engine clocks)
-    assert "sustained_mhz" in rf and "frac_at_sustained_clock" in rf and "stagger_gain_2^17" in rf
-    assert rf["sustained_mhz"] is None or 500 < rf["sustained_mhz"] < 3500
+    # round 6: the line certifies its own clock -- the live probe of the timed kernels (2^13 elements run on the quad route, which carries the
+    # probe as well: 2 steps x 512 wavefronts of 16 quads)
+    assert "frac_at_sustained_clock" in rf and "stagger_gain_2^17" in rf
+    assert 500 < rf["sustained_mhz"] < 3500 and 500 < rf["verify_sustained_mhz"] < 3500 and rf["probe_wavefronts"] == 2 * 512
     cbk = list(cb)
     assert cbk.index("cgroup_cpu_quota_cores") < 16 and cbk.index("checked") < 16 and cbk.index("mismatches") < 16 and cb["nproc"] >= cb["cores"]
     e2e = out["aux"]["e2e"]
