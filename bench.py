@@ -17,14 +17,19 @@ verifications incl. the AND over ranks (`config.bls_verifies_per_s`, `config.bls
 One JSON line is printed by rank 0:
  * `roofline`      the roof that BINDS the dominant kernel, plk::k_pairing: VALU issue (cycle-weighted by instruction class) --
                    `achieved` = ideal issue cycles of one launch / its live HIP-event duration, `peak` = 1024 SIMDs x 2.4 GHz,
-                   `frac_clock_free` = the same ratio taken inside one rocprofv3 pass (no clock enters); the contract's HBM pricing
+                   `frac_clock_free` = the same ratio taken inside one rocprofv3 pass (no clock enters); LIVE in every run (round 6):
+                   `sustained_mhz` = the engine clock the K timed launches held (every wavefront adds its s_memtime / s_memrealtime
+                   deltas: sylow_hip_clock_probe), `simd_cycles_per_pairing_live` and `frac_at_sustained_clock` from it, and
+                   `stagger_gain_*` = plain / skewed launch times of an A/B run through the ABI option; the contract's HBM pricing
                    (576 algorithmic bytes per pairing: ~2x10^4 field multiplications on 576 bytes, tiny by nature) stays beside it as
                    `hbm_*`, `traffic` = HBM bytes per launch from the PMC counters; the verify kernel's figures are `verify_*`;
+                   the driver's record keeps a prefix of this object's keys, so what certifies the line comes first;
  * `aux`           the other BLS shapes at batch 2^20 (two-pairing form, same signer, aggregates, strong scaling), the batch-size sweep,
                    the end-to-end (host arrays in, host results out) pipeline, and at N = 1 the other single-GPU
                    configs (C2a Fp mul/add -- the HBM-bound kernels --, C2b G1 scalar-mul, C3 2^18 pairings, C5 byte-level
                    ecPairing) each with its own algorithmic GB/s and fraction of the HBM roof;
- * `cpu_baseline`  the C oracle (a port of the reference) on the host cores, the sign shape, the cargo probe, and an oracle
+ * `cpu_baseline`  the C oracle (a port of the reference) on the host cores -- the all-core loop runs inside the C library on POSIX
+                   threads, with nproc / affinity / cgroup quota beside it --, the sign shape, the cargo probe, and an oracle
                    spot check of rows the TIMED launches wrote (`checked` / `mismatches`).
 """
 import argparse
