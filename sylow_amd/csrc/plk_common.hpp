@@ -44,18 +44,6 @@ struct Stagger {
 // when it starts and when it ends; lane 0 adds the two deltas, a wavefront count and the longest residency into slot blockIdx % 64.  Four scalar
 // registers across the kernel and four fire-and-forget atomics per wavefront (32 768 wavefronts per 2^20 pairings): not measurable in the kernel's
 // time (same-box A/B in DESIGN.md section 8).
-// A/B knob (round 6): BN_SETPRIO = 1 gives the wavefront in the odd hardware slot of its SIMD static priority 1 over its
-// partner in the even slot (s_setprio; HW_ID bits 3:0 = the wave slot) -- the two resident wavefronts then do not alternate by age
-#ifndef BN_SETPRIO
-#define BN_SETPRIO 0
-#endif
-BN_DEV void wave_static_priority() {
-#if BN_SETPRIO
-  unsigned slot;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));
-  if (slot & 1u) __builtin_amdgcn_s_setprio(BN_SETPRIO);
-#endif
-}
 struct ClockProbe { u64 c0, w0; };
 BN_DEV void probe_begin(ClockProbe& pb, const u64* clk) {
   if (clk) { pb.c0 = __builtin_amdgcn_s_memtime(); pb.w0 = __builtin_amdgcn_s_memrealtime(); }

@@ -68,7 +68,6 @@ BN_DEV void pairing_body(const u64* pxy, const uint8_t* pinf, const u64* qxy, co
 __global__ void HEAVY_BOUNDS k_pairing(const u64* pxy, const uint8_t* pinf, const u64* qxy, const uint8_t* qinf, u64* gout, size_t n, size_t m, Stagger st) {
   ClockProbe pb;
   probe_begin(pb, st.clk);
-  wave_static_priority();
   pairing_body(pxy, pinf, qxy, qinf, gout, n, m, st);
   probe_end(pb, st.clk);
 }

@@ -136,7 +136,6 @@ __global__ void HEAVY_BOUNDS k_bls_verify_fused(const u64* pkxy, const uint8_t* 
                                                 const u64* sigxy, const uint8_t* siginf, const i32* gen_table, uint8_t* okout, size_t n, size_t m, Stagger st) {
   ClockProbe pb;
   probe_begin(pb, st.clk);
-  wave_static_priority();
   bls_verify_fused_body<PK_TABLE>(pkxy, pkinf, pk_table, hneg, hneg_inf, sigxy, siginf, gen_table, okout, n, m, st);
   probe_end(pb, st.clk);
 }
