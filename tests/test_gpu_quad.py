@@ -147,11 +147,21 @@ def test_tail_split_every_row(engine, coracle, points, n):
     dm, doff = engine.to_device(np.frombuffer(blob, dtype=np.uint8)), engine.to_device(off)
     dsig, dpk, ok = engine.to_device_soa(sigs, 8), engine.to_device_soa(pk[vid], 16), engine.empty((n,), np.uint8)
 
+    # one key for the whole batch (the line-table form of the fused check: the key's table is shared by the rounds and the tail)
+    pk1, msgs1, sig1 = signed_batch(engine, 48, same_signer=True, seed=SEED + 63)
+    sigs1 = sig1[vid].copy()
+    sigs1[bad] = sig[vid[bad]]                                        # a signature under ANOTHER key
+    blob1 = b"".join(msgs1[i] for i in vid)
+    off1 = np.zeros(n + 1, dtype=np.uint64); off1[1:] = np.cumsum([len(msgs1[i]) for i in vid])
+    dm1, doff1 = engine.to_device(np.frombuffer(blob1, dtype=np.uint8)), engine.to_device(off1)
+    dsig1, dpk1, ok1 = engine.to_device_soa(sigs1, 8), engine.to_device_soa(pk1, 16), engine.empty((n,), np.uint8)
+
     def run():
-        dg.upload(np.zeros((48, n), dtype=np.uint64)); ok.upload(np.full(n, 7, dtype=np.uint8))
+        dg.upload(np.zeros((48, n), dtype=np.uint64)); ok.upload(np.full(n, 7, dtype=np.uint8)); ok1.upload(np.full(n, 7, dtype=np.uint8))
         engine._call("sylow_hip_pairing_batch", dp.ptr, dpi.ptr, dq.ptr, dqi.ptr, dg.ptr, n)
         engine._call("sylow_hip_bls_verify_batch", dpk.ptr, None, dm.ptr, doff.ptr, dsig.ptr, None, ok.ptr, n)
-        return engine.from_device_soa(dg), ok.download()
+        engine._call("sylow_hip_bls_verify_same_signer_batch", dpk1.ptr, None, dm1.ptr, doff1.ptr, dsig1.ptr, None, ok1.ptr, n)
+        return engine.from_device_soa(dg), np.stack([ok.download(), ok1.download()])
 
     prev = engine.get_option("TAIL_SPLIT")
     try:
@@ -163,7 +173,7 @@ def test_tail_split_every_row(engine, coracle, points, n):
         engine.set_option("TAIL_SPLIT", prev)
     assert np.array_equal(g1, g0) and np.array_equal(o1, o0)
     want = np.ones(n, dtype=np.uint8); want[bad] = 0
-    assert np.array_equal(o1, want)
+    assert np.array_equal(o1[0], want) and np.array_equal(o1[1], want)
     rows = np.concatenate([np.arange(seam - 8, seam + 24), np.arange(n - 8, n), [3, 4]])
     one4 = np.zeros((d, 4), dtype=np.uint64); one4[:, 0] = 1
     gt = coracle.pairing(np.concatenate([p, one4], axis=1), np.concatenate([q, one4, np.zeros((d, 4), dtype=np.uint64)], axis=1))
