@@ -317,7 +317,7 @@ def single_gpu_configs(eng, torch, stream, p, q, ka, n, pmc_cfgs=None):
     for name, e in res.items():                      # both roofs for every configuration
         e.update(issue_fields((pmc_cfgs or {}).get(name)))
     # C1 (BASELINE.json configs[0], the reference's own bench shapes benches/pairing.rs:5-10, benches/sig.rs:10-21) as SINGLE device calls:
-    # latency, not throughput -- one Miller loop / final exponentiation spread over a wavefront ("the tails")
+    # latency, not throughput -- one Miller loop / final exponentiation spread over a wavefront (docs/DESIGN_LOG.md R5-8.4 .. R5-8.6)
     p1 = eng.empty((8, 1)).upload(np.ascontiguousarray(p.download()[:, :1]))
     q1 = eng.empty((16, 1)).upload(np.ascontiguousarray(q.download()[:, :1]))
     gt1 = eng.empty((48, 1))

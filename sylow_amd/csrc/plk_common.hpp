@@ -43,7 +43,7 @@ struct Stagger {
 // Live clock probe (include/sylow_hip.h: sylow_hip_clock_probe).  Every wavefront reads the shader-clock counter and the constant-rate counter
 // when it starts and when it ends; lane 0 adds the two deltas, a wavefront count and the longest residency into slot blockIdx % 64.  Four scalar
 // registers across the kernel and four fire-and-forget atomics per wavefront (32 768 wavefronts per 2^20 pairings): not measurable in the kernel's
-// time (same-box A/B in DESIGN.md section 8).
+// time (same-box A/B: profiles/r06_ab/r05_vs_r06.log).
 struct ClockProbe { u64 c0, w0; };
 BN_DEV void probe_begin(ClockProbe& pb, const u64* clk) {
   if (clk) { pb.c0 = __builtin_amdgcn_s_memtime(); pb.w0 = __builtin_amdgcn_s_memrealtime(); }

@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(BLOCK) k_gt_eq_flags(const u64* a, const u64* 
 }
 namespace plkh {
 // Small batches on one wavefront per one or two elements (k_miller_wide_batch / k_final_exp_wide_batch): up to this many pairings the
-// latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each, and one more half-round)
+// latency route beats the one-lane-pair kernels (2048 resident wavefronts of two elements each, and one more half-round; docs/DESIGN_LOG.md R5-8.3)
 // SYLOW_HIP_OPT_WIDE_MAX / _WIDE_VERIFY_MAX move the two caps (crossover runs, tools/dbg/time_small.py)
 size_t wide_batch_max() {
   const size_t v = (size_t)host::option_or(SYLOW_HIP_OPT_WIDE_MAX, 0);

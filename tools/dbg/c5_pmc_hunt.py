@@ -1,4 +1,4 @@
-"""Hunt for the rare wrong ecPairing result seen twice inside `rocprofv3 --pmc` passes of tools/prof_configs.py: the same
+"""Hunt for the rare wrong ecPairing result seen twice inside `rocprofv3 --pmc` passes of tools/prof_configs.py (docs/DESIGN_LOG.md): the same
 memory-pool history as the profile driver (G1 / G2 scalar multiplications with leased window tables first), then R rounds of
   3 x sylow_hip_evm_ecpairing_batch back to back (2^16 jobs of 2 pairs, every result must be 1, every status 0)
   1 x sylow_hip_multi_pairing_batch on the same points with Gt out (must be bit-identical to the first round's Gt)

@@ -47,7 +47,7 @@ def _runs(idx):
 
 
 def diagnose_ecpairing(eng, k, nj, res, st, d_in, d_off, d_res, d_st, jobs, first_downloads):
-    """Everything observable about a wrong ecPairing batch (seen twice in counter passes): which jobs, whether the device copy
+    """Everything observable about a wrong ecPairing batch (seen twice in counter passes, docs/DESIGN_LOG.md): which jobs, whether the device copy
     of the input still equals the host copy, whether repeating the call reproduces it."""
     z, e = np.flatnonzero(res == 0), np.flatnonzero(st != 0)
     print("ecPairing k=%d WRONG: %d zero results in runs %s; %d nonzero statuses in runs %s values %s" % (k, z.size, _runs(z)[:16], e.size, _runs(e)[:16], sorted(set(st[e].tolist()))), flush=True)
