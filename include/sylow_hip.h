@@ -116,7 +116,9 @@ int32_t sylow_hip_get_option(int32_t option, int64_t* value_host);      /* HOST 
  * slot s = blockIdx % 64:  acc[4 s] += shader-clock ticks, acc[4 s + 1] += constant-rate ticks, acc[4 s + 2] += 1 (wavefronts),
  * acc[4 s + 3] = max(constant-rate ticks of one wavefront).  sum(acc[4 s]) / sum(acc[4 s + 1]) x the constant rate
  * (sylow_hip_wall_clock_khz) is the engine clock those wavefronts ran at, weighted by residency: what bench.py reports as
- * roofline.sustained_mhz.  Process-wide; the pointer must stay valid until the probe is switched off and the stream is drained. */
+ * roofline.sustained_mhz.  Process-wide: one accumulator for whichever launches follow, so it must be memory of the device those launches run
+ * on (a host that drives several GPUs from one process probes one device at a time); the pointer must stay valid until the probe is switched off
+ * and the stream is drained. */
 /* @shape acc=u64[256]? */
 int32_t sylow_hip_clock_probe(uint64_t* acc);
 /* @shape khz_host=i32[1] */
