@@ -9,30 +9,49 @@
 using namespace bn254;
 using namespace bn254::pl;
 
+// two products per call, one operand shared (27 argument registers, 18 result registers): half the calls and returns per product
+// (a struct of 18 ints comes back through memory: a vector of 18 comes back in registers)
+typedef i32 i32x18 __attribute__((ext_vector_type(18)));
+struct F29x2 { F29 r0, r1; };
+__device__ __noinline__ i32x18 w2_mul_dual_shared_leaf(i32 a0, i32 a1, i32 a2, i32 a3, i32 a4, i32 a5, i32 a6, i32 a7, i32 a8,
+                                                      i32 b0, i32 b1, i32 b2, i32 b3, i32 b4, i32 b5, i32 b6, i32 b7, i32 b8,
+                                                      i32 c0, i32 c1, i32 c2, i32 c3, i32 c4, i32 c5, i32 c6, i32 c7, i32 c8) {
+  const W2 a{F29{{a0, a1, a2, a3, a4, a5, a6, a7, a8}}}, b{F29{{b0, b1, b2, b3, b4, b5, b6, b7, b8}}}, c{F29{{c0, c1, c2, c3, c4, c5, c6, c7, c8}}};
+  const F29 x = w2_mul_inl(a, b).c, y = w2_mul_inl(a, c).c;
+  return i32x18{x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8], y.v[0], y.v[1], y.v[2], y.v[3], y.v[4], y.v[5], y.v[6], y.v[7], y.v[8]};
+}
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_leaf_loop(i32* out, int n, int seed) {
-  W2 a, b;
+  W2 a, b, c;
+  for (int i = 0; i < 9; ++i) c.c.v[i] = (i32)((threadIdx.x * 7919u + i * 104729u + seed) & 0x0fffffff);
   for (int i = 0; i < 9; ++i) { a.c.v[i] = (i32)((threadIdx.x * 2654435761u + i * 40503u + seed) & 0x0fffffff); b.c.v[i] = (i32)((threadIdx.x * 40503u + i * 7919u + seed) & 0x0fffffff); }
 #pragma unroll 1
   for (int it = 0; it < n; ++it) {
     if (MODE == 0) a = w2_mul(a, b);                       // out-of-line leaf: call + return per product
     else if (MODE == 1) a = w2_mul_inl(a, b);              // the same product inlined: no control transfer but the loop branch
-    else { a = w2_mul(a, b); a = w2_reduce(w2_add(a, b)); }  // leaf + one reduce pass (the tower's rhythm)
+    else if (MODE == 2) { a = w2_mul(a, b); a = w2_reduce(w2_add(a, b)); }  // leaf + one reduce pass (the tower's rhythm)
+    else if (MODE == 3) { const W2 x = w2_mul(a, b), y = w2_mul(a, c); a = w2_add(x, y); a = w2_norm(a); c = w2_norm(w2_sub(x, y)); }   // two leaf calls per iteration
+    else {                                                                                                                             // the same two products in ONE call
+      const i32x18 d = w2_mul_dual_shared_leaf(W_ARGS(a.c), W_ARGS(b.c), W_ARGS(c.c));
+      const W2 x{F29{{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8]}}}, y{F29{{d[9], d[10], d[11], d[12], d[13], d[14], d[15], d[16], d[17]}}};
+      a = w2_norm(w2_add(x, y)); c = w2_norm(w2_sub(x, y));
+    }
   }
-  for (int i = 0; i < 9; ++i) out[(blockIdx.x * blockDim.x + threadIdx.x) * 9 + i] = a.c.v[i];
+  for (int i = 0; i < 9; ++i) out[(blockIdx.x * blockDim.x + threadIdx.x) * 9 + i] = a.c.v[i] ^ c.c.v[i];
 }
 int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int blocks = p.multiProcessorCount * 2, n = 20000;
   i32* out; hipMalloc(&out, (size_t)blocks * 256 * 9 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
-      if (mode == 0) k_leaf_loop<0><<<blocks, 256>>>(out, n, rep); else if (mode == 1) k_leaf_loop<1><<<blocks, 256>>>(out, n, rep); else k_leaf_loop<2><<<blocks, 256>>>(out, n, rep);
+      if (mode == 0) k_leaf_loop<0><<<blocks, 256>>>(out, n, rep); else if (mode == 1) k_leaf_loop<1><<<blocks, 256>>>(out, n, rep); else if (mode == 2) k_leaf_loop<2><<<blocks, 256>>>(out, n, rep);
+      else if (mode == 3) k_leaf_loop<3><<<blocks, 256>>>(out, n, rep); else k_leaf_loop<4><<<blocks, 256>>>(out, n, rep);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      if (rep) printf("mode %d (%s): %.3f ms for %d iterations = %.1f ns per iteration per wavefront pair\n", mode, mode == 0 ? "leaf call" : mode == 1 ? "leaf inlined" : "leaf call + reduce pass", ms, n, ms * 1e6 / n);
+      if (rep) printf("mode %d (%s): %.3f ms for %d iterations = %.1f ns per iteration per wavefront pair\n", mode, mode == 0 ? "leaf call" : mode == 1 ? "leaf inlined" : mode == 2 ? "leaf call + reduce pass" : mode == 3 ? "two leaf calls + norms" : "one dual-leaf call + norms", ms, n, ms * 1e6 / n);
     }
   }
   return 0;
