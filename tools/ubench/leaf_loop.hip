@@ -31,6 +31,10 @@ __global__ void __launch_bounds__(256, 2) k_leaf_loop(i32* out, int n, int seed)
     else if (MODE == 1) a = w2_mul_inl(a, b);              // the same product inlined: no control transfer but the loop branch
     else if (MODE == 2) { a = w2_mul(a, b); a = w2_reduce(w2_add(a, b)); }  // leaf + one reduce pass (the tower's rhythm)
     else if (MODE == 3) { const W2 x = w2_mul(a, b), y = w2_mul(a, c); a = w2_add(x, y); a = w2_norm(a); c = w2_norm(w2_sub(x, y)); }   // two leaf calls per iteration
+    else if (MODE == 5) {                                  // linear layer only: the passes the tower runs between leaf calls (xi-combination, lazy sums, carry normalisation), no product
+      const W2 x = w2_xi_lin(a, 1, b, 1), y = w2_lin2(c, 3, a, -2);
+      a = w2_norm(w2_add(x, y)); c = w2_norm(w2_sub(y, b));
+    }
     else {                                                                                                                             // the same two products in ONE call
       const i32x18 d = w2_mul_dual_shared_leaf(W_ARGS(a.c), W_ARGS(b.c), W_ARGS(c.c));
       const W2 x{F29{{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8]}}}, y{F29{{d[9], d[10], d[11], d[12], d[13], d[14], d[15], d[16], d[17]}}};
@@ -44,14 +48,14 @@ int main() {
   const int blocks = p.multiProcessorCount * 2, n = 20000;
   i32* out; hipMalloc(&out, (size_t)blocks * 256 * 9 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = 0; mode < 6; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
       if (mode == 0) k_leaf_loop<0><<<blocks, 256>>>(out, n, rep); else if (mode == 1) k_leaf_loop<1><<<blocks, 256>>>(out, n, rep); else if (mode == 2) k_leaf_loop<2><<<blocks, 256>>>(out, n, rep);
-      else if (mode == 3) k_leaf_loop<3><<<blocks, 256>>>(out, n, rep); else k_leaf_loop<4><<<blocks, 256>>>(out, n, rep);
+      else if (mode == 3) k_leaf_loop<3><<<blocks, 256>>>(out, n, rep); else if (mode == 4) k_leaf_loop<4><<<blocks, 256>>>(out, n, rep); else k_leaf_loop<5><<<blocks, 256>>>(out, n, rep);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      if (rep) printf("mode %d (%s): %.3f ms for %d iterations = %.1f ns per iteration per wavefront pair\n", mode, mode == 0 ? "leaf call" : mode == 1 ? "leaf inlined" : mode == 2 ? "leaf call + reduce pass" : mode == 3 ? "two leaf calls + norms" : "one dual-leaf call + norms", ms, n, ms * 1e6 / n);
+      if (rep) printf("mode %d (%s): %.3f ms for %d iterations = %.1f ns per iteration per wavefront pair\n", mode, mode == 0 ? "leaf call" : mode == 1 ? "leaf inlined" : mode == 2 ? "leaf call + reduce pass" : mode == 3 ? "two leaf calls + norms" : mode == 4 ? "one dual-leaf call + norms" : "linear passes only", ms, n, ms * 1e6 / n);
     }
   }
   return 0;
