@@ -94,7 +94,7 @@ int32_t sylow_hip_set_scratch_limit(size_t bytes);
  *   WIDE_VERIFY_MAX  largest batch of verifications on it (default 4096)
  *   QUAD_MAX         largest batch of pairings / Miller loops / final exponentiations / verifications on one lane QUAD per element
  *                    (plk_quad.hip; default: 64 x the CU count = 16384, one wavefront per SIMD; 0 never)
- *   TAIL_SPLIT       1 (default) a batch of one to three whole rounds of one wavefront per SIMD (128 x the CU count = 32768 elements each) plus a
+ *   TAIL_SPLIT       1 (default) a batch of one or two whole rounds of one wavefront per SIMD (128 x the CU count = 32768 elements each) plus a
  *                    tail that fits the quad route runs the tail on quads on a side stream beside the rounds, 0 one launch */
 #define SYLOW_HIP_OPT_STAGGER 0
 #define SYLOW_HIP_OPT_MULTI_TABLES 1

@@ -50,6 +50,6 @@ while time.time() - t0 < budget:
     ident = np.zeros(48, dtype=np.uint64); ident[0] = 1
     flagged = np.flatnonzero(pinf | qinf)
     assert all(np.array_equal(res[1][0][:, i], ident) for i in flagged[:64]), ("identity rule", seed, rounds, n)
-    quad_rounds += n <= 16384; tail_rounds += (n > 32768 and 0 < n % 32768 <= 16384)
+    quad_rounds += n <= 16384; tail_rounds += (32768 < n < 3 * 32768 and 0 < n % 32768 <= 16384)
     rounds += 1
 print("fuzz_mid ok: seed %s, %d rounds (%d on the quad route, %d with a quad tail), %.0f s" % (sys.argv[2] if len(sys.argv) > 2 else "1", rounds, quad_rounds, tail_rounds, time.time() - t0))
